@@ -1,0 +1,66 @@
+"""Build libbhcore.so (HIP, gfx950) in-tree with hipcc.  `python -m biahub_amd.build`."""
+
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+INCLUDE = PKG.parent / "include"
+LIB = PKG / "libbhcore.so"
+SOURCES = ["context.hip", "deskew.hip", "fill.hip", "deconv.hip", "affine.hip", "copy.hip"]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def needs_build() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.hpp", INCLUDE / "bhcore.h"]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    if not force and not needs_build():
+        return LIB
+    objdir = PKG / "build"
+    objdir.mkdir(exist_ok=True)
+    flags = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", f"-I{INCLUDE}", f"-I{CSRC}",
+             "-Wall", "-Wno-unused-function"]
+
+    def compile_one(src: str) -> Path:
+        obj = objdir / (src + ".o")
+        srcp = CSRC / src
+        hdr_t = max((CSRC / "common.hpp").stat().st_mtime, (INCLUDE / "bhcore.h").stat().st_mtime)
+        if not force and obj.exists() and obj.stat().st_mtime > max(srcp.stat().st_mtime, hdr_t):
+            return obj
+        cmd = [_hipcc(), *flags, "-c", str(srcp), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs),
+           "-L/opt/rocm/lib", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

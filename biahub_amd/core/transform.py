@@ -1,0 +1,158 @@
+"""Immutable homogeneous transform — mirror of ``biahub/core/transform.py`` for the 3-D hot path.
+
+``Transform.apply`` is the SciPy-semantics resample (``core/transform.py:374-396``): the stored
+matrix is a PUSH transform, the kernel pulls with its inverse, boundary mode "constant" (no
+interpolation past the edge, ``cval`` outside).  It runs in ``csrc/affine.hip`` with
+``BH_BOUNDARY_SCIPY_CONSTANT``; orders 0 and 1 are supported.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _lib
+
+
+class Transform:
+    """Homogeneous 3-D (4x4) or 2-D (3x3) transform; operations return new instances."""
+
+    __slots__ = ("_matrix", "_ndim", "_transform_type")
+
+    def __init__(self, matrix, transform_type: str = "affine"):
+        m = np.array(matrix, dtype=np.float64)
+        if m.ndim != 2 or m.shape[0] != m.shape[1] or m.shape[0] not in (3, 4):
+            raise ValueError(f"matrix must be 3x3 (2D) or 4x4 (3D), got shape {m.shape}")
+        m.setflags(write=False)
+        self._matrix = m
+        self._ndim = m.shape[0] - 1
+        self._transform_type = transform_type
+
+    # -- properties (core/transform.py:78-108) ------------------------------------------
+    @property
+    def matrix(self):
+        return self._matrix.copy()
+
+    @property
+    def ndim(self) -> int:
+        return self._ndim
+
+    @property
+    def transform_type(self) -> str:
+        return self._transform_type
+
+    @property
+    def translation(self):
+        return self._matrix[:-1, -1].copy()
+
+    @property
+    def linear(self):
+        return self._matrix[:-1, :-1].copy()
+
+    @property
+    def is_identity(self) -> bool:
+        return bool(np.allclose(self._matrix, np.eye(self._ndim + 1)))
+
+    # -- constructors (core/transform.py:110-166) ----------------------------------------
+    @classmethod
+    def identity(cls, ndim: int = 3) -> "Transform":
+        return cls(np.eye(ndim + 1), "identity")
+
+    @classmethod
+    def from_translation(cls, offset) -> "Transform":
+        offset = np.asarray(offset, dtype=np.float64)
+        m = np.eye(len(offset) + 1)
+        m[:-1, -1] = offset
+        return cls(m, "translation")
+
+    # -- algebra (core/transform.py:231-298) ----------------------------------------------
+    def invert(self) -> "Transform":
+        return Transform(np.linalg.inv(self._matrix), self._transform_type)
+
+    def compose(self, other: "Transform") -> "Transform":
+        if not isinstance(other, Transform):
+            raise TypeError(f"Cannot compose Transform with {type(other)}")
+        if other._ndim != self._ndim:
+            raise ValueError(f"Cannot compose {self._ndim}D transform with {other._ndim}D transform")
+        return Transform(self._matrix @ other._matrix, "affine")
+
+    def __matmul__(self, other):
+        return self.compose(other)
+
+    def apply_points(self, points):
+        points = np.asarray(points, dtype=np.float64)
+        if points.ndim != 2:
+            raise ValueError(f"points must be 2D array (N, D), got shape {points.shape}")
+        if points.shape[1] != self._ndim:
+            raise ValueError(f"points must have {self._ndim} columns, got {points.shape[1]}")
+        h = np.hstack([points, np.ones((points.shape[0], 1))])
+        return (self._matrix @ h.T).T[:, :-1]
+
+    # -- resampling (core/transform.py:321-396) -------------------------------------------
+    def apply(self, moving, reference=None, order: int = 1, mode: str = "constant", cval: float = 0.0,
+              backend: str = "scipy", device="cuda"):
+        """Resample ``moving`` into the reference grid on the GPU.
+
+        ``backend="scipy"`` -> SciPy "constant" boundary; ``backend="ants"`` -> ITK boundary rule.
+        Result dtype follows the reference: the input dtype for SciPy, float32 for ANTs.
+        """
+        from ..register import affine_device
+
+        moving = np.asarray(moving)
+        if moving.ndim != self._ndim:
+            raise ValueError(f"Expected {self._ndim}D array, got {moving.ndim}D")
+        if self._ndim != 3:
+            raise NotImplementedError("the GPU path resamples 3-D volumes only")
+        if backend not in ("scipy", "ants"):
+            raise ValueError(f"Unknown backend: {backend}")
+        if backend == "scipy" and mode != "constant":
+            raise NotImplementedError(f"boundary mode {mode!r} is not implemented on the GPU path")
+        if order not in (0, 1):
+            raise NotImplementedError("only interpolation orders 0 and 1 are implemented on the GPU path")
+        out_shape = reference.shape if reference is not None else moving.shape
+        inv = np.linalg.inv(self._matrix)
+        boundary = _lib.BOUNDARY_SCIPY_CONSTANT if backend == "scipy" else _lib.BOUNDARY_ITK
+        out = affine_device(moving, inv, out_shape, "linear" if order == 1 else "nearestneighbor", boundary,
+                            float(cval) if backend == "scipy" else 0.0, device=device).cpu().numpy()
+        if backend == "scipy" and moving.dtype != np.float32:
+            out = out.astype(moving.dtype)
+        return out
+
+    # -- ANTs parameter packing (core/transform.py:427-495) -------------------------------
+    def to_ants(self):
+        """The 12 (3-D) ITK AffineTransform parameters ``[A row-major ; t]`` (centre 0)."""
+        n = self._ndim
+        return np.concatenate([self._matrix[:n, :n].ravel(), self._matrix[:n, n]])
+
+    @classmethod
+    def from_ants(cls, parameters, fixed_parameters=None) -> "Transform":
+        p = np.asarray(parameters, dtype=np.float64)
+        n = 3 if p.size == 12 else 2
+        m = np.eye(n + 1)
+        m[:n, :n] = p[: n * n].reshape(n, n)
+        fixed = np.zeros(n) if fixed_parameters is None else np.asarray(fixed_parameters, dtype=np.float64)
+        m[:n, n] = p[n * n :] + (np.eye(n) - m[:n, :n]) @ fixed
+        return cls(m)
+
+    # -- (de)serialisation (core/transform.py:499-530) ------------------------------------
+    def to_list(self):
+        return self._matrix.tolist()
+
+    @classmethod
+    def from_list(cls, data, transform_type: str = "affine") -> "Transform":
+        return cls(np.array(data), transform_type)
+
+    def to_dict(self) -> dict:
+        return {"matrix": self.to_list(), "transform_type": self._transform_type, "ndim": self._ndim}
+
+    @classmethod
+    def from_dict(cls, data: dict) -> "Transform":
+        return cls(np.array(data["matrix"]), data.get("transform_type", "affine"))
+
+    def __repr__(self) -> str:
+        return f"Transform(ndim={self._ndim}, type={self._transform_type})"
+
+    def __eq__(self, other) -> bool:
+        return isinstance(other, Transform) and np.allclose(self._matrix, other._matrix)
+
+    def __hash__(self) -> int:
+        return hash(self._matrix.tobytes())

@@ -1,0 +1,188 @@
+// Context, error string, workspace and hipFFT plan cache of libbhcore.
+#include "common.hpp"
+
+#include <cstring>
+
+namespace bh {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int get_scratch(bh_ctx* ctx, const char* name, size_t bytes, void** out) {
+    Scratch& s = ctx->scratch[name];
+    if (s.bytes < bytes) {
+        if (s.ptr) {
+            BH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+            BH_CHECK_HIP(hipFree(s.ptr));
+            s.ptr = nullptr;
+            s.bytes = 0;
+        }
+        BH_CHECK_HIP(hipMalloc(&s.ptr, bytes));
+        s.bytes = bytes;
+    }
+    *out = s.ptr;
+    return BH_OK;
+}
+
+int get_plans(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, FftPlans** out) {
+    auto key = std::make_tuple(Z, Y, X);
+    auto it = ctx->plans.find(key);
+    if (it != ctx->plans.end()) {
+        *out = &it->second;
+        return BH_OK;
+    }
+    BH_REQUIRE(Z > 0 && Y > 0 && X > 0 && Z < (1ll << 31) && Y < (1ll << 31) && X < (1ll << 31),
+               "invalid FFT shape (%lld,%lld,%lld)", (long long)Z, (long long)Y, (long long)X);
+    FftPlans p;
+    size_t ws_r2c = 0, ws_c2r = 0;
+    BH_CHECK_FFT(hipfftCreate(&p.r2c));
+    BH_CHECK_FFT(hipfftSetAutoAllocation(p.r2c, 0));
+    BH_CHECK_FFT(hipfftMakePlan3d(p.r2c, (int)Z, (int)Y, (int)X, HIPFFT_R2C, &ws_r2c));
+    BH_CHECK_FFT(hipfftCreate(&p.c2r));
+    BH_CHECK_FFT(hipfftSetAutoAllocation(p.c2r, 0));
+    BH_CHECK_FFT(hipfftMakePlan3d(p.c2r, (int)Z, (int)Y, (int)X, HIPFFT_C2R, &ws_c2r));
+    p.work_bytes = ws_r2c > ws_c2r ? ws_r2c : ws_c2r;
+    if (p.work_bytes) {
+        // one work area shared by both directions (they never run concurrently on one stream)
+        BH_CHECK_HIP(hipMalloc(&p.work, p.work_bytes));
+        BH_CHECK_FFT(hipfftSetWorkArea(p.r2c, p.work));
+        BH_CHECK_FFT(hipfftSetWorkArea(p.c2r, p.work));
+    }
+    BH_CHECK_FFT(hipfftSetStream(p.r2c, ctx->stream));
+    BH_CHECK_FFT(hipfftSetStream(p.c2r, ctx->stream));
+    auto ins = ctx->plans.emplace(key, p);
+    *out = &ins.first->second;
+    return BH_OK;
+}
+
+}  // namespace bh
+
+extern "C" {
+
+int bh_abi_version(void) { return BH_ABI_VERSION; }
+
+const char* bh_last_error(void) { return bh::g_err; }
+
+int bh_device_count(int* count) {
+    BH_REQUIRE(count != nullptr, "count is NULL");
+    BH_CHECK_HIP(hipGetDeviceCount(count));
+    return BH_OK;
+}
+
+int bh_ctx_create(int device, void* hip_stream, bh_ctx** out) {
+    BH_REQUIRE(out != nullptr, "out is NULL");
+    int n = 0;
+    BH_CHECK_HIP(hipGetDeviceCount(&n));
+    BH_REQUIRE(device >= 0 && device < n, "device %d out of range (have %d)", device, n);
+    BH_CHECK_HIP(hipSetDevice(device));
+    bh_ctx* c = new bh_ctx();
+    c->device = device;
+    c->stream = (hipStream_t)hip_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    for (int i = 0; i < 2 * bh::T_COUNT; ++i) BH_CHECK_HIP(hipEventCreate(&c->ev[i]));
+    *out = c;
+    return BH_OK;
+}
+
+int bh_ctx_release_workspace(bh_ctx* ctx) {
+    BH_REQUIRE(ctx != nullptr, "ctx is NULL");
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    BH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& kv : ctx->plans) {
+        if (kv.second.r2c) hipfftDestroy(kv.second.r2c);
+        if (kv.second.c2r) hipfftDestroy(kv.second.c2r);
+        if (kv.second.work) (void)hipFree(kv.second.work);
+    }
+    ctx->plans.clear();
+    for (auto& kv : ctx->scratch)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    ctx->scratch.clear();
+    return BH_OK;
+}
+
+int bh_ctx_workspace_bytes(bh_ctx* ctx, uint64_t* bytes) {
+    BH_REQUIRE(ctx != nullptr && bytes != nullptr, "NULL argument");
+    uint64_t b = 0;
+    for (auto& kv : ctx->plans) b += kv.second.work_bytes;
+    for (auto& kv : ctx->scratch) b += kv.second.bytes;
+    *bytes = b;
+    return BH_OK;
+}
+
+int bh_ctx_destroy(bh_ctx* ctx) {
+    if (!ctx) return BH_OK;
+    bh_ctx_release_workspace(ctx);
+    for (int i = 0; i < 2 * bh::T_COUNT; ++i)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    delete ctx;
+    return BH_OK;
+}
+
+int bh_ctx_set_stream(bh_ctx* ctx, void* hip_stream) {
+    BH_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->stream = (hipStream_t)hip_stream;
+    for (auto& kv : ctx->plans) {
+        BH_CHECK_FFT(hipfftSetStream(kv.second.r2c, ctx->stream));
+        BH_CHECK_FFT(hipfftSetStream(kv.second.c2r, ctx->stream));
+    }
+    return BH_OK;
+}
+
+int bh_ctx_synchronize(bh_ctx* ctx) {
+    BH_REQUIRE(ctx != nullptr, "ctx is NULL");
+    BH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return BH_OK;
+}
+
+int bh_ctx_set_timing(bh_ctx* ctx, int enabled) {
+    BH_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->timing = enabled != 0;
+    return BH_OK;
+}
+
+int bh_last_elapsed_ms(bh_ctx* ctx, int what, float* ms) {
+    BH_REQUIRE(ctx != nullptr && ms != nullptr, "NULL argument");
+    BH_REQUIRE(what >= 0 && what < bh::T_COUNT, "unknown timer slot %d", what);
+    if (what == bh::T_RL_ITER) {
+        *ms = ctx->ms_override[what];
+        return BH_OK;
+    }
+    BH_REQUIRE(ctx->ev_valid[what], "no timed call recorded for slot %d (enable bh_ctx_set_timing)", what);
+    BH_CHECK_HIP(hipEventSynchronize(ctx->ev[2 * what + 1]));
+    BH_CHECK_HIP(hipEventElapsedTime(ms, ctx->ev[2 * what], ctx->ev[2 * what + 1]));
+    return BH_OK;
+}
+
+int bh_malloc(void** dptr, uint64_t bytes) {
+    BH_REQUIRE(dptr != nullptr, "dptr is NULL");
+    BH_CHECK_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return BH_OK;
+}
+
+int bh_free(void* dptr) {
+    if (dptr) BH_CHECK_HIP(hipFree(dptr));
+    return BH_OK;
+}
+
+int bh_memcpy_h2d(bh_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+    BH_REQUIRE(ctx != nullptr, "ctx is NULL");
+    BH_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    BH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return BH_OK;
+}
+
+int bh_memcpy_d2h(bh_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+    BH_REQUIRE(ctx != nullptr, "ctx is NULL");
+    BH_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return BH_OK;
+}
+
+}  // extern "C"

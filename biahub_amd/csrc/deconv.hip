@@ -1,0 +1,352 @@
+// FFT deconvolution on gfx950: transfer function (C1), Tikhonov inverse filter (C2) and
+// Richardson-Lucy (C3).  3-D real FFTs go through hipFFT (R2C / C2R, half spectrum); every
+// pointwise step between them is a fused HIP kernel here.
+//
+//   C1  biahub/deconvolve.py:30-43   H = |fftn(pad(psf))| / max          -> bh_transfer_function
+//   C2  biahub/deconvolve.py:46-66   real(ifftn(fftn(x) * H / (H^2 + reg))) (H real >= 0)
+//   C3  north-star extension         Richardson-Lucy, circular boundary
+//
+// All spectra are Hermitian halves (Z, Y, X/2+1) of complex64; H is real and even, so the
+// half-spectrum filter is exactly the reference's full-spectrum product.
+#include "common.hpp"
+
+namespace bh {
+
+typedef float2 cf;
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// sum of the PSF in double (wavefront reduction -> one partial per block -> host-free finalize)
+__global__ __launch_bounds__(256) void psf_sum_kernel(const float* __restrict__ psf, int64_t n, double* out) {
+    __shared__ double sh[4];
+    double s = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)psf[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// scatter the (optionally normalised, optionally origin-centred) PSF into a zeroed volume.
+// before[] = leading zero-pad per axis (deconvolve.py:34-35: odd remainder goes to the END);
+// roll[]   = circular shift applied to the destination index (0 for C1).
+__global__ void place_psf_kernel(const float* __restrict__ psf, float* __restrict__ vol, int pz, int py, int px,
+                                 int64_t Z, int64_t Y, int64_t X, int bz, int by, int bx, int rz, int ry, int rx,
+                                 const double* __restrict__ psf_sum) {
+    const int64_t n = (int64_t)pz * py * px;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % px), y = (int)((i / px) % py), z = (int)(i / ((int64_t)px * py));
+        int64_t dz = (z + bz - rz) % Z, dy = (y + by - ry) % Y, dx = (x + bx - rx) % X;
+        if (dz < 0) dz += Z;
+        if (dy < 0) dy += Y;
+        if (dx < 0) dx += X;
+        float v = psf[i];
+        if (psf_sum) {
+            // normalise in double like the oracle: float(psf / sum)
+            v = (float)((double)v / *psf_sum);
+        }
+        vol[(dz * Y + dy) * X + dx] = v;
+    }
+}
+
+// |S| in place into a float array + global max (non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void abs_max_kernel(const cf* __restrict__ spec, float* __restrict__ mag, int64_t n,
+                                                      unsigned int* gmax) {
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cf c = spec[i];
+        const float a = hypotf(c.x, c.y);
+        mag[i] = a;
+        m = fmaxf(m, a);
+    }
+    __shared__ float sh[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        atomicMax(gmax, __float_as_uint(m));
+    }
+}
+
+// expand the half-spectrum magnitude to the reference's full (Z,Y,X) array, dividing by the max
+__global__ void tf_expand_kernel(const float* __restrict__ mag, float* __restrict__ tf, int64_t Z, int64_t Y,
+                                 int64_t X, const unsigned int* gmax) {
+    const int64_t Xh = X / 2 + 1;
+    const int64_t n = Z * Y * X;
+    const float mx = __uint_as_float(*gmax);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t x = i % X, y = (i / X) % Y, z = i / (X * Y);
+        float v;
+        if (x < Xh) {
+            v = mag[(z * Y + y) * Xh + x];
+        } else {  // Hermitian mirror: |F(k)| = |F(-k)|
+            const int64_t zz = z ? Z - z : 0, yy = y ? Y - y : 0;
+            v = mag[(zz * Y + yy) * Xh + (X - x)];
+        }
+        tf[i] = v / mx;
+    }
+}
+
+// S *= H / (H^2 + reg) / V   with H read from the FULL-spectrum float array the reference passes
+__global__ void tikhonov_filter_kernel(cf* __restrict__ spec, const float* __restrict__ tf, int64_t Z, int64_t Y,
+                                       int64_t X, float reg, float inv_v) {
+    const int64_t Xh = X / 2 + 1;
+    const int64_t n = Z * Y * Xh;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t x = i % Xh;
+        const int64_t zy = i / Xh;
+        const float h = tf[zy * X + x];
+        const float f = (h / (h * h + reg)) * inv_v;
+        cf c = spec[i];
+        c.x *= f;
+        c.y *= f;
+        spec[i] = c;
+    }
+}
+
+// ---- Richardson-Lucy pointwise kernels (float4 / 2x complex per lane) ---------------------
+__global__ void scale_spectrum_kernel(cf* __restrict__ s, int64_t n, float f) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        cf c = s[i];
+        c.x *= f;
+        c.y *= f;
+        s[i] = c;
+    }
+}
+
+template <bool CONJ>
+__global__ __launch_bounds__(256) void cmul_kernel(cf* __restrict__ s, const cf* __restrict__ otf, int64_t n2) {
+    // n2 = number of complex PAIRS (float4); caller handles an odd tail element separately
+    float4* s4 = reinterpret_cast<float4*>(s);
+    const float4* o4 = reinterpret_cast<const float4*>(otf);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 a = s4[i];
+        const float4 b = o4[i];
+        float4 r;
+        if (CONJ) {
+            r.x = a.x * b.x + a.y * b.y;
+            r.y = a.y * b.x - a.x * b.y;
+            r.z = a.z * b.z + a.w * b.w;
+            r.w = a.w * b.z - a.z * b.w;
+        } else {
+            r.x = a.x * b.x - a.y * b.y;
+            r.y = a.x * b.y + a.y * b.x;
+            r.z = a.z * b.z - a.w * b.w;
+            r.w = a.z * b.w + a.w * b.z;
+        }
+        s4[i] = r;
+    }
+}
+
+template <bool CONJ>
+__global__ void cmul_tail_kernel(cf* __restrict__ s, const cf* __restrict__ otf, int64_t i) {
+    const cf a = s[i], b = otf[i];
+    cf r;
+    if (CONJ) {
+        r.x = a.x * b.x + a.y * b.y;
+        r.y = a.y * b.x - a.x * b.y;
+    } else {
+        r.x = a.x * b.x - a.y * b.y;
+        r.y = a.x * b.y + a.y * b.x;
+    }
+    s[i] = r;
+}
+
+// blur <- d / max(blur, eps)
+__global__ __launch_bounds__(256) void ratio_kernel(float* __restrict__ blur, const float* __restrict__ d, int64_t n,
+                                                    float eps) {
+    const int64_t n4 = n / 4;
+    float4* b4 = reinterpret_cast<float4*>(blur);
+    const float4* d4 = reinterpret_cast<const float4*>(d);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 b = b4[i];
+        const float4 v = d4[i];
+        b.x = v.x / fmaxf(b.x, eps);
+        b.y = v.y / fmaxf(b.y, eps);
+        b.z = v.z / fmaxf(b.z, eps);
+        b.w = v.w / fmaxf(b.w, eps);
+        b4[i] = b;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        blur[i] = d[i] / fmaxf(blur[i], eps);
+    }
+}
+
+// est <- max(est * corr, 0)
+__global__ __launch_bounds__(256) void update_kernel(float* __restrict__ est, const float* __restrict__ corr, int64_t n) {
+    const int64_t n4 = n / 4;
+    float4* e4 = reinterpret_cast<float4*>(est);
+    const float4* c4 = reinterpret_cast<const float4*>(corr);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 e = e4[i];
+        const float4 c = c4[i];
+        e.x = fmaxf(e.x * c.x, 0.0f);
+        e.y = fmaxf(e.y * c.y, 0.0f);
+        e.z = fmaxf(e.z * c.z, 0.0f);
+        e.w = fmaxf(e.w * c.w, 0.0f);
+        e4[i] = e;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        est[i] = fmaxf(est[i] * corr[i], 0.0f);
+    }
+}
+
+// out <- max(in, 0)
+__global__ void clip_copy_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = fmaxf(in[i], 0.0f);
+}
+
+static inline dim3 grid_for(bh_ctx* ctx, int64_t n, int tb = 256) {
+    int64_t g = ceil_div(n, tb);
+    const int64_t cap = (int64_t)ctx->num_cus * 8;
+    return dim3((unsigned)std::max<int64_t>(1, std::min(g, cap)));
+}
+
+static void pad_before(int64_t p, int64_t S, int* before) { *before = (int)((S - p) / 2); }
+
+}  // namespace bh
+
+using namespace bh;
+
+extern "C" {
+
+int bh_transfer_function(bh_ctx* ctx, const float* psf, int64_t pz, int64_t py, int64_t px, int64_t Z, int64_t Y,
+                         int64_t X, float* tf_full) {
+    BH_REQUIRE(ctx && psf && tf_full, "NULL argument");
+    BH_REQUIRE(pz > 0 && py > 0 && px > 0, "invalid PSF shape");
+    BH_REQUIRE(pz <= Z && py <= Y && px <= X, "PSF (%lld,%lld,%lld) larger than volume (%lld,%lld,%lld)",
+               (long long)pz, (long long)py, (long long)px, (long long)Z, (long long)Y, (long long)X);
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    ScopedTimer timer(ctx, T_TF);
+    FftPlans* pl;
+    BH_TRY(get_plans(ctx, Z, Y, X, &pl));
+    const int64_t V = Z * Y * X, Xh = X / 2 + 1, NS = Z * Y * Xh;
+    float* real;
+    cf* spec;
+    unsigned int* gmax;
+    BH_TRY(get_scratch(ctx, "fft_real", V * sizeof(float), (void**)&real));
+    BH_TRY(get_scratch(ctx, "fft_spec", NS * sizeof(cf), (void**)&spec));
+    BH_TRY(get_scratch(ctx, "tf_max", 64, (void**)&gmax));
+    hipStream_t s = ctx->stream;
+    BH_CHECK_HIP(hipMemsetAsync(real, 0, V * sizeof(float), s));
+    BH_CHECK_HIP(hipMemsetAsync(gmax, 0, 4, s));
+    int bz, by, bx;
+    pad_before(pz, Z, &bz);
+    pad_before(py, Y, &by);
+    pad_before(px, X, &bx);
+    hipLaunchKernelGGL(place_psf_kernel, grid_for(ctx, pz * py * px), dim3(256), 0, s, psf, real, (int)pz, (int)py,
+                       (int)px, Z, Y, X, bz, by, bx, 0, 0, 0, (const double*)nullptr);
+    BH_CHECK_FFT(hipfftExecR2C(pl->r2c, real, (hipfftComplex*)spec));
+    // magnitude goes into the (now free) real buffer: NS floats <= V + slack? NS*4 <= V*4 only when Xh <= X
+    float* mag;
+    BH_TRY(get_scratch(ctx, "tf_mag", NS * sizeof(float), (void**)&mag));
+    hipLaunchKernelGGL(abs_max_kernel, grid_for(ctx, NS), dim3(256), 0, s, spec, mag, NS, gmax);
+    hipLaunchKernelGGL(tf_expand_kernel, grid_for(ctx, V), dim3(256), 0, s, mag, tf_full, Z, Y, X, gmax);
+    BH_CHECK_HIP(hipGetLastError());
+    return BH_OK;
+}
+
+int bh_tikhonov(bh_ctx* ctx, const float* in, const float* tf_full, int64_t Z, int64_t Y, int64_t X,
+                double regularization_strength, float* out) {
+    BH_REQUIRE(ctx && in && tf_full && out, "NULL argument");
+    BH_REQUIRE(Z > 0 && Y > 0 && X > 0, "invalid shape");
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    ScopedTimer timer(ctx, T_TIKHONOV);
+    FftPlans* pl;
+    BH_TRY(get_plans(ctx, Z, Y, X, &pl));
+    const int64_t V = Z * Y * X, Xh = X / 2 + 1, NS = Z * Y * Xh;
+    cf* spec;
+    BH_TRY(get_scratch(ctx, "fft_spec", NS * sizeof(cf), (void**)&spec));
+    hipStream_t s = ctx->stream;
+    BH_CHECK_FFT(hipfftExecR2C(pl->r2c, const_cast<float*>(in), (hipfftComplex*)spec));
+    hipLaunchKernelGGL(tikhonov_filter_kernel, grid_for(ctx, NS), dim3(256), 0, s, spec, tf_full, Z, Y, X,
+                       (float)regularization_strength, (float)(1.0 / (double)V));
+    BH_CHECK_FFT(hipfftExecC2R(pl->c2r, (hipfftComplex*)spec, out));
+    BH_CHECK_HIP(hipGetLastError());
+    return BH_OK;
+}
+
+int bh_richardson_lucy(bh_ctx* ctx, const float* in, const float* psf, int64_t pz, int64_t py, int64_t px, int64_t Z,
+                       int64_t Y, int64_t X, int iterations, float eps, float* out) {
+    BH_REQUIRE(ctx && in && psf && out, "NULL argument");
+    BH_REQUIRE(iterations >= 0, "iterations must be >= 0");
+    BH_REQUIRE(pz > 0 && py > 0 && px > 0 && pz <= Z && py <= Y && px <= X, "PSF must fit inside the volume");
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    FftPlans* pl;
+    BH_TRY(get_plans(ctx, Z, Y, X, &pl));
+    const int64_t V = Z * Y * X, Xh = X / 2 + 1, NS = Z * Y * Xh;
+    float *real, *dcopy = nullptr;
+    cf *spec, *otf;
+    double* psum;
+    BH_TRY(get_scratch(ctx, "fft_real", V * sizeof(float), (void**)&real));
+    BH_TRY(get_scratch(ctx, "fft_spec", NS * sizeof(cf), (void**)&spec));
+    BH_TRY(get_scratch(ctx, "rl_otf", NS * sizeof(cf), (void**)&otf));
+    BH_TRY(get_scratch(ctx, "rl_psum", 64, (void**)&psum));
+    hipStream_t s = ctx->stream;
+    const float* d = in;
+    if (in == out) {  // the estimate overwrites `out`; keep the data term
+        BH_TRY(get_scratch(ctx, "rl_data", V * sizeof(float), (void**)&dcopy));
+        BH_CHECK_HIP(hipMemcpyAsync(dcopy, in, V * sizeof(float), hipMemcpyDeviceToDevice, s));
+        d = dcopy;
+    }
+    ScopedTimer timer(ctx, T_RL_TOTAL);
+    // OTF = rfftn(roll(pad(psf / sum), -centre)) / V   (the 1/V makes every C2R normalised)
+    BH_CHECK_HIP(hipMemsetAsync(real, 0, V * sizeof(float), s));
+    hipLaunchKernelGGL(psf_sum_kernel, dim3(1), dim3(256), 0, s, psf, pz * py * px, psum);
+    int bz, by, bx;
+    pad_before(pz, Z, &bz);
+    pad_before(py, Y, &by);
+    pad_before(px, X, &bx);
+    hipLaunchKernelGGL(place_psf_kernel, grid_for(ctx, pz * py * px), dim3(256), 0, s, psf, real, (int)pz, (int)py,
+                       (int)px, Z, Y, X, bz, by, bx, bz + (int)(pz / 2), by + (int)(py / 2), bx + (int)(px / 2),
+                       (const double*)psum);
+    BH_CHECK_FFT(hipfftExecR2C(pl->r2c, real, (hipfftComplex*)otf));
+    hipLaunchKernelGGL(scale_spectrum_kernel, grid_for(ctx, NS), dim3(256), 0, s, otf, NS, (float)(1.0 / (double)V));
+    // e0 = max(d, 0)
+    hipLaunchKernelGGL(clip_copy_kernel, grid_for(ctx, V), dim3(256), 0, s, d, out, V);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing && iterations > 0) {
+        BH_CHECK_HIP(hipEventCreate(&e0));
+        BH_CHECK_HIP(hipEventCreate(&e1));
+        BH_CHECK_HIP(hipEventRecord(e0, s));
+    }
+    const int64_t n2 = NS / 2;
+    for (int it = 0; it < iterations; ++it) {
+        BH_CHECK_FFT(hipfftExecR2C(pl->r2c, out, (hipfftComplex*)spec));
+        hipLaunchKernelGGL(cmul_kernel<false>, grid_for(ctx, n2), dim3(256), 0, s, spec, otf, n2);
+        if (NS & 1) hipLaunchKernelGGL(cmul_tail_kernel<false>, dim3(1), dim3(1), 0, s, spec, otf, NS - 1);
+        BH_CHECK_FFT(hipfftExecC2R(pl->c2r, (hipfftComplex*)spec, real));
+        hipLaunchKernelGGL(ratio_kernel, grid_for(ctx, V / 4 + 1), dim3(256), 0, s, real, d, V, eps);
+        BH_CHECK_FFT(hipfftExecR2C(pl->r2c, real, (hipfftComplex*)spec));
+        hipLaunchKernelGGL(cmul_kernel<true>, grid_for(ctx, n2), dim3(256), 0, s, spec, otf, n2);
+        if (NS & 1) hipLaunchKernelGGL(cmul_tail_kernel<true>, dim3(1), dim3(1), 0, s, spec, otf, NS - 1);
+        BH_CHECK_FFT(hipfftExecC2R(pl->c2r, (hipfftComplex*)spec, real));
+        hipLaunchKernelGGL(update_kernel, grid_for(ctx, V / 4 + 1), dim3(256), 0, s, out, real, V);
+    }
+    BH_CHECK_HIP(hipGetLastError());
+    if (e0) {
+        BH_CHECK_HIP(hipEventRecord(e1, s));
+        BH_CHECK_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        BH_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ctx->ms_override[T_RL_ITER] = ms / iterations;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    return BH_OK;
+}
+
+}  // extern "C"

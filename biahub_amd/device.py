@@ -1,0 +1,126 @@
+"""Device plumbing: torch provides device memory and streams, libbhcore does the work.
+
+One ``bh_ctx`` per (process, device); every call binds it to torch's *current* stream so
+the kernels order correctly with torch copies issued around them.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_CTX: dict[int, "Context"] = {}
+
+_NP_TO_DT = {
+    np.dtype(np.uint8): _lib.DT_U8,
+    np.dtype(np.uint16): _lib.DT_U16,
+    np.dtype(np.float32): _lib.DT_F32,
+    np.dtype(np.int16): _lib.DT_I16,
+}
+_TORCH_TO_DT = {
+    torch.uint8: _lib.DT_U8,
+    torch.uint16: _lib.DT_U16,
+    torch.float32: _lib.DT_F32,
+    torch.int16: _lib.DT_I16,
+}
+
+
+def resolve_device(device) -> torch.device:
+    """Turn the reference's ``device`` argument ("cuda", "cuda:1", torch.device) into a GPU.
+
+    A CPU device is refused: this package is the MI355X path and has no CPU fallback.
+    """
+    dev = torch.device(device) if not isinstance(device, torch.device) else device
+    if dev.type != "cuda":
+        raise RuntimeError(
+            f"biahub_amd runs on AMD GPUs only (got device={device!r}); it has no CPU path. "
+            "Use the reference biahub package for CPU execution."
+        )
+    if not torch.cuda.is_available():
+        raise RuntimeError("biahub_amd: no GPU visible to torch (torch.cuda.is_available() is False)")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+class Context:
+    def __init__(self, index: int):
+        self.index = index
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib.bh_ctx_create(index, None, C.byref(h)))
+        self.handle = h
+        self._stream = 0
+
+    def bind_stream(self):
+        s = torch.cuda.current_stream(self.index).cuda_stream
+        if s != self._stream:
+            _lib.check(self.lib.bh_ctx_set_stream(self.handle, C.c_void_p(s)))
+            self._stream = s
+
+    def synchronize(self):
+        _lib.check(self.lib.bh_ctx_synchronize(self.handle))
+
+    def set_timing(self, on: bool):
+        _lib.check(self.lib.bh_ctx_set_timing(self.handle, int(on)))
+
+    def elapsed_ms(self, what: int) -> float:
+        ms = C.c_float()
+        _lib.check(self.lib.bh_last_elapsed_ms(self.handle, what, C.byref(ms)))
+        return float(ms.value)
+
+    def workspace_bytes(self) -> int:
+        b = C.c_uint64()
+        _lib.check(self.lib.bh_ctx_workspace_bytes(self.handle, C.byref(b)))
+        return int(b.value)
+
+    def release_workspace(self):
+        _lib.check(self.lib.bh_ctx_release_workspace(self.handle))
+
+
+def get_context(device) -> Context:
+    dev = resolve_device(device)
+    ctx = _CTX.get(dev.index)
+    if ctx is None:
+        with torch.cuda.device(dev):
+            torch.cuda.current_stream(dev)  # make sure torch has initialised the device
+            ctx = Context(dev.index)
+        _CTX[dev.index] = ctx
+    ctx.bind_stream()
+    return ctx
+
+
+def ptr(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def upload(array: np.ndarray, device: torch.device) -> tuple[torch.Tensor, int]:
+    """Host array -> contiguous device tensor in a dtype the kernels read natively.
+
+    uint8/uint16/int16/float32 travel as they are (a uint16 camera stack crosses PCIe at 2 B/voxel
+    and is widened to float32 inside the kernel); anything else is cast to float32 on the host, as
+    the reference does with ``.to(dtype=torch.float32)`` (biahub/deskew.py:578).
+    """
+    a = np.asarray(array)
+    if a.dtype not in _NP_TO_DT:
+        a = a.astype(np.float32)
+    a = np.ascontiguousarray(a)
+    code = _NP_TO_DT[a.dtype]
+    return torch.from_numpy(a).to(device), code
+
+
+def as_device_volume(x, device=None) -> tuple[torch.Tensor, int, torch.device]:
+    """Accept a numpy array or a torch tensor; return (contiguous device tensor, dtype code, device)."""
+    if isinstance(x, torch.Tensor):
+        dev = resolve_device(x.device if device is None else device)
+        t = x.to(dev)
+        if t.dtype not in _TORCH_TO_DT:
+            t = t.to(torch.float32)
+        return t.contiguous(), _TORCH_TO_DT[t.dtype], dev
+    dev = resolve_device("cuda" if device is None else device)
+    t, code = upload(x, dev)
+    return t, code, dev

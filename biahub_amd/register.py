@@ -1,0 +1,138 @@
+"""3-D affine register / crop on MI355X — host-side mirror of ``biahub/register.py``.
+
+The reference resamples with ANTs/ITK (``ANTsTransform.apply_to_image``, register.py:261-269);
+here the same pull-resample ``out(p) = in(A p + t)`` (ZYX index space, origin 0, spacing 1) runs
+in ``csrc/affine.hip``.  ITK's boundary rule (inside iff -0.5 <= c < N-0.5, edge clamp) is the
+default; see DESIGN.md §3 for what is pinned.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .device import as_device_volume, get_context, ptr, resolve_device
+
+_INTERP = {"linear": _lib.INTERP_LINEAR, "nearestneighbor": _lib.INTERP_NEAREST}
+
+
+def get_3D_rescaling_matrix(start_shape_zyx, scaling_factor_zyx=(1, 1, 1), end_shape_zyx=None):
+    """Centre-preserving YX scaling (biahub/register.py:32-57)."""
+    cy0, cx0 = np.array(start_shape_zyx)[-2:] / 2
+    cy1, cx1 = (cy0, cx0) if end_shape_zyx is None else np.array(end_shape_zyx)[-2:] / 2
+    sz, sy, sx = scaling_factor_zyx[-3], scaling_factor_zyx[-2], scaling_factor_zyx[-1]
+    return np.array([[sz, 0, 0, 0], [0, sy, 0, -cy0 * sy + cy1], [0, 0, sx, -cx0 * sx + cx1], [0, 0, 0, 1]])
+
+
+def get_3D_rotation_matrix(start_shape_zyx: tuple, angle: float = 0.0, end_shape_zyx: tuple = None) -> np.ndarray:
+    """Rotation about Z through the YX centre (biahub/register.py:60-111)."""
+    cy0, cx0 = np.array(start_shape_zyx)[-2:] / 2
+    cy1, cx1 = (cy0, cx0) if end_shape_zyx is None else np.array(end_shape_zyx)[-2:] / 2
+    t = np.radians(angle)
+    c, s = np.cos(t), np.sin(t)
+    return np.array([[1, 0, 0, 0], [0, c, -s, -cy0 * c + s * cx0 + cy1], [0, s, c, -cy0 * s - cx0 * c + cx1],
+                     [0, 0, 0, 1]])
+
+
+def get_3D_fliplr_matrix(start_shape_zyx: tuple, end_shape_zyx: tuple = None) -> np.ndarray:
+    """Left-right flip (biahub/register.py:114-145)."""
+    cx0 = start_shape_zyx[-1] / 2
+    cx1 = cx0 if end_shape_zyx is None else end_shape_zyx[-1] / 2
+    return np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, -1, 2 * cx1], [0, 0, 0, 1]])
+
+
+def rescale_voxel_size(affine_matrix, input_scale):
+    """Row norms times scale (biahub/register.py:397-398)."""
+    return np.linalg.norm(affine_matrix, axis=1) * input_scale
+
+
+def convert_transform_to_ants(T_numpy: np.ndarray) -> np.ndarray:
+    """4x4 -> the 12 ITK AffineTransform parameters ``[A row-major ; t]`` (register.py:148-168).
+
+    Returns the parameter vector itself (there is no ANTs object here); centre is 0.
+    """
+    T = np.asarray(T_numpy, dtype=np.float64)
+    assert T.shape == (4, 4)
+    return np.concatenate([T[:3, :3].ravel(), T[:3, 3]])
+
+
+def convert_transform_to_numpy(params: np.ndarray, fixed_parameters=(0.0, 0.0, 0.0)) -> np.ndarray:
+    """Inverse of the above incl. the centre term ``t + (I - A) c`` (register.py:171-199)."""
+    p = np.asarray(params, dtype=np.float64)
+    T = np.eye(4)
+    T[:3, :3] = p[:9].reshape(3, 3)
+    T[:3, 3] = p[9:12] + (np.eye(3) - T[:3, :3]) @ np.asarray(fixed_parameters, dtype=np.float64)
+    return T
+
+
+def affine_device(vol, matrix, output_shape_zyx, interpolation="linear", boundary=_lib.BOUNDARY_ITK, cval=0.0,
+                  crop_lo=(0, 0, 0), crop_shape=None, device=None) -> torch.Tensor:
+    """Device-level warp: tensor/array in, float32 tensor out (the sub-box ``crop`` of the target grid)."""
+    if interpolation not in _INTERP:
+        raise ValueError(f"Unknown interpolation {interpolation!r}; expected one of {sorted(_INTERP)}")
+    t, code, dev = as_device_volume(vol, device)
+    if t.ndim != 3:
+        raise ValueError(f"expected a 3-D volume, got shape {tuple(t.shape)}")
+    M = np.asarray(matrix, dtype=np.float64)
+    if M.shape != (4, 4):
+        raise ValueError(f"matrix must be 4x4, got {M.shape}")
+    shape = tuple(int(s) for s in (crop_shape if crop_shape is not None else output_shape_zyx))
+    m12 = (C.c_double * 12)(*M[:3, :].ravel())
+    lo = (C.c_int64 * 3)(*[int(v) for v in crop_lo])
+    Zi, Yi, Xi = (int(s) for s in t.shape)
+    ctx = get_context(dev)
+    with torch.cuda.device(dev):
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
+        if out.numel():
+            _lib.check(ctx.lib.bh_affine(ctx.handle, ptr(t), code, Zi, Yi, Xi, m12, _INTERP[interpolation],
+                                         int(boundary), float(cval), ptr(out), shape[0], shape[1], shape[2], lo))
+    return out
+
+
+def _slice_bounds(sl: slice, n: int):
+    start, stop, step = sl.indices(n)
+    if step != 1:
+        raise ValueError("crop slices must have step 1")
+    return start, max(stop - start, 0)
+
+
+def apply_affine_transform(
+    zyx_data: np.ndarray,
+    matrix: np.ndarray,
+    output_shape_zyx: tuple,
+    method="ants",
+    interpolation: str = "linear",
+    crop_output_slicing: bool = None,
+    device="cuda",
+) -> np.ndarray:
+    """Apply a 4x4 ZYX affine, optionally crop (biahub/register.py:202-281).
+
+    4-D input recurses per channel (:241-252); NaN -> 0 before resampling (:254, fused into the
+    kernel load); ``method`` accepts "ants" (ITK boundary rule) or "scipy" (the reference's raw
+    ``scipy.ndimage.affine_transform`` call, :271-272: spline order 3 there — not implemented, raises);
+    anything else raises ``ValueError("Unknown method ...")`` (:275).  Only the cropped sub-box is
+    computed (the reference warps the full grid and slices, :278-279).
+    """
+    if method == "scipy":
+        raise NotImplementedError("method='scipy' (cubic spline) is not implemented on the GPU path")
+    if method != "ants":
+        raise ValueError(f"Unknown method {method}")
+    zyx_data = np.asarray(zyx_data)
+    Z, Y, X = (int(s) for s in output_shape_zyx)
+    lo, shape = (0, 0, 0), (Z, Y, X)
+    if crop_output_slicing is not None:
+        b = [_slice_bounds(s, n) for s, n in zip(crop_output_slicing, (Z, Y, X))]
+        lo, shape = tuple(v[0] for v in b), tuple(v[1] for v in b)
+    if zyx_data.ndim == 4:
+        out = np.zeros((zyx_data.shape[0],) + shape, dtype=np.float32)
+        for c in range(zyx_data.shape[0]):
+            out[c] = apply_affine_transform(zyx_data[c], matrix, output_shape_zyx, method=method,
+                                            interpolation=interpolation, crop_output_slicing=crop_output_slicing,
+                                            device=device)
+        return out
+    dev = resolve_device(device)
+    return affine_device(zyx_data, matrix, (Z, Y, X), interpolation, _lib.BOUNDARY_ITK, 0.0, lo, shape,
+                         dev).cpu().numpy()

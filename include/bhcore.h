@@ -1,0 +1,156 @@
+/*
+ * bhcore.h — C-ABI of the MI355X-native volumetric reconstruction core.
+ *
+ * This is the drop-in boundary for biahub's per-position hot path.  The
+ * reference is pure Python, so what binds here is a ctypes stub; the
+ * entry points are one flat, re-entrant call per operator of the reference's L1 layer:
+ *
+ *   bh_deskew_shape        <- biahub/deskew.py:213-274  get_deskewed_data_shape
+ *   bh_deskew              <- biahub/deskew.py:456-542  fast_deskew_zyx  (+ :99-154)
+ *   bh_overhang_fill       <- biahub/deskew.py:339-368  _fill_overhang_torch
+ *   bh_transfer_function   <- biahub/deconvolve.py:30-43 compute_tranfser_function
+ *   bh_tikhonov            <- biahub/deconvolve.py:46-66 deconvolve (waveorder Tikhonov)
+ *   bh_richardson_lucy     <- (north-star extension; no reference function)
+ *   bh_affine              <- biahub/register.py:202-281 apply_affine_transform,
+ *                             biahub/stabilize.py:32-90 apply_stabilization_transform,
+ *                             biahub/core/transform.py:374-396 Transform._apply_scipy
+ *   bh_crop_flip           <- biahub/utils/array_ops.py:9-59 copy_n_paste[_czyx],
+ *                             biahub/flip.py:22-32 flip_cli body
+ *
+ * Conventions
+ *   - Every data pointer is a DEVICE pointer (hipMalloc'd, or a torch CUDA tensor's
+ *     data_ptr()).  bh_malloc/bh_free/bh_memcpy_* are exported so a host without torch
+ *     can stage buffers itself.
+ *   - Volumes are C-contiguous (Z, Y, X), X fastest, exactly like the numpy arrays the
+ *     reference hands to its operators.
+ *   - All work is enqueued on the context's stream (hipStream_t passed as void*; NULL =
+ *     the default stream) and is asynchronous unless stated; bh_ctx_synchronize waits.
+ *   - Every function returns BH_OK (0) or an error code; the message for the calling
+ *     thread's last error is returned by bh_last_error().  BH_ERR_INVALID corresponds
+ *     to the reference's ValueError.
+ *   - A context owns cached hipFFT plans and a grow-only device workspace; it is not
+ *     thread-safe (use one per thread / per process, as the reference uses one process
+ *     per worker: biahub/deskew.py:38-40).
+ */
+#ifndef BHCORE_H
+#define BHCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BH_ABI_VERSION 1
+
+/* status codes */
+#define BH_OK 0
+#define BH_ERR_INVALID 1     /* bad argument / geometry (reference: ValueError)   */
+#define BH_ERR_HIP 2         /* HIP runtime or hipFFT failure                     */
+#define BH_ERR_NOMEM 3       /* device allocation failed                          */
+#define BH_ERR_UNSUPPORTED 4 /* valid request this build does not implement       */
+
+/* element types of input volumes */
+#define BH_DT_U8 0
+#define BH_DT_U16 1
+#define BH_DT_F32 2
+#define BH_DT_I16 3
+
+/* overhang fill modes (biahub/deskew.py:538-540) */
+#define BH_FILL_NONE 0
+#define BH_FILL_CONSTANT 1
+#define BH_FILL_MEAN 2
+
+/* affine interpolation (register.py:207 "linear" | "nearestneighbor") */
+#define BH_INTERP_NEAREST 0
+#define BH_INTERP_LINEAR 1
+
+/* affine boundary rule */
+#define BH_BOUNDARY_ITK 0            /* inside iff -0.5 <= c < N-0.5, neighbours clamped (ANTs/ITK) */
+#define BH_BOUNDARY_SCIPY_CONSTANT 1 /* inside iff 0 <= c <= N-1 (scipy mode="constant")            */
+#define BH_BOUNDARY_ZEROS 2          /* out-of-range neighbours read cval (grid-constant)           */
+
+typedef struct bh_ctx bh_ctx;
+
+/* ---- library / context ------------------------------------------------------------ */
+int bh_abi_version(void);
+const char* bh_last_error(void);
+int bh_device_count(int* count);
+int bh_ctx_create(int device, void* hip_stream, bh_ctx** out);
+int bh_ctx_destroy(bh_ctx* ctx);
+int bh_ctx_set_stream(bh_ctx* ctx, void* hip_stream);
+int bh_ctx_synchronize(bh_ctx* ctx);
+int bh_ctx_release_workspace(bh_ctx* ctx); /* frees cached plans + scratch             */
+int bh_ctx_workspace_bytes(bh_ctx* ctx, uint64_t* bytes);
+
+/* device-memory helpers for hosts that do not bring their own allocator */
+int bh_malloc(void** dptr, uint64_t bytes);
+int bh_free(void* dptr);
+int bh_memcpy_h2d(bh_ctx* ctx, void* dst, const void* src, uint64_t bytes); /* synchronous */
+int bh_memcpy_d2h(bh_ctx* ctx, void* dst, const void* src, uint64_t bytes); /* synchronous */
+
+/* ---- deskew ------------------------------------------------------------------------ */
+/* Host-only geometry. out_shape = (ceil(Y/n), X, Xp); voxel = (n*sin(t)*px, px, px).
+ * BH_ERR_INVALID when keep_overhang==0 and Xp<=0, with the reference's message. */
+int bh_deskew_shape(int64_t Z, int64_t Y, int64_t X, double ls_angle_deg, double px_to_scan_ratio,
+                    int keep_overhang, int average_n_slices, double pixel_size_um,
+                    int64_t out_shape[3], double voxel_size[3]);
+
+/* Fused permute/flip + scan-axis shear interpolation + N-slice mean.
+ * in : (Z,Y,X) of in_dtype ;  out : float32 (out_shape) as given by bh_deskew_shape.
+ * fill_mode/fill_value apply only when keep_overhang!=0 (reference :538).
+ * mean_out (host pointer, may be NULL) receives the fill value used (sync if non-NULL). */
+int bh_deskew(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, int64_t X,
+              double ls_angle_deg, double px_to_scan_ratio, int keep_overhang, int average_n_slices,
+              int fill_mode, float fill_value, float* out, float* mean_out);
+
+/* Stand-alone overhang fill on an already deskewed float32 volume, in place. */
+int bh_overhang_fill(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X, int fill_mode,
+                     float fill_value, int dilation_iterations, float* mean_out);
+
+/* ---- deconvolution ----------------------------------------------------------------- */
+/* tf_full: float32 (Z,Y,X) = |FFT(zero-padded psf)| / max, full spectrum like the reference. */
+int bh_transfer_function(bh_ctx* ctx, const float* psf, int64_t pz, int64_t py, int64_t px, int64_t Z,
+                         int64_t Y, int64_t X, float* tf_full);
+
+/* out = real(ifftn(fftn(in) * conj(H) / (|H|^2 + reg))) with real H = tf_full. in/out float32,
+ * may alias. */
+int bh_tikhonov(bh_ctx* ctx, const float* in, const float* tf_full, int64_t Z, int64_t Y, int64_t X,
+                double regularization_strength, float* out);
+
+/* Richardson-Lucy with circular (FFT) boundary; psf is normalised to unit sum on device.
+ * e0 = max(in,0); e <- max(e * corr(d / max(conv(e), eps)), 0).  in/out float32, may alias. */
+int bh_richardson_lucy(bh_ctx* ctx, const float* in, const float* psf, int64_t pz, int64_t py,
+                       int64_t px, int64_t Z, int64_t Y, int64_t X, int iterations, float eps,
+                       float* out);
+
+/* ---- affine warp ------------------------------------------------------------------- */
+/* out(p) = in(M p), M = 3x4 row-major pull matrix (rows z,y,x; last column translation) in ZYX
+ * index space; NaN inputs read as 0 (register.py:254).  The output is the sub-box
+ * [crop_lo, crop_lo + out_shape) of the full target grid (register.py:278-279); pass crop_lo =
+ * {0,0,0} for no crop. */
+int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, int64_t Yi, int64_t Xi,
+              const double matrix[12], int interpolation, int boundary, float cval, float* out,
+              int64_t Zo, int64_t Yo, int64_t Xo, const int64_t crop_lo[3]);
+
+/* ---- bit-exact crop / flip --------------------------------------------------------- */
+/* (C, Zi, Yi, Xi) of itemsize bytes -> (C, Zo, Yo, Xo) starting at lo, optionally flipped along
+ * Y and/or X *after* the crop.  nan_to_zero (float32/float64 only) restates copy_n_paste's
+ * np.nan_to_num.  Pure data movement: outputs are bit-identical to numpy slicing. */
+int bh_crop_flip(bh_ctx* ctx, const void* in, int itemsize, int64_t C, int64_t Zi, int64_t Yi,
+                 int64_t Xi, const int64_t lo[3], int64_t Zo, int64_t Yo, int64_t Xo, int flip_y,
+                 int flip_x, int nan_to_zero, void* out);
+
+/* ---- measurement support ----------------------------------------------------------- */
+/* Elapsed milliseconds of the last call of each kind, measured with HIP events on the
+ * context's stream (what: 0 deskew kernel, 1 fill passes, 2 RL total, 3 tikhonov, 4 affine,
+ * 5 crop_flip, 6 one RL iteration (mean), 7 transfer function). Synchronises. */
+int bh_last_elapsed_ms(bh_ctx* ctx, int what, float* ms);
+/* Enable/disable event timing (off by default: events cost a few us per call). */
+int bh_ctx_set_timing(bh_ctx* ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BHCORE_H */

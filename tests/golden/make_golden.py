@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by running the *reference* (czbiohub-sf/biahub).
+
+Run ONLY in the build container, where the reference is mounted at /root/reference:
+
+    python tests/golden/make_golden.py
+
+It imports the reference's own functions (through oracle/ref_import.py, which stubs the
+absent orchestration packages), evaluates them on small seeded inputs and stores inputs,
+parameters and outputs as data files next to this script.  No reference source is copied;
+on the GPU box this script is inert (no /root/reference) and the tests read the fixtures.
+
+Fixtures written:
+  deskew_shapes.json      get_deskewed_data_shape table (+ the ValueError case)
+  deskew_cases.npz        fast_deskew_zyx / _fast_deskew_czyx inputs+outputs
+  average_n_slices.npz    _average_n_slices known answers
+  transfer_function.npz   compute_tranfser_function (odd/even psf x odd/even volume)
+  transform_scipy.npz     core.transform.Transform.apply (SciPy), orders 0/1
+  helpers.json            settings dumps, fingerprints, estimate_resources, output paths,
+                          sbatch parsing, matrix builders
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent.parent))
+
+from oracle.ref_import import load_reference, reference_available  # noqa: E402
+
+
+def main():
+    if not reference_available():
+        print("reference checkout not present; nothing to do")
+        return 0
+    load_reference()
+    import torch
+
+    import biahub.deskew as D
+    from biahub.core.transform import Transform
+    from biahub.deconvolve import compute_tranfser_function
+
+    torch.set_num_threads(4)
+    rng = np.random.default_rng(20261003)
+
+    # ---- 1. shape table ---------------------------------------------------------------
+    rows = []
+    grid = [
+        ((64, 256, 256), 36.17, 0.371, True, 3, 0.116),
+        ((512, 2048, 2048), 36.17, 0.371, True, 3, 0.116),
+        ((256, 1024, 1024), 36.17, 0.371, True, 3, 0.116),
+        ((2, 3, 4), 36, 0.386, True, 1, 1.0),
+        ((20, 14, 9), 36.17, 0.371, True, 1, 1.0),
+        ((20, 14, 9), 36.17, 0.371, True, 2, 1.0),
+        ((33, 17, 12), 30.0, 0.25, True, 3, 0.2),
+        ((40, 31, 24), 36.17, 0.371, False, 3, 0.116),
+        ((40, 31, 24), 45.0, 0.8, False, 2, 0.116),
+        ((100, 50, 7), 10.0, 0.5, False, 4, 1.0),
+        ((10, 500, 100), 30, 0.1, True, 1, 1.0),
+    ]
+    for shape, ang, r, ko, n, px in grid:
+        out, vox = D.get_deskewed_data_shape(shape, ang, r, ko, n, px)
+        rows.append(
+            dict(shape=list(shape), angle=ang, ratio=r, keep_overhang=ko, n=n, pixel=px,
+                 out=[int(v) for v in out], voxel=[float(v) for v in vox])
+        )
+    err = None
+    try:
+        D.get_deskewed_data_shape((10, 500, 100), 30, 0.1, keep_overhang=False)
+    except ValueError as e:  # tests/test_cli/test_deskew_cli.py:189-197
+        err = str(e)
+    json.dump({"rows": rows, "error_case": {"shape": [10, 500, 100], "angle": 30, "ratio": 0.1,
+                                            "message": err}},
+              open(HERE / "deskew_shapes.json", "w"), indent=1)
+
+    # ---- 2/3. fast_deskew_zyx and the CZYX adapter ------------------------------------
+    store = {}
+    meta = []
+
+    def add_case(name, vol, ang, r, ko, n, fill, splits=None):
+        if splits is None:
+            out = D.fast_deskew_zyx(torch.from_numpy(vol.astype(np.float32)), ang, r, ko, n, fill).numpy()
+        else:
+            out = D._fast_deskew_czyx(vol[None], device="cpu", num_splits=splits, ls_angle_deg=ang,
+                                      px_to_scan_ratio=r, keep_overhang=ko, average_n_slices=n,
+                                      overhang_fill=fill)
+        store[name + "__in"] = vol
+        store[name + "__out"] = out.astype(np.float32)
+        meta.append(dict(name=name, angle=ang, ratio=r, keep_overhang=ko, n=n,
+                         fill=fill, splits=splits))
+
+    vols = {
+        "a": rng.random((20, 14, 9), dtype=np.float32),
+        "b": rng.random((33, 17, 12), dtype=np.float32),
+        "c": rng.random((40, 31, 24), dtype=np.float32),
+        "u": rng.integers(90, 4000, (24, 16, 10)).astype(np.uint16),
+    }
+    # sprinkle exact zeros so the zero-mask of the overhang fill sees interior zeros too
+    vols["b"][5, 3, 2] = 0.0
+    vols["c"][20:22, 10:12, 5] = 0.0
+    i = 0
+    for key in ("a", "b", "c"):
+        for n in (1, 2, 3):
+            for fill in (0, 100.0, "mean"):
+                if key == "c" and fill == 100.0:
+                    continue
+                add_case(f"d{i:02d}_{key}_n{n}", vols[key], 36.17, 0.371, True, n, fill)
+                i += 1
+    add_case("k0_c_n3_nooverhang", vols["c"], 36.17, 0.371, False, 3, 0)
+    add_case("k1_c_n2_nooverhang", vols["c"], 45.0, 0.8, False, 2, 0)
+    add_case("p0_b_n3_angle30", vols["b"], 30.0, 0.25, True, 3, 0)
+    add_case("p1_a_n4", vols["a"], 20.0, 0.5, True, 4, "mean")
+    add_case("u0_uint16_n3", vols["u"], 36.17, 0.371, True, 3, 0, splits=1)
+    add_case("u1_uint16_n3_mean", vols["u"], 36.17, 0.371, True, 3, "mean", splits=1)
+    for s in (1, 2, 3):
+        add_case(f"s{s}_c_split", vols["c"], 36.17, 0.371, True, 3, 0, splits=s)
+    store["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(HERE / "deskew_cases.npz", **store)
+
+    # ---- 4. _average_n_slices ----------------------------------------------------------
+    data = np.arange(1, 17).reshape(4, 2, 2)
+    np.savez(HERE / "average_n_slices.npz", data=data,
+             w3=D._average_n_slices(data, 3), w2=D._average_n_slices(data, 2),
+             w1=D._average_n_slices(data, 1))
+
+    # ---- 5. transfer function ----------------------------------------------------------
+    tf = {}
+    for j, (ps, vs) in enumerate([((5, 5, 5), (8, 9, 10)), ((4, 6, 5), (9, 12, 8)),
+                                  ((7, 3, 3), (16, 8, 8)), ((9, 9, 9), (9, 9, 9))]):
+        psf = rng.random(ps, dtype=np.float32)
+        tf[f"psf{j}"] = psf
+        tf[f"shape{j}"] = np.array(vs)
+        tf[f"tf{j}"] = compute_tranfser_function(psf, vs)
+    np.savez_compressed(HERE / "transfer_function.npz", **tf)
+
+    # ---- 6. Transform.apply (SciPy path) ----------------------------------------------
+    tr = {}
+    mov = rng.random((12, 16, 20), dtype=np.float32)
+    th = np.deg2rad(7.0)
+    M = np.array([[1.02, 0.0, 0.0, 0.4],
+                  [0.0, np.cos(th), -np.sin(th), 1.75],
+                  [0.0, np.sin(th), np.cos(th), -2.25],
+                  [0, 0, 0, 1.0]])
+    t = Transform(M)
+    tr["moving"] = mov
+    tr["matrix"] = M
+    tr["order1"] = t.apply(mov, order=1)
+    tr["order0"] = t.apply(mov, order=0)
+    ref_shape = np.zeros((10, 20, 18), dtype=np.float32)
+    tr["order1_ref"] = t.apply(mov, reference=ref_shape, order=1, cval=3.0)
+    tr["inv"] = t.invert().matrix
+    tr["compose"] = (t @ Transform.from_translation([1, 2, 3])).matrix
+    pts = rng.random((5, 3)) * 10
+    tr["points"] = pts
+    tr["points_out"] = t.apply_points(pts)
+    tr["shift_int"] = Transform.from_translation([-3.0, 1.0, 4.0]).apply(np.ones((10, 10, 10), np.float32))
+    np.savez_compressed(HERE / "transform_scipy.npz", **tr)
+
+    # ---- 7. settings / helpers ---------------------------------------------------------
+    import biahub.register as R
+    import biahub.settings as S
+    from biahub.cli.parsing import sbatch_to_submitit
+    from biahub.utils.cluster import estimate_resources, get_submitit_cluster
+    from biahub.utils.config import settings_fingerprint, yaml_to_model
+    from biahub.utils.ngff import get_output_paths
+
+    helpers = {}
+    sdir = Path("/root/reference/settings")
+    for fname, model in [("example_deskew_settings.yml", S.DeskewSettings),
+                         ("example_registration_settings.yml", S.RegistrationSettings),
+                         ("example_stabilize_timelapse_settings.yml", S.StabilizationSettings)]:
+        m = yaml_to_model(sdir / fname, model)
+        helpers[fname] = {"yaml": (sdir / fname).read_text(), "dump": m.model_dump(mode="json"),
+                          "fingerprint": settings_fingerprint(m)}
+    m = S.DeconvolveSettings()
+    helpers["deconvolve_default"] = {"dump": m.model_dump(mode="json"),
+                                     "fingerprint": settings_fingerprint(m)}
+    m = S.DeskewSettings(pixel_size_um=0.116, ls_angle_deg=36.1749, scan_step_um=0.3125)
+    helpers["deskew_derived_ratio"] = m.model_dump(mode="json")
+    res = []
+    for ci in ("true", None):
+        if ci:
+            os.environ["CI"] = ci
+        else:
+            os.environ.pop("CI", None)
+        for shape, kw in [((3, 6, 4, 5, 6), dict(ram_multiplier=8, time_multiplier=0.5, max_num_cpus=16)),
+                          ((4, 2, 256, 1024, 1024), dict(ram_multiplier=8, time_multiplier=0.5, max_num_cpus=16)),
+                          ((100, 3, 512, 2048, 2048), dict(ram_multiplier=16, max_num_cpus=16)),
+                          ((1, 1, 64, 256, 256), dict())]:
+            res.append({"ci": ci, "shape": list(shape), "kw": kw,
+                        "out": [int(v) for v in estimate_resources(shape, **kw)]})
+        res.append({"ci": ci, "cluster": [get_submitit_cluster(False, None), get_submitit_cluster(True, None),
+                                          get_submitit_cluster(False, "debug")]})
+    os.environ.pop("CI", None)
+    helpers["estimate_resources"] = res
+    ins = [Path("/data/in.zarr/A/1/0"), Path("/data/in.zarr/B/2/0"), Path("/data/other.zarr/A/1/0")]
+    helpers["output_paths"] = {
+        "plain": [str(p) for p in get_output_paths(ins, Path("/out/o.zarr"))],
+        "unique": [str(p) for p in get_output_paths(ins, Path("/out/o.zarr"), ensure_unique_positions=True)],
+    }
+    with tempfile.NamedTemporaryFile("w", suffix=".sh", delete=False) as f:
+        f.write("#!/bin/bash\n#SBATCH --mem-per-cpu=16G\n#SBATCH --time=1:00:00\n#LOCAL --cpus-per-task=1\n# comment\n")
+    helpers["sbatch"] = sbatch_to_submitit(f.name)
+    os.unlink(f.name)
+    helpers["matrices"] = {
+        "rescale": R.get_3D_rescaling_matrix((10, 20, 30), (1, 2, 0.5), (10, 40, 15)).tolist(),
+        "rotate": R.get_3D_rotation_matrix((10, 20, 30), 30.0, (10, 25, 35)).tolist(),
+        "fliplr": R.get_3D_fliplr_matrix((10, 20, 30), (10, 20, 40)).tolist(),
+        "rescale_voxel": R.rescale_voxel_size(np.array(M[:3, :3]), np.array([0.2, 0.1, 0.1])).tolist(),
+    }
+    json.dump(helpers, open(HERE / "helpers.json", "w"), indent=1, default=str)
+    total = sum(p.stat().st_size for p in HERE.glob("*.np*")) + sum(p.stat().st_size for p in HERE.glob("*.json"))
+    print(f"golden fixtures written to {HERE} ({total/1e6:.2f} MB)")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,300 @@
+"""GPU: parity of the HIP path (through the C-ABI) against the reference's golden vectors and the oracle.
+
+Tolerances (relative to the volume's max |value|):
+  deskew            <= 1e-5  (coordinates restated bit-exactly; only summation order differs)
+  overhang fill     <= 1e-5  (mean computed in float64 here, cascade float32 in torch)
+  transfer function <= 1e-5 ; Tikhonov / Richardson-Lucy <= 1e-4 (FFT ordering)
+  affine linear     <= 1e-5 ; nearest / crop / flip / NaN->0 bit-exact
+"""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+
+DESKEW_TOL = 1e-5
+FFT_TOL = 1e-4
+
+
+# ----------------------------------------------------------------------------- deskew
+def test_deskew_golden_vectors(gpu, deskew_cases):
+    from biahub_amd.deskew import _fast_deskew_czyx, fast_deskew_zyx
+
+    z, meta = deskew_cases
+    for m in meta:
+        vol = z[m["name"] + "__in"]
+        ref = z[m["name"] + "__out"]
+        kw = dict(ls_angle_deg=m["angle"], px_to_scan_ratio=m["ratio"], keep_overhang=m["keep_overhang"],
+                  average_n_slices=m["n"], overhang_fill=m["fill"])
+        if m["splits"] is None:
+            got = fast_deskew_zyx(torch.from_numpy(vol.astype(np.float32)).to(gpu), **kw).cpu().numpy()
+        else:
+            got = _fast_deskew_czyx(vol[None], device="cuda", num_splits=m["splits"], **kw)
+        assert got.shape == ref.shape, m
+        assert got.dtype == np.float32
+        assert rel_err(got, ref) <= DESKEW_TOL, (m, rel_err(got, ref))
+
+
+@pytest.mark.parametrize("shape,n,angle,ratio", [
+    ((64, 256, 256), 3, 36.17, 0.371),   # BASELINE config 1
+    ((48, 100, 70), 3, 36.17, 0.371),    # Y % N != 0 (last-slab rule), X not a tile multiple
+    ((96, 64, 200), 2, 30.0, 0.25),
+    ((40, 33, 65), 5, 20.0, 0.5),        # generic-N path
+    ((31, 50, 33), 1, 45.0, 0.9),
+])
+def test_deskew_vs_oracle(gpu, shape, n, angle, ratio):
+    from biahub_amd.deskew import fast_deskew_zyx
+
+    rng = np.random.default_rng(sum(shape))
+    vol = rng.random(shape, dtype=np.float32) * 1000
+    want = O.fast_deskew_zyx(vol, angle, ratio, True, n, 0)
+    got = fast_deskew_zyx(torch.from_numpy(vol).to(gpu), angle, ratio, True, n, 0).cpu().numpy()
+    assert got.shape == want.shape
+    assert rel_err(got, want) <= DESKEW_TOL
+
+
+def test_deskew_uint16_equals_float32_input(gpu):
+    from biahub_amd.deskew import _fast_deskew_czyx
+
+    rng = np.random.default_rng(5)
+    vol = rng.integers(0, 65535, (40, 60, 90)).astype(np.uint16)
+    kw = dict(ls_angle_deg=36.17, px_to_scan_ratio=0.371, keep_overhang=True, average_n_slices=3, overhang_fill=0)
+    a = _fast_deskew_czyx(vol[None], device="cuda", **kw)
+    b = _fast_deskew_czyx(vol[None].astype(np.float32), device="cuda", **kw)
+    assert np.array_equal(a, b)  # widening on load is exact
+
+
+def test_deskew_fill_modes_vs_oracle(gpu):
+    from biahub_amd.deskew import fast_deskew_zyx
+
+    rng = np.random.default_rng(11)
+    vol = (rng.random((48, 70, 50), dtype=np.float32) * 500 + 100).astype(np.float32)
+    vol[10:14, 20:30, 10:20] = 0  # true zeros inside the signal are masked too (deskew.py:361)
+    for fill in ("mean", 100.0):
+        want = O.fast_deskew_zyx(vol, 36.17, 0.371, True, 3, fill)
+        got = fast_deskew_zyx(torch.from_numpy(vol).to(gpu), 36.17, 0.371, True, 3, fill).cpu().numpy()
+        assert rel_err(got, want) <= DESKEW_TOL, fill
+    # keep_overhang=False never fills (deskew.py:538)
+    a = fast_deskew_zyx(torch.from_numpy(vol).to(gpu), 36.17, 0.371, False, 3, "mean").cpu().numpy()
+    b = fast_deskew_zyx(torch.from_numpy(vol).to(gpu), 36.17, 0.371, False, 3, 0).cpu().numpy()
+    assert np.array_equal(a, b)
+
+
+def test_deskew_properties_large(gpu):
+    """Size-independent properties at a size the oracle would not finish quickly."""
+    from biahub_amd.deskew import fast_deskew_zyx, get_deskewed_data_shape
+
+    Z, Y, X = 256, 512, 512
+    g = torch.Generator(device=gpu).manual_seed(1)
+    a = torch.rand((Z, Y, X), generator=g, device=gpu)
+    b = torch.rand((Z, Y, X), generator=g, device=gpu)
+    kw = dict(ls_angle_deg=36.17, px_to_scan_ratio=0.371, keep_overhang=True, average_n_slices=3)
+    da, db, dab = fast_deskew_zyx(a, **kw), fast_deskew_zyx(b, **kw), fast_deskew_zyx(2 * a + b, **kw)
+    assert tuple(da.shape) == get_deskewed_data_shape((Z, Y, X), 36.17, 0.371, True, 3)[0]
+    assert float((dab - (2 * da + db)).abs().max()) <= 1e-5 * float(dab.abs().max())  # linearity
+    ones = fast_deskew_zyx(torch.ones((Z, Y, X), device=gpu), **kw)
+    assert float(ones.max()) <= 1.0 + 1e-6 and float(ones.min()) >= 0.0  # partition of unity, zero overhang
+    # the Y (coverslip) axis is independent: deskewing a slab equals the slab of the deskew (flipped index)
+    sub = fast_deskew_zyx(a[:, :, 100:164].contiguous(), **kw)
+    assert torch.equal(sub, da[:, X - 164:X - 100, :])
+    # splits along X reproduce the unsplit result exactly
+    assert torch.equal(fast_deskew_zyx(a, **kw), da)  # deterministic
+
+
+def test_deskew_errors(gpu):
+    from biahub_amd.deskew import fast_deskew_zyx
+
+    x = torch.zeros((10, 500, 100), device=gpu)
+    with pytest.raises(ValueError, match="Dataset contains only overhang"):
+        fast_deskew_zyx(x, 30, 0.1, keep_overhang=False)
+    with pytest.raises(ValueError):
+        fast_deskew_zyx(torch.zeros((4, 4), device=gpu), 30, 0.3, True)
+    with pytest.raises(ValueError):
+        fast_deskew_zyx(x, 30, 0.1, True, 1, "median")
+
+
+def test_fill_overhang_standalone(gpu):
+    from biahub_amd.deskew import fill_overhang
+
+    rng = np.random.default_rng(3)
+    vol = rng.random((20, 37, 150), dtype=np.float32) + 0.5
+    vol[:, :, :40] = 0
+    vol[5, 5, 100] = 0
+    vol[19, 36, 149] = 0
+    for it in (0, 1, 3):
+        want = O.fill_overhang(vol, None, it)
+        got = fill_overhang(torch.from_numpy(vol).to(gpu), None, it).cpu().numpy()
+        assert rel_err(got, want) <= 1e-6, it
+    want = O.fill_overhang(vol, 7.5, 3)
+    got = fill_overhang(torch.from_numpy(vol).to(gpu), 7.5, 3).cpu().numpy()
+    assert np.array_equal(got, want)
+    allzero = fill_overhang(torch.zeros((4, 5, 6), device=gpu), None).cpu().numpy()
+    assert np.isnan(allzero).all()  # mean of an empty selection is NaN in the reference too
+
+
+# ----------------------------------------------------------------------------- deconvolution
+def test_transfer_function_golden(gpu):
+    from biahub_amd.deconvolve import compute_tranfser_function
+
+    z = np.load(GOLDEN / "transfer_function.npz")
+    for j in range(4):
+        got = compute_tranfser_function(z[f"psf{j}"], tuple(int(v) for v in z[f"shape{j}"]))
+        assert got.shape == z[f"tf{j}"].shape and got.dtype == np.float32
+        assert rel_err(got, z[f"tf{j}"]) <= 1e-5, j
+
+
+@pytest.mark.parametrize("shape", [(16, 20, 24), (15, 21, 25), (32, 64, 48)])
+def test_tikhonov_vs_oracle(gpu, shape):
+    from biahub_amd.deconvolve import compute_tranfser_function, deconvolve
+
+    rng = np.random.default_rng(7)
+    psf = O.gaussian_psf((7, 5, 5), (1.5, 1.0, 1.0))
+    czyx = rng.random((2,) + shape, dtype=np.float32) * 100
+    tf = compute_tranfser_function(psf, shape)
+    assert rel_err(tf, O.compute_transfer_function(psf, shape)) <= 1e-5
+    got = deconvolve(czyx, transfer_function=tf, regularization_strength=1e-3)
+    want = O.deconvolve_czyx(czyx, tf, 1e-3)
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert rel_err(got, want) <= FFT_TOL
+
+
+@pytest.mark.parametrize("shape,pshape", [((16, 20, 24), (5, 5, 5)), ((15, 21, 25), (7, 5, 3)), ((32, 48, 64), (9, 7, 7))])
+def test_richardson_lucy_vs_oracle(gpu, shape, pshape):
+    from biahub_amd.deconvolve import richardson_lucy, richardson_lucy_czyx
+
+    vol = O.synthetic_volume(shape, seed=3, n_blobs=6)
+    psf = O.gaussian_psf(pshape, tuple(max(p / 5.0, 0.8) for p in pshape))
+    want = O.richardson_lucy_zyx(vol, psf, iterations=10, eps=1e-6)
+    got = richardson_lucy(torch.from_numpy(vol).to(gpu), torch.from_numpy(psf).to(gpu), 10, 1e-6).cpu().numpy()
+    assert rel_err(got, want) <= FFT_TOL
+    assert got.min() >= 0
+    assert abs(got.sum(dtype=np.float64) - vol.sum(dtype=np.float64)) / vol.sum(dtype=np.float64) < 1e-4  # flux kept
+    got0 = richardson_lucy(torch.from_numpy(vol).to(gpu), torch.from_numpy(psf).to(gpu), 0).cpu().numpy()
+    assert np.array_equal(got0, np.maximum(vol, 0))
+    c = richardson_lucy_czyx(np.stack([vol, vol]), psf, iterations=3)
+    assert c.shape == (2,) + shape and np.array_equal(c[0], c[1])
+
+
+# ----------------------------------------------------------------------------- affine
+def test_affine_reference_tests(gpu):
+    """tests/test_affine.py:26-59 of the reference, verbatim expectations."""
+    from biahub_amd.register import apply_affine_transform
+
+    ones = np.ones((10, 10, 10))
+    for interp in ("linear", "nearestneighbor"):
+        r = apply_affine_transform(ones, np.eye(4), (10, 10, 10), interpolation=interp)
+        assert isinstance(r, np.ndarray) and r.shape == (10, 10, 10)
+        assert np.all(r == 1)
+    m = np.eye(4)
+    m[:3, -1] = np.array([-3, 1, 4])
+    r = apply_affine_transform(ones, m, (10, 10, 10))
+    assert r.shape == (10, 10, 10)
+    assert np.all(r[3:10, 0:9, 0:6] == 1)
+    assert np.all(r[0:3] == 0)
+    with pytest.raises(ValueError, match="Unknown method"):
+        apply_affine_transform(ones, m, (10, 10, 10), method="cupy")
+
+
+def _similarity(angle_deg, scale, t):
+    th = np.deg2rad(angle_deg)
+    return np.array([[scale, 0, 0, t[0]], [0, scale * np.cos(th), -scale * np.sin(th), t[1]],
+                     [0, scale * np.sin(th), scale * np.cos(th), t[2]], [0, 0, 0, 1.0]])
+
+
+@pytest.mark.parametrize("interp", ["linear", "nearestneighbor"])
+@pytest.mark.parametrize("M", [
+    _similarity(2.0, 1.02, (3.5, -12.25, 20.75)),   # BASELINE config 3's ground-truth transform
+    _similarity(30.0, 0.7, (1.0, 20.0, -5.0)),
+    _similarity(90.0, 1.0, (0.0, 0.0, 39.0)),        # LDS box does not fit -> global gather path
+    np.array([[0.5, 0.1, 0.0, 2.0], [0.0, 1.5, 0.2, -3.0], [0.1, 0.0, 2.0, 1.0], [0, 0, 0, 1.0]]),
+])
+def test_affine_itk_mode_vs_oracle(gpu, M, interp):
+    from biahub_amd.register import apply_affine_transform
+
+    rng = np.random.default_rng(9)
+    vol = rng.random((24, 40, 72), dtype=np.float32) * 1000
+    vol[3, 4, 5] = np.nan
+    out_shape = (20, 44, 80)
+    want = O.apply_affine_transform(vol, M, out_shape, interp)
+    got = apply_affine_transform(vol, M, out_shape, interpolation=interp)
+    assert got.shape == want.shape and got.dtype == np.float32
+    if interp == "linear":
+        assert rel_err(got, want) <= 1e-5
+    else:
+        assert np.array_equal(got, want)
+    crop = (slice(2, 18), slice(5, 40), slice(7, 70))
+    got_c = apply_affine_transform(vol, M, out_shape, interpolation=interp, crop_output_slicing=crop)
+    assert np.array_equal(got_c, got[crop])  # the cropped launch equals slicing the full warp
+    got4 = apply_affine_transform(np.stack([vol, vol * 2]), M, out_shape, interpolation=interp)
+    assert got4.shape == (2,) + out_shape and np.array_equal(got4[0], got)
+
+
+def test_affine_scipy_mode_golden(gpu):
+    from biahub_amd.core.transform import Transform
+
+    z = np.load(GOLDEN / "transform_scipy.npz")
+    t = Transform(z["matrix"])
+    assert rel_err(t.apply(z["moving"], order=1), z["order1"]) <= 1e-5
+    assert np.array_equal(t.apply(z["moving"], order=0), z["order0"])
+    ref = np.zeros((10, 20, 18), np.float32)
+    assert rel_err(t.apply(z["moving"], reference=ref, order=1, cval=3.0), z["order1_ref"]) <= 1e-5
+    assert np.array_equal(Transform.from_translation([-3.0, 1.0, 4.0]).apply(np.ones((10, 10, 10), np.float32)),
+                          z["shift_int"])
+
+
+def test_stabilization_transform(gpu):
+    from biahub_amd.stabilize import apply_stabilization_transform
+
+    rng = np.random.default_rng(2)
+    vol = rng.random((2, 12, 30, 40), dtype=np.float32)
+    shifts = [np.eye(4), _similarity(0, 1, (0.5, -2.25, 3.0)), _similarity(1.0, 1, (0, 1, 1))]
+    for t in range(3):
+        got = apply_stabilization_transform(vol, shifts, t)
+        want = np.stack([O.apply_affine_transform(v, shifts[t], v.shape) for v in vol])
+        assert got.shape == vol.shape and rel_err(got, want) <= 1e-5
+    assert np.array_equal(apply_stabilization_transform(vol, shifts, 0), vol)  # identity is exact
+    with pytest.raises(IndexError):
+        apply_stabilization_transform(vol, shifts, 7)
+    big = apply_stabilization_transform(vol[0], shifts, 1, output_shape=(14, 32, 44))
+    assert big.shape == (14, 32, 44)
+
+
+# ----------------------------------------------------------------------------- crop / flip
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32, np.float64, np.int32])
+def test_crop_flip_bit_exact(gpu, dtype):
+    from biahub_amd.array_ops import copy_n_paste, copy_n_paste_czyx, flip_zyx
+
+    rng = np.random.default_rng(4)
+    a = (rng.random((3, 9, 17, 33)) * 200).astype(dtype)
+    s = [slice(2, 7), slice(0, 17), slice(5, 30)]
+    got = copy_n_paste_czyx(a, s)
+    assert got.dtype == a.dtype and np.array_equal(got, a[:, 2:7, 0:17, 5:30])
+    assert copy_n_paste_czyx(a, [slice(3, 3), slice(0, 5), slice(0, 5)]).shape == (3, 0, 5, 5)  # empty crop
+    for fx in (False, True):
+        for fy in (False, True):
+            assert np.array_equal(flip_zyx(a[0], x=fx, y=fy), O.flip_zyx(a[0], x=fx, y=fy))
+    if np.dtype(dtype).kind == "f":
+        f = a[0].copy()
+        f[1, 2, 3] = np.nan
+        f[4, 5, 6] = np.inf
+        f[4, 5, 7] = -np.inf
+        want = O.copy_n_paste(f, s)
+        got = copy_n_paste(f, s)
+        assert got.dtype == f.dtype and np.array_equal(got, want)  # nan_to_num incl. its +-inf handling
+    else:
+        assert np.array_equal(copy_n_paste(a[0], s), a[0][2:7, 0:17, 5:30])
+
+
+def test_flip_involution_large(gpu):
+    from biahub_amd.array_ops import crop_flip_device
+
+    t = torch.randint(0, 65535, (1, 64, 512, 1000), device=gpu, dtype=torch.int32).to(torch.int16)
+    once = crop_flip_device(t, (0, 0, 0), t.shape[1:], True, True)
+    assert torch.equal(once, t.flip([2, 3]))
+    assert torch.equal(crop_flip_device(once, (0, 0, 0), t.shape[1:], True, True), t)
