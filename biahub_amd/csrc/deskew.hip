@@ -22,6 +22,7 @@
 #include "common.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace bh {
 
@@ -52,18 +53,52 @@ __device__ __forceinline__ float to_f32(T v) {
     return (float)v;
 }
 
+template <typename T>
+struct Vec4;
+template <>
+struct Vec4<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct Vec4<uint16_t> {
+    typedef unsigned short type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct Vec4<int16_t> {
+    typedef short type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct Vec4<uint8_t> {
+    typedef unsigned char type __attribute__((ext_vector_type(4)));
+};
+
+// a / N, N a small positive integer: q = a*(1/N) corrected by one fused residual step
+// (r = a - q*N is exact in fma), which is the correctly rounded quotient for these operands.
+__device__ __forceinline__ float div_small(float a, float n, float rn) {
+    const float q = a * rn;
+    const float r = __builtin_fmaf(-q, n, a);
+    return __builtin_fmaf(r, rn, q);
+}
+
 // NK > 0: N == NK known at compile time (interpolation plan kept in registers).
 // NK == 0: generic N, plan recomputed per row.
-template <typename TIN, int TX, int NT, int NK>
+// TX = input-x columns per workgroup (row segment TX*sizeof(TIN) bytes, loaded 4 elements per lane);
+// J = outputs per lane per row, so one wave covers the whole XC = 64*J output chunk and the NT/64
+// waves take different rows.  LDS tile is [k][z][TX+1]: the odd row pitch makes both the staging
+// stores (lanes along x) and the compute loads (lanes along z) bank-conflict free.
+template <typename TIN, int TX, int J, int NK, int NT, bool DMA>
 __global__ __launch_bounds__(NT) void deskew_kernel(const TIN* __restrict__ in, float* __restrict__ out,
                                                     DeskewGeom g) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];  // [N][TX][ZS]
+#pragma clang fp contract(off)
+    constexpr int XC = 64 * J;
+    constexpr int PITCH = TX + 1;
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [N][ZC][PITCH]
     const int tid = threadIdx.x;
     const int xt0 = blockIdx.x * TX;
-    const int xo0 = blockIdx.y * g.XC;
+    const int xo0 = blockIdx.y * XC;
     const int a = blockIdx.z;
     const int N = NK > 0 ? NK : g.N;
-    const int xoN = min(g.XC, g.Xp - xo0);
+    const int xoN = min(XC, g.Xp - xo0);
     const int zo0 = a * N;
 
     // z-window covering every sample of this (a, xo-chunk): ix is monotone in xo and zo
@@ -72,99 +107,178 @@ __global__ __launch_bounds__(NT) void deskew_kernel(const TIN* __restrict__ in, 
     const int zlo = (int)floorf(ix_min);
     int zcnt = (int)floorf(ix_max) + 2 - zlo;
     zcnt = min(zcnt, g.ZC);  // host guarantees zcnt <= ZC; clamp is a memory-safety net only
+    const int kstride = g.ZC * PITCH;
 
-    // ---- stage: global (rows of TX contiguous x) -> LDS transposed [k][x][z] ----------
+    // Overhang chunk: every sample lies outside the scanned range, so the output is exactly 0
+    // (grid_sample zero padding) — stream zeros, touch neither the input nor LDS.
+    if (zlo + zcnt <= 0 || zlo >= g.Z) {
+        const int lane0 = tid & 63;
+        for (int xl = tid >> 6; xl < TX; xl += NT / 64) {
+            const int x = xt0 + xl;
+            if (x >= g.X) break;
+            float* orow = out + ((size_t)a * g.X + (g.X - 1 - x)) * g.Xp;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int xo = xo0 + lane0 + 64 * j;
+                if (xo < g.Xp) orow[xo] = 0.0f;
+            }
+        }
+        return;
+    }
+
+    // ---- stage: global rows (TX contiguous x) -> LDS [k][z][x] ------------------------------
+    // Fast path (float32, TX == 64, tile inside the volume): one LDS-DMA per row — every lane
+    // fetches 4 B of a 256-B row segment straight into LDS (wave-uniform row base + lane*4, so the
+    // odd row pitch is free), nothing is staged in VGPRs and all of a wave's rows are in flight
+    // at once.  Rows outside [0, Z) are zero-filled with ordinary LDS stores.
+    // Other dtypes / ragged tiles take the register path: unconditional (clamped address + select)
+    // vector loads, because predicated loads inside an unrolled loop serialise on gfx950 and cost
+    // ~30 % of HBM throughput (tools/membench*.hip).
     const size_t plane = (size_t)g.Y * g.X;
-    for (int k = 0; k < N; ++k) {
-        const int yin = g.Y - 1 - min(zo0 + k, g.Y - 1);
-        const TIN* src = in + (size_t)yin * g.X + xt0;
-        float* dst = tile + (size_t)k * TX * g.ZS;
-        const int xl = tid % TX;
-        const bool xok = (xt0 + xl) < g.X;
-        for (int zz = tid / TX; zz < zcnt; zz += NT / TX) {
-            const int z = zlo + zz;
-            float v = 0.0f;
-            if (xok && z >= 0 && z < g.Z) v = to_f32(src[(size_t)z * plane + xl]);
-            dst[xl * g.ZS + zz] = v;
+    if (DMA && TX == 64 && sizeof(TIN) == 4 && (xt0 + TX <= g.X)) {
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        constexpr int NW = NT / 64;
+        // rows of the window that exist in the volume: [za, zb) relative to zlo
+        const int za = max(0, -zlo), zb = min(zcnt, g.Z - zlo);
+        for (int k = 0; k < N; ++k) {
+            const int yin = g.Y - 1 - min(zo0 + k, g.Y - 1);
+            float* dk = tile + k * kstride;
+            for (int zz = wave; zz < za; zz += NW) dk[zz * PITCH + lane] = 0.0f;
+            for (int zz = max(zb, 0) + wave; zz < zcnt; zz += NW) dk[zz * PITCH + lane] = 0.0f;
+            const int z0 = za + wave;
+            const TIN* src = in + (size_t)(zlo + z0) * plane + (size_t)yin * g.X + xt0 + lane;
+            unsigned lds_dst = (unsigned)(size_t)(dk + z0 * PITCH);  // LDS byte address (wave-uniform)
+            for (int zz = z0; zz < zb; zz += NW) {
+                unsigned keep;
+                asm volatile(
+                    "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                    : "=&s"(keep)
+                    : "v"(src), "s"(lds_dst)
+                    : "memory");
+                src += (size_t)NW * plane;
+                lds_dst += NW * PITCH * 4;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not count asm LDS-DMA
+    } else {
+        typedef typename Vec4<TIN>::type V4;
+        constexpr int LPR = TX / 4;        // lanes per row
+        constexpr int ZSTEP = NT / LPR;    // rows per pass of the workgroup
+        constexpr int U = 8;
+        const int xq = (tid % LPR) * 4;
+        const int zz0 = tid / LPR;
+        const bool vec_ok = (xt0 + TX <= g.X) && ((g.X & 3) == 0);  // whole tile inside, rows 4-aligned
+        for (int k = 0; k < N; ++k) {
+            const int yin = g.Y - 1 - min(zo0 + k, g.Y - 1);
+            const TIN* src = in + (size_t)yin * g.X + xt0 + xq;
+            float* dst = tile + k * kstride + xq;
+            if (vec_ok) {
+                for (int zb = zz0; zb < zcnt; zb += ZSTEP * U) {
+                    V4 v[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int z = zlo + zb + u * ZSTEP;
+                        const int zc = max(0, min(z, g.Z - 1));
+                        v[u] = *reinterpret_cast<const V4*>(src + (size_t)zc * plane);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int zz = zb + u * ZSTEP;
+                        const int z = zlo + zz;
+                        const bool ok = z >= 0 && z < g.Z;
+                        if (zz < zcnt) {
+                            float* d = dst + zz * PITCH;
+                            d[0] = ok ? to_f32(v[u].x) : 0.0f;
+                            d[1] = ok ? to_f32(v[u].y) : 0.0f;
+                            d[2] = ok ? to_f32(v[u].z) : 0.0f;
+                            d[3] = ok ? to_f32(v[u].w) : 0.0f;
+                        }
+                    }
+                }
+            } else {  // ragged tile: scalar, clamped
+                for (int zz = zz0; zz < zcnt; zz += ZSTEP) {
+                    const int z = zlo + zz;
+                    const int zc = max(0, min(z, g.Z - 1));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int x = xt0 + xq + c;
+                        const float t = to_f32(in[(size_t)zc * plane + (size_t)yin * g.X + min(x, g.X - 1)]);
+                        dst[zz * PITCH + c] = (x < g.X && z == zc) ? t : 0.0f;
+                    }
+                }
+            }
         }
     }
     __syncthreads();
 
-    // ---- compute: lanes along xo, 4 outputs per lane spaced by 64 --------------------
-    constexpr int WAVES = NT / 64;
+    // ---- compute: lanes along xo, J outputs per lane spaced by 64; one wave per output row ----
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int WR = g.XC / 256;           // waves needed to cover one output row chunk
-    const int sub = wave % WR;           // which 256-wide part of the chunk
-    const int row0 = wave / WR;
-    const int RG = WAVES / WR;           // rows processed concurrently
-    const int xbase = xo0 + sub * 256 + lane;
+    const int xbase = xo0 + lane;
 
     constexpr int NKK = NK > 0 ? NK : 1;
-    int i0[NKK][4];
-    float w0[NKK][4], w1[NKK][4];
+    int i0[NKK][J];
+    float w0[NKK][J], w1[NKK][J];
     if (NK > 0) {
 #pragma unroll
         for (int k = 0; k < NKK; ++k)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < J; ++j) {
                 const float ix = deskew_ix(g.px, g.pxct, g.offset, g.zm1, xbase + 64 * j, zo0 + k);
                 const float fl = floorf(ix);
                 w1[k][j] = ix - fl;
                 w0[k][j] = (fl + 1.0f) - ix;
                 int rel = (int)fl - zlo;
                 rel = max(0, min(rel, g.ZC - 2));  // lanes past Xp may fall outside the window
-                i0[k][j] = k * TX * g.ZS + rel;
+                i0[k][j] = k * kstride + rel * PITCH;
             }
     }
-    const float invN_is_div = (float)N;
-    for (int xl = row0; xl < TX; xl += RG) {
+    const float fN = (float)N;
+    const float rN = 1.0f / fN;
+    for (int xl = wave; xl < TX; xl += NT / 64) {
         const int x = xt0 + xl;
         if (x >= g.X) break;
         const int yo = g.X - 1 - x;
         float* orow = out + ((size_t)a * g.X + yo) * g.Xp;
-        const float* trow = tile + xl * g.ZS;
-        float acc[4];
+        const float* tcol = tile + xl;
+        float acc[J];
         if (NK > 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < J; ++j) {
                 float s = 0.0f;
 #pragma unroll
                 for (int k = 0; k < NKK; ++k) {
-                    const float v0 = trow[i0[k][j]];
-                    const float v1 = trow[i0[k][j] + 1];
-                    const float val = v0 * w0[k][j] + v1 * w1[k][j];
+                    const float v0 = tcol[i0[k][j]];
+                    const float v1 = tcol[i0[k][j] + PITCH];
+                    const float val = __builtin_fmaf(v1, w1[k][j], v0 * w0[k][j]);
                     s = (k == 0) ? val : s + val;
                 }
                 acc[j] = s;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < J; ++j) {
                 float s = 0.0f;
                 for (int k = 0; k < N; ++k) {
                     const float ix = deskew_ix(g.px, g.pxct, g.offset, g.zm1, xbase + 64 * j, zo0 + k);
                     const float fl = floorf(ix);
                     int rel = (int)fl - zlo;
                     rel = max(0, min(rel, g.ZC - 2));
-                    const float* p = trow + k * TX * g.ZS + rel;
-                    const float val = p[0] * ((fl + 1.0f) - ix) + p[1] * (ix - fl);
+                    const float* p = tcol + k * kstride + rel * PITCH;
+                    const float val = __builtin_fmaf(p[PITCH], ix - fl, p[0] * ((fl + 1.0f) - ix));
                     s = (k == 0) ? val : s + val;
                 }
                 acc[j] = s;
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < J; ++j) {
             const int xo = xbase + 64 * j;
-            if (xo < g.Xp) orow[xo] = (N > 1) ? acc[j] / invN_is_div : acc[j];
+            if (xo < g.Xp) orow[xo] = (N > 1) ? div_small(acc[j], fN, rN) : acc[j];
         }
     }
 }
-
-struct LaunchCfg {
-    int TX, NT, XC;
-};
 
 static int deskew_geometry(int64_t Z, int64_t Y, int64_t X, double angle, double ratio, int keep_overhang,
                            int n, DeskewGeom* g, int64_t out_shape[3]) {
@@ -204,32 +318,16 @@ static int max_window(const DeskewGeom& g, int XC) {
     return worst;
 }
 
-template <typename TIN>
-static int launch_deskew(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g) {
-    constexpr int TX = 32;
-    constexpr int NT = 256;
-    // pick the largest chunk whose [N][TX][ZS] tile leaves room for two workgroups per CU
-    const size_t lds_budget = 78 * 1024;
-    int XC = 0, ZC = 0;
-    for (int cand : {1024, 512, 256}) {
-        if (cand > 256 && cand / 2 >= g.Xp) continue;  // do not over-size tiny problems
-        const int zc = max_window(g, cand);
-        const int zs = zc | 1;
-        if ((size_t)g.N * TX * zs * sizeof(float) <= lds_budget || cand == 256) {
-            XC = cand;
-            ZC = zc;
-            break;
-        }
-    }
+template <typename TIN, int TX, int J, int NT, bool DMA>
+static int launch_deskew_cfg(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g) {
+    constexpr int XC = 64 * J;
     g.XC = XC;
-    g.ZC = ZC;
-    g.ZS = ZC | 1;
-    const size_t lds = (size_t)g.N * TX * g.ZS * sizeof(float);
+    g.ZC = max_window(g, XC);
+    g.ZS = TX + 1;
+    const size_t lds = (size_t)g.N * g.ZC * (TX + 1) * sizeof(float);
     BH_REQUIRE(lds <= 160 * 1024,
                "deskew tile needs %zu bytes of LDS (px_to_scan_ratio=%g, average_n_slices=%d) — exceeds 160 KiB",
                lds, (double)g.px, g.N);
-    // waves per row chunk must divide the workgroup's wave count
-    BH_REQUIRE((NT / 64) % (XC / 256) == 0, "internal: XC=%d incompatible with %d threads", XC, NT);
     dim3 grid((unsigned)ceil_div(g.X, TX), (unsigned)ceil_div(g.Xp, XC), (unsigned)g.Za);
     BH_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "deskew grid too large (%u,%u,%u)", grid.x, grid.y, grid.z);
     auto run = [&](auto kern) -> int {
@@ -241,11 +339,42 @@ static int launch_deskew(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g) {
         return BH_OK;
     };
     switch (g.N) {
-        case 1: return run(deskew_kernel<TIN, TX, NT, 1>);
-        case 2: return run(deskew_kernel<TIN, TX, NT, 2>);
-        case 3: return run(deskew_kernel<TIN, TX, NT, 3>);
-        case 4: return run(deskew_kernel<TIN, TX, NT, 4>);
-        default: return run(deskew_kernel<TIN, TX, NT, 0>);
+        case 1: return run(deskew_kernel<TIN, TX, J, 1, NT, DMA>);
+        case 2: return run(deskew_kernel<TIN, TX, J, 2, NT, DMA>);
+        case 3: return run(deskew_kernel<TIN, TX, J, 3, NT, DMA>);
+        case 4: return run(deskew_kernel<TIN, TX, J, 4, NT, DMA>);
+        default: return run(deskew_kernel<TIN, TX, J, 0, NT, DMA>);
+    }
+}
+
+// LDS bytes of a (TX, J) configuration for this geometry
+static size_t cfg_lds(const DeskewGeom& g, int TX, int J) {
+    return (size_t)g.N * max_window(g, 64 * J) * (TX + 1) * sizeof(float);
+}
+
+template <typename TIN>
+static int launch_deskew(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g) {
+    // Candidates (TX, J, threads, LDS-DMA staging) from fastest measured (profiles/, tools/tune_deskew.py:
+    // 5.7 ms at 512x2048x2048 -> 683x2048x3034 for cfg 0) to smallest tile; take the first whose tile
+    // lets two workgroups share a CU, else the first that fits.  BH_DESKEW_CFG=<n> forces one.
+    int force = -1;
+    if (const char* e = getenv("BH_DESKEW_CFG")) force = atoi(e);
+    const size_t two_per_cu = 80 * 1024;
+    constexpr int NC = 5;
+    const int cand[NC][2] = {{64, 4}, {64, 2}, {32, 4}, {64, 1}, {32, 1}};
+    int pick = -1;
+    if (force >= 0 && force < NC) pick = force;
+    for (int i = 0; i < NC && pick < 0; ++i)
+        if (cfg_lds(g, cand[i][0], cand[i][1]) <= two_per_cu) pick = i;
+    for (int i = 0; i < NC && pick < 0; ++i)
+        if (cfg_lds(g, cand[i][0], cand[i][1]) <= 160 * 1024) pick = i;
+    if (pick < 0) pick = NC - 1;
+    switch (pick) {
+        case 0: return launch_deskew_cfg<TIN, 64, 4, 256, true>(ctx, in, out, g);
+        case 1: return launch_deskew_cfg<TIN, 64, 2, 256, true>(ctx, in, out, g);
+        case 2: return launch_deskew_cfg<TIN, 32, 4, 256, false>(ctx, in, out, g);
+        case 3: return launch_deskew_cfg<TIN, 64, 1, 256, true>(ctx, in, out, g);
+        default: return launch_deskew_cfg<TIN, 32, 1, 256, false>(ctx, in, out, g);
     }
 }
 
