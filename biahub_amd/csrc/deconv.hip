@@ -10,6 +10,9 @@
 // half-spectrum filter is exactly the reference's full-spectrum product.
 #include "common.hpp"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace bh {
 
 typedef float2 cf;
@@ -217,6 +220,82 @@ static inline dim3 grid_for(bh_ctx* ctx, int64_t n, int tb = 256) {
 
 static void pad_before(int64_t p, int64_t S, int* before) { *before = (int)((S - p) / 2); }
 
+// fused FFT-convolution engine (fftconv.hip)
+struct ConvPlan;
+bool fftconv_supported(int64_t Z, int64_t Y, int64_t X);
+int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out);
+size_t fftconv_spectrum_elems(const ConvPlan& pl);
+int fftconv_make_otf(bh_ctx* ctx, const ConvPlan& pl, const float* padded_psf, cf* otf);
+int fftconv_apply(bh_ctx* ctx, const ConvPlan& pl, const float* in, const cf* otf, bool correlate, cf* spec,
+                  int epilogue, const float* aux, float eps, float* out);
+
+static bool use_fused_engine(int64_t Z, int64_t Y, int64_t X) {
+    if (const char* e = getenv("BH_FFT_BACKEND"))
+        if (strcmp(e, "hipfft") == 0) return false;
+    return fftconv_supported(Z, Y, X);
+}
+
+// zero-padded, unit-sum, origin-centred PSF in `real` (V floats)
+static int stage_rl_psf(bh_ctx* ctx, const float* psf, int64_t pz, int64_t py, int64_t px, int64_t Z, int64_t Y,
+                        int64_t X, float* real, double* psum) {
+    hipStream_t s = ctx->stream;
+    BH_CHECK_HIP(hipMemsetAsync(real, 0, (size_t)Z * Y * X * sizeof(float), s));
+    hipLaunchKernelGGL(psf_sum_kernel, dim3(1), dim3(256), 0, s, psf, pz * py * px, psum);
+    int bz, by, bx;
+    pad_before(pz, Z, &bz);
+    pad_before(py, Y, &by);
+    pad_before(px, X, &bx);
+    hipLaunchKernelGGL(place_psf_kernel, grid_for(ctx, pz * py * px), dim3(256), 0, s, psf, real, (int)pz, (int)py,
+                       (int)px, Z, Y, X, bz, by, bx, bz + (int)(pz / 2), by + (int)(py / 2), bx + (int)(px / 2),
+                       (const double*)psum);
+    BH_CHECK_HIP(hipGetLastError());
+    return BH_OK;
+}
+
+// Richardson-Lucy on the fused engine: per iteration two 5-pass convolutions, the divide and the
+// multiply/clip ride in the inverse X passes.
+static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, int64_t pz, int64_t py, int64_t px,
+                                 int64_t Z, int64_t Y, int64_t X, int iterations, float eps, float* out) {
+    ConvPlan* pl;
+    BH_TRY(fftconv_plan(ctx, Z, Y, X, &pl));
+    const int64_t V = Z * Y * X;
+    const size_t NS = fftconv_spectrum_elems(*pl);
+    float* real;
+    cf *spec, *otf;
+    double* psum;
+    BH_TRY(get_scratch(ctx, "fft_real", V * sizeof(float), (void**)&real));
+    BH_TRY(get_scratch(ctx, "fc_spec", NS * sizeof(cf), (void**)&spec));
+    BH_TRY(get_scratch(ctx, "fc_otf", NS * sizeof(cf), (void**)&otf));
+    BH_TRY(get_scratch(ctx, "rl_psum", 64, (void**)&psum));
+    hipStream_t s = ctx->stream;
+    ScopedTimer timer(ctx, T_RL_TOTAL);
+    BH_TRY(stage_rl_psf(ctx, psf, pz, py, px, Z, Y, X, real, psum));
+    BH_TRY(fftconv_make_otf(ctx, *pl, real, otf));
+    hipLaunchKernelGGL(clip_copy_kernel, grid_for(ctx, V), dim3(256), 0, s, d, out, V);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing && iterations > 0) {
+        BH_CHECK_HIP(hipEventCreate(&e0));
+        BH_CHECK_HIP(hipEventCreate(&e1));
+        BH_CHECK_HIP(hipEventRecord(e0, s));
+    }
+    for (int it = 0; it < iterations; ++it) {
+        // ratio = d / max(h * est, eps)            (XE_RATIO = 1)
+        BH_TRY(fftconv_apply(ctx, *pl, out, otf, false, spec, 1, d, eps, real));
+        // est = max(est * (h~ * ratio), 0)          (XE_UPDATE = 2, aux = est, in place)
+        BH_TRY(fftconv_apply(ctx, *pl, real, otf, true, spec, 2, out, eps, out));
+    }
+    if (e0) {
+        BH_CHECK_HIP(hipEventRecord(e1, s));
+        BH_CHECK_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        BH_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ctx->ms_override[T_RL_ITER] = ms / iterations;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    return BH_OK;
+}
+
 }  // namespace bh
 
 using namespace bh;
@@ -285,16 +364,8 @@ int bh_richardson_lucy(bh_ctx* ctx, const float* in, const float* psf, int64_t p
     BH_REQUIRE(iterations >= 0, "iterations must be >= 0");
     BH_REQUIRE(pz > 0 && py > 0 && px > 0 && pz <= Z && py <= Y && px <= X, "PSF must fit inside the volume");
     BH_CHECK_HIP(hipSetDevice(ctx->device));
-    FftPlans* pl;
-    BH_TRY(get_plans(ctx, Z, Y, X, &pl));
     const int64_t V = Z * Y * X, Xh = X / 2 + 1, NS = Z * Y * Xh;
     float *real, *dcopy = nullptr;
-    cf *spec, *otf;
-    double* psum;
-    BH_TRY(get_scratch(ctx, "fft_real", V * sizeof(float), (void**)&real));
-    BH_TRY(get_scratch(ctx, "fft_spec", NS * sizeof(cf), (void**)&spec));
-    BH_TRY(get_scratch(ctx, "rl_otf", NS * sizeof(cf), (void**)&otf));
-    BH_TRY(get_scratch(ctx, "rl_psum", 64, (void**)&psum));
     hipStream_t s = ctx->stream;
     const float* d = in;
     if (in == out) {  // the estimate overwrites `out`; keep the data term
@@ -302,6 +373,15 @@ int bh_richardson_lucy(bh_ctx* ctx, const float* in, const float* psf, int64_t p
         BH_CHECK_HIP(hipMemcpyAsync(dcopy, in, V * sizeof(float), hipMemcpyDeviceToDevice, s));
         d = dcopy;
     }
+    if (use_fused_engine(Z, Y, X)) return richardson_lucy_fused(ctx, d, psf, pz, py, px, Z, Y, X, iterations, eps, out);
+    FftPlans* pl;
+    BH_TRY(get_plans(ctx, Z, Y, X, &pl));
+    cf *spec, *otf;
+    double* psum;
+    BH_TRY(get_scratch(ctx, "fft_real", V * sizeof(float), (void**)&real));
+    BH_TRY(get_scratch(ctx, "fft_spec", NS * sizeof(cf), (void**)&spec));
+    BH_TRY(get_scratch(ctx, "rl_otf", NS * sizeof(cf), (void**)&otf));
+    BH_TRY(get_scratch(ctx, "rl_psum", 64, (void**)&psum));
     ScopedTimer timer(ctx, T_RL_TOTAL);
     // OTF = rfftn(roll(pad(psf / sum), -centre)) / V   (the 1/V makes every C2R normalised)
     BH_CHECK_HIP(hipMemsetAsync(real, 0, V * sizeof(float), s));

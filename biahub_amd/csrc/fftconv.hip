@@ -1,0 +1,714 @@
+// Fused 3-D real FFT convolution engine for gfx950 (power-of-two volumes) — the Richardson-Lucy hot loop.
+//
+// hipFFT runs a 3-D R2C/C2R of a 512x2048x2048 volume as 5-7 kernels (row FFTs + transposes + a slow
+// strided z kernel), and every pointwise step between transforms is one more pass over HBM:
+// ~29 ms forward + ~23 ms inverse + 4 x 5.4 ms pointwise per convolution pair (profiles/r01a_*).
+// A convolution does not need the spectrum in natural order or natural layout, only a forward and an
+// inverse that agree with the transformed kernel (OTF).  So this engine
+//   * runs each axis as ONE in-place pass (no transposes), leaving every axis in the scrambled order its
+//     decimation-in-frequency FFT produces (bit-reversed; Y additionally split even/odd by a radix-2 step
+//     that is folded into the X pass so the Y pass fits LDS with 128-B row segments);
+//   * fuses forward-Z, the OTF multiply and inverse-Z into one kernel (a tile is loaded once);
+//   * fuses the real<->complex packing, and Richardson-Lucy's divide / multiply-clip, into the X passes.
+// One convolution = 5 passes, 48 B/voxel of HBM traffic (two per R-L iteration: 96 B/voxel, against the
+// 112 B/voxel of the 3-pass-per-FFT model and ~260 B/voxel measured for the hipFFT path).
+//
+// Layout of the half spectrum: S[z][y][p], p in [0, XP), XP = X/2 + 16 complex per row (128-B aligned
+// column tiles; column X/2 holds the Nyquist bin, the remaining pad columns stay zero).
+//
+// Each pass is a persistent kernel (one 1024-thread workgroup per CU) that walks 128-KiB tiles:
+// registers prefetch tile t+1 from HBM while the FFT of tile t runs out of LDS.
+#include "common.hpp"
+
+#include <cmath>
+#include <vector>
+
+namespace bh {
+
+typedef float2 cf;
+
+constexpr int FC_NT = 1024;        // threads per workgroup
+constexpr int FC_TILE = 16384;     // complex elements per column tile (128 KiB)
+constexpr int FC_XR = 16;          // rows per X-pass tile (8 row pairs)
+constexpr int FC_XPITCH = FC_XR + 1;
+
+__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cf cmulc(cf a, cf b) {  // a * conj(b)
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ cf cconj(cf a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ cf mul_mi(cf a) { return make_float2(a.y, -a.x); }  // a * (-i)
+__device__ __forceinline__ cf mul_pi(cf a) { return make_float2(-a.y, a.x); }  // a * (+i)
+__device__ __forceinline__ cf cscale(cf a, float s) { return make_float2(a.x * s, a.y * s); }
+
+// ------------------------------------------------------------------------------------------------
+// In-LDS, in-place FFT of W interleaved columns: element (n, c) at buf[n * P + c].
+// Forward = decimation in frequency, natural in -> bit-reversed out.  Inverse = the mirrored
+// decimation in time with conjugate twiddles, bit-reversed in -> natural out, unnormalised (x N).
+// Radix-4 steps are two fused radix-2 levels; an odd log2(N) adds one radix-2 step (first fwd / last inv).
+// Twiddle table (see make_twiddles): [radix-2: w_N^j, j < N/2 (only if log2 N odd)] then for each
+// radix-4 step of half-size h (descending) and j < h/2: w_2h^j, w_2h^2j, w_2h^3j.
+// ------------------------------------------------------------------------------------------------
+template <bool INV>
+__device__ __forceinline__ void radix4_step(cf* buf, int N, int logW, int P, int h, const cf* t, int tid) {
+    const int q = h >> 1;
+    const int W = 1 << logW;
+    const int total = (N >> 2) << logW;
+    for (int idx = tid; idx < total; idx += FC_NT) {
+        const int c = idx & (W - 1);
+        const int b = idx >> logW;
+        const int j = b & (q - 1);
+        const int i = ((b - j) << 2) + j;  // (b / q) * 2h + j
+        cf* p0 = buf + (size_t)i * P + c;
+        cf* p1 = p0 + (size_t)q * P;
+        cf* p2 = p1 + (size_t)q * P;
+        cf* p3 = p2 + (size_t)q * P;
+        const cf t1 = t[3 * j], t2 = t[3 * j + 1], t3 = t[3 * j + 2];
+        const cf x0 = *p0, x1 = *p1, x2 = *p2, x3 = *p3;
+        if (!INV) {
+            const cf s02 = cadd(x0, x2), d02 = csub(x0, x2);
+            const cf s13 = cadd(x1, x3), d13 = mul_mi(csub(x1, x3));
+            *p0 = cadd(s02, s13);
+            *p1 = cmul(csub(s02, s13), t2);
+            *p2 = cmul(cadd(d02, d13), t1);
+            *p3 = cmul(csub(d02, d13), t3);
+        } else {
+            const cf u1 = cmulc(x1, t2), u2 = cmulc(x2, t1), u3 = cmulc(x3, t3);
+            const cf A = cadd(x0, u1), B = csub(x0, u1);
+            const cf C = cadd(u2, u3), D = mul_pi(csub(u2, u3));
+            *p0 = cadd(A, C);
+            *p2 = csub(A, C);
+            *p1 = cadd(B, D);
+            *p3 = csub(B, D);
+        }
+    }
+}
+
+template <bool INV>
+__device__ __forceinline__ void radix2_step(cf* buf, int N, int logW, int P, const cf* t, int tid) {
+    const int h = N >> 1;
+    const int W = 1 << logW;
+    const int total = h << logW;
+    for (int idx = tid; idx < total; idx += FC_NT) {
+        const int c = idx & (W - 1);
+        const int j = idx >> logW;
+        cf* pa = buf + (size_t)j * P + c;
+        cf* pb = pa + (size_t)h * P;
+        const cf a = *pa, b = *pb, w = t[j];
+        if (!INV) {
+            *pa = cadd(a, b);
+            *pb = cmul(csub(a, b), w);
+        } else {
+            const cf ub = cmulc(b, w);
+            *pa = cadd(a, ub);
+            *pb = csub(a, ub);
+        }
+    }
+}
+
+template <bool INV>
+__device__ __forceinline__ void fft_lds(cf* buf, int N, int logN, int logW, int P, const cf* tw, int tid) {
+    const bool odd = logN & 1;
+    const int H0 = odd ? (N >> 2) : (N >> 1);
+    const cf* t4 = tw + (odd ? (N >> 1) : 0);
+    if (!INV) {
+        if (odd) {
+            radix2_step<false>(buf, N, logW, P, tw, tid);
+            __syncthreads();
+        }
+        for (int h = H0; h >= 2; h >>= 2) {
+            radix4_step<false>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
+            __syncthreads();
+        }
+    } else {
+        for (int h = 2; h <= H0; h <<= 2) {
+            radix4_step<true>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
+            __syncthreads();
+        }
+        if (odd) {
+            radix2_step<true>(buf, N, logW, P, tw, tid);
+            __syncthreads();
+        }
+    }
+}
+
+static int twiddle_count(int N) {
+    int logN = 0;
+    while ((1 << logN) < N) ++logN;
+    const bool odd = logN & 1;
+    const int H0 = odd ? N / 4 : N / 2;
+    int n = odd ? N / 2 : 0;
+    for (int h = H0; h >= 2; h /= 4) n += 3 * (h / 2);
+    return n;
+}
+
+static void make_twiddles(int N, std::vector<cf>& out) {
+    int logN = 0;
+    while ((1 << logN) < N) ++logN;
+    const bool odd = logN & 1;
+    const int H0 = odd ? N / 4 : N / 2;
+    out.clear();
+    if (odd)
+        for (int j = 0; j < N / 2; ++j) {
+            const double a = -2.0 * M_PI * j / N;
+            out.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
+        }
+    for (int h = H0; h >= 2; h /= 4)
+        for (int j = 0; j < h / 2; ++j)
+            for (int m = 1; m <= 3; ++m) {
+                const double a = -2.0 * M_PI * (double)j * m / (2.0 * h);
+                out.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
+            }
+}
+
+// position of frequency (M - k) when frequency k sits at bit-reversed position p
+__device__ __forceinline__ int mirror_pos(int p) {
+    if (p < 2) return p;
+    const int top = 31 - __clz(p);
+    return 3 * (1 << top) - 1 - p;
+}
+
+struct ConvDims {
+    int Z, Y, X;   // real volume
+    int M;         // X / 2 (complex FFT length along x)
+    int XP;        // spectrum row pitch in complex elements
+    int logM, logYh, logZ;
+};
+
+// ================================================================================================
+// Column passes (Y: two length-Y/2 halves per z; Z: fused forward x OTF x inverse)
+// ================================================================================================
+enum ColMode { COL_FWD = 0, COL_INV = 1, COL_FWD_SCALE = 2, COL_CONV = 3, COL_CORR = 4 };
+
+struct ColParams {
+    cf* S;
+    const cf* otf;
+    const cf* tw;       // twiddles for length N
+    int ntw;
+    int N, logN, W, logW;  // FFT length, tile width (complex columns)
+    int XP;             // valid columns per row
+    long row_stride;    // complex elements between consecutive n
+    long outer_stride;  // base(o) = (o / nsub) * outer_stride + (o % nsub) * sub_stride
+    long sub_stride;
+    int nsub;
+    int nouter;         // number of o values
+    int ncoltiles;
+    float scale;
+};
+
+template <int MODE, int ROUNDS>
+__global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* buf = reinterpret_cast<cf*>(smem);                         // [N][W]
+    cf* tw = reinterpret_cast<cf*>(smem + (size_t)p.N * p.W * 8);  // twiddles
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.ntw; i += FC_NT) tw[i] = p.tw[i];
+
+    const int LPS = p.W >> 1;           // lanes per row segment (float4 = 2 complex)
+    const int RPR = FC_NT / LPS;        // rows per round
+    const int lane = tid % LPS;
+    const int r0 = tid / LPS;
+    const long ntiles = (long)p.nouter * p.ncoltiles;
+    constexpr bool HAS_OTF = (MODE == COL_CONV || MODE == COL_CORR);
+
+    float4 v[ROUNDS];
+    auto tile_base = [&](long t) -> long {
+        const long ou = t / p.ncoltiles;
+        const int ct = (int)(t - ou * p.ncoltiles);
+        return (ou / p.nsub) * p.outer_stride + (ou % p.nsub) * p.sub_stride + (long)ct * p.W + 2 * lane;
+    };
+    auto load_tile = [&](const cf* src, long t, float4* dst) {
+        const long base = tile_base(t);
+#pragma unroll
+        for (int u = 0; u < ROUNDS; ++u) {
+            const int r = min(r0 + u * RPR, p.N - 1);  // unconditional, clamped (see deskew.hip on predicated loads)
+            dst[u] = *reinterpret_cast<const float4*>(src + base + (long)r * p.row_stride);
+        }
+    };
+
+    long t = blockIdx.x;
+    if (t < ntiles) load_tile(p.S, t, v);
+    for (; t < ntiles; t += gridDim.x) {
+        // registers -> LDS
+#pragma unroll
+        for (int u = 0; u < ROUNDS; ++u) {
+            const int r = r0 + u * RPR;
+            if (r < p.N) *reinterpret_cast<float4*>(buf + (size_t)r * p.W + 2 * lane) = v[u];
+        }
+        const long base = tile_base(t);
+        const int ct = (int)(t % p.ncoltiles);
+        const bool col_ok = (ct * p.W + 2 * lane) < p.XP;  // pad columns of a ragged last tile are never stored
+        __syncthreads();
+        const long tn = t + gridDim.x;
+        if (HAS_OTF) {
+            // this tile's OTF arrives behind the forward FFT; the next tile's data behind the inverse FFT
+            load_tile(p.otf, t, v);
+            fft_lds<false>(buf, p.N, p.logN, p.logW, p.W, tw, tid);
+#pragma unroll
+            for (int u = 0; u < ROUNDS; ++u) {
+                const int r = r0 + u * RPR;
+                if (r < p.N) {
+                    float4* q = reinterpret_cast<float4*>(buf + (size_t)r * p.W + 2 * lane);
+                    const float4 a = *q;
+                    const float4 b = v[u];
+                    float4 c;
+                    if (MODE == COL_CONV) {
+                        c.x = a.x * b.x - a.y * b.y;
+                        c.y = a.x * b.y + a.y * b.x;
+                        c.z = a.z * b.z - a.w * b.w;
+                        c.w = a.z * b.w + a.w * b.z;
+                    } else {
+                        c.x = a.x * b.x + a.y * b.y;
+                        c.y = a.y * b.x - a.x * b.y;
+                        c.z = a.z * b.z + a.w * b.w;
+                        c.w = a.w * b.z - a.z * b.w;
+                    }
+                    *q = c;
+                }
+            }
+            __syncthreads();
+            if (tn < ntiles) load_tile(p.S, tn, v);
+            fft_lds<true>(buf, p.N, p.logN, p.logW, p.W, tw, tid);
+        } else {
+            if (tn < ntiles) load_tile(p.S, tn, v);  // prefetch the next tile behind the FFT
+            if (MODE == COL_INV) {
+                fft_lds<true>(buf, p.N, p.logN, p.logW, p.W, tw, tid);
+            } else {
+                fft_lds<false>(buf, p.N, p.logN, p.logW, p.W, tw, tid);
+            }
+        }
+        // LDS -> global
+#pragma unroll
+        for (int u = 0; u < ROUNDS; ++u) {
+            const int r = r0 + u * RPR;
+            if (r < p.N && col_ok) {
+                float4 a = *reinterpret_cast<const float4*>(buf + (size_t)r * p.W + 2 * lane);
+                if (MODE == COL_FWD_SCALE) {
+                    a.x *= p.scale;
+                    a.y *= p.scale;
+                    a.z *= p.scale;
+                    a.w *= p.scale;
+                }
+                *reinterpret_cast<float4*>(p.S + base + (long)r * p.row_stride) = a;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ================================================================================================
+// X passes: real rows <-> half-spectrum rows, with the Y radix-2 step across row pairs (y, y + Y/2)
+// ================================================================================================
+enum XEpilogue { XE_STORE = 0, XE_RATIO = 1, XE_UPDATE = 2 };
+
+struct XParams {
+    const float* in;      // forward: real input volume
+    cf* S;                // spectrum
+    float* out;           // inverse: real output volume
+    const float* aux;     // inverse: d (ratio) or est (update)
+    const cf* tw;         // twiddles for length M
+    const cf* untangle;   // w_X^{brev(p)}, p < M
+    int ntw;
+    ConvDims d;
+    float eps;
+};
+
+// tile = (z, group g): rows c < 8 -> y = 8g + c ; rows c >= 8 -> y = 8g + (c - 8) + Y/2
+__device__ __forceinline__ long x_row_index(const ConvDims& d, long tile, int c) {
+    const int gpz = d.Y / FC_XR;  // groups per z
+    const long z = tile / gpz;
+    const int g = (int)(tile - z * gpz);
+    const int y = 8 * g + (c & 7) + ((c >> 3) ? d.Y / 2 : 0);
+    return z * d.Y + y;
+}
+
+template <int ROUNDS>
+__global__ __launch_bounds__(FC_NT) void x_fwd_kernel(XParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ConvDims d = p.d;
+    const int M = d.M;
+    cf* buf = reinterpret_cast<cf*>(smem);                                  // [(M + 1)][17]
+    cf* tw = buf + (size_t)(M + 1) * FC_XPITCH;
+    cf* ut = tw + p.ntw;                                                    // [M]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.ntw; i += FC_NT) tw[i] = p.tw[i];
+    for (int i = tid; i < M; i += FC_NT) ut[i] = p.untangle[i];
+
+    const int QPR = M >> 1;                 // float4 per real row
+    const int RPR = FC_NT / QPR;            // rows per round (QPR <= 512)
+    const int q = tid % QPR;
+    const int rr = tid / QPR;
+    const long ntiles = (long)d.Z * (d.Y / FC_XR);
+
+    float4 v[ROUNDS];
+    auto load_tile = [&](long t) {
+#pragma unroll
+        for (int u = 0; u < ROUNDS; ++u) {
+            const int c = min(rr + u * RPR, FC_XR - 1);
+            v[u] = *reinterpret_cast<const float4*>(p.in + x_row_index(d, t, c) * d.X + 4 * q);
+        }
+    };
+    long t = blockIdx.x;
+    if (t < ntiles) load_tile(t);
+    for (; t < ntiles; t += gridDim.x) {
+#pragma unroll
+        for (int u = 0; u < ROUNDS; ++u) {
+            const int c = rr + u * RPR;
+            if (c < FC_XR) {
+                buf[(size_t)(2 * q) * FC_XPITCH + c] = make_float2(v[u].x, v[u].y);
+                buf[(size_t)(2 * q + 1) * FC_XPITCH + c] = make_float2(v[u].z, v[u].w);
+            }
+        }
+        __syncthreads();
+        const long tn = t + gridDim.x;
+        if (tn < ntiles) load_tile(tn);
+
+        fft_lds<false>(buf, M, d.logM, 4, FC_XPITCH, tw, tid);
+
+        // untangle in place: pairs (p, mirror(p)); u = 0 handles p = 0 (DC + Nyquist) and p = 1
+        for (int idx = tid; idx < (M >> 1) * FC_XR; idx += FC_NT) {
+            const int c = idx % FC_XR;
+            const int u = idx / FC_XR;
+            if (u == 0) {
+                const cf z0 = buf[c];
+                buf[c] = make_float2(z0.x + z0.y, 0.0f);                              // X[0]
+                buf[(size_t)M * FC_XPITCH + c] = make_float2(z0.x - z0.y, 0.0f);      // X[M] (Nyquist)
+                if (M > 1) {
+                    const cf z1 = buf[FC_XPITCH + c];                                  // k = M/2: w^k = -i
+                    buf[FC_XPITCH + c] = cconj(z1);
+                }
+            } else {
+                const int top = 31 - __clz(u);
+                const int pp = (2 << top) + (u - (1 << top));
+                const int pm = 3 * (2 << top) - 1 - pp;
+                const cf a = buf[(size_t)pp * FC_XPITCH + c], b = buf[(size_t)pm * FC_XPITCH + c];
+                const cf E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));   // (a + conj b)/2
+                const cf Dm = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));  // (a - conj b)/2
+                const cf O = mul_mi(Dm);                                              // -i (a - conj b)/2
+                const cf wO = cmul(ut[pp], O);
+                buf[(size_t)pp * FC_XPITCH + c] = cadd(E, wO);
+                buf[(size_t)pm * FC_XPITCH + c] = cconj(csub(E, wO));
+            }
+        }
+        __syncthreads();
+
+        // Y radix-2 step across the row pair + store rows (pad columns written as zero)
+        const int gpz = d.Y / FC_XR;
+        const long z = t / gpz;
+        const int g = (int)(t - z * gpz);
+        for (int idx = tid; idx < 8 * d.XP; idx += FC_NT) {
+            const int pcol = idx % d.XP;
+            const int rp = idx / d.XP;
+            const int y = 8 * g + rp;
+            cf A = make_float2(0.f, 0.f), B = A;
+            if (pcol <= M) {
+                const cf xa = buf[(size_t)pcol * FC_XPITCH + rp], xb = buf[(size_t)pcol * FC_XPITCH + rp + 8];
+                float sn, cs;
+                sincospif(-2.0f * (float)y / (float)d.Y, &sn, &cs);
+                A = cadd(xa, xb);
+                B = cmul(csub(xa, xb), make_float2(cs, sn));
+            }
+            p.S[((long)z * d.Y + y) * d.XP + pcol] = A;
+            p.S[((long)z * d.Y + y + d.Y / 2) * d.XP + pcol] = B;
+        }
+        __syncthreads();
+    }
+}
+
+template <int EPI, int ROUNDS>
+__global__ __launch_bounds__(FC_NT) void x_inv_kernel(XParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ConvDims d = p.d;
+    const int M = d.M;
+    cf* buf = reinterpret_cast<cf*>(smem);  // [(M + 1)][17]
+    cf* tw = buf + (size_t)(M + 1) * FC_XPITCH;
+    cf* ut = tw + p.ntw;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.ntw; i += FC_NT) tw[i] = p.tw[i];
+    for (int i = tid; i < M; i += FC_NT) ut[i] = p.untangle[i];
+
+    const int QPR = M >> 1;
+    const int RPR = FC_NT / QPR;
+    const int q = tid % QPR;
+    const int rr = tid / QPR;
+    const int gpz = d.Y / FC_XR;
+    const long ntiles = (long)d.Z * gpz;
+
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long z = t / gpz;
+        const int g = (int)(t - z * gpz);
+        // load spectrum rows of 8 pairs, undo the Y radix-2 step, write X[p] into LDS (transposed)
+        for (int idx = tid; idx < 8 * (M + 1); idx += FC_NT) {
+            const int pcol = idx % (M + 1);
+            const int rp = idx / (M + 1);
+            const int y = 8 * g + rp;
+            const cf A = p.S[((long)z * d.Y + y) * d.XP + pcol];
+            const cf B = p.S[((long)z * d.Y + y + d.Y / 2) * d.XP + pcol];
+            float sn, cs;
+            sincospif(-2.0f * (float)y / (float)d.Y, &sn, &cs);
+            const cf ub = cmulc(B, make_float2(cs, sn));
+            buf[(size_t)pcol * FC_XPITCH + rp] = cadd(A, ub);
+            buf[(size_t)pcol * FC_XPITCH + rp + 8] = csub(A, ub);
+        }
+        __syncthreads();
+        // inverse untangle in place: Zf[k] = E + i O, E = (X[k] + conj X[M-k])/2, O = (X[k] - conj X[M-k])/2 * conj(w^k)
+        for (int idx = tid; idx < (M >> 1) * FC_XR; idx += FC_NT) {
+            const int c = idx % FC_XR;
+            const int u = idx / FC_XR;
+            if (u == 0) {
+                const float x0 = buf[c].x, xm = buf[(size_t)M * FC_XPITCH + c].x;
+                buf[c] = make_float2(0.5f * (x0 + xm), 0.5f * (x0 - xm));
+                if (M > 1) buf[FC_XPITCH + c] = cconj(buf[FC_XPITCH + c]);
+            } else {
+                const int top = 31 - __clz(u);
+                const int pp = (2 << top) + (u - (1 << top));
+                const int pm = 3 * (2 << top) - 1 - pp;
+                const cf a = buf[(size_t)pp * FC_XPITCH + c], b = buf[(size_t)pm * FC_XPITCH + c];
+                const cf E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+                const cf Dm = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
+                const cf O = cmulc(Dm, ut[pp]);
+                const cf iO = mul_pi(O);
+                buf[(size_t)pp * FC_XPITCH + c] = cadd(E, iO);
+                // partner: Zf[M-k] = conj(E) + i conj(O) = conj(E - i O)
+                buf[(size_t)pm * FC_XPITCH + c] = cconj(csub(E, iO));
+            }
+        }
+        __syncthreads();
+        fft_lds<true>(buf, M, d.logM, 4, FC_XPITCH, tw, tid);
+        // natural order now: z[j] = x[2j] + i x[2j+1]; write real rows with the fused epilogue
+#pragma unroll
+        for (int u = 0; u < ROUNDS; ++u) {
+            const int c = rr + u * RPR;
+            if (c < FC_XR) {
+                const cf e0 = buf[(size_t)(2 * q) * FC_XPITCH + c], e1 = buf[(size_t)(2 * q + 1) * FC_XPITCH + c];
+                float4 r = make_float4(e0.x, e0.y, e1.x, e1.y);
+                const long off = x_row_index(d, t, c) * d.X + 4 * q;
+                if (EPI == XE_RATIO) {
+                    const float4 dd = *reinterpret_cast<const float4*>(p.aux + off);
+                    r.x = dd.x / fmaxf(r.x, p.eps);
+                    r.y = dd.y / fmaxf(r.y, p.eps);
+                    r.z = dd.z / fmaxf(r.z, p.eps);
+                    r.w = dd.w / fmaxf(r.w, p.eps);
+                } else if (EPI == XE_UPDATE) {
+                    const float4 e = *reinterpret_cast<const float4*>(p.aux + off);
+                    r.x = fmaxf(e.x * r.x, 0.0f);
+                    r.y = fmaxf(e.y * r.y, 0.0f);
+                    r.z = fmaxf(e.z * r.z, 0.0f);
+                    r.w = fmaxf(e.w * r.w, 0.0f);
+                }
+                *reinterpret_cast<float4*>(p.out + off) = r;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+struct ConvPlan {
+    ConvDims d;
+    cf *tw_x = nullptr, *tw_y = nullptr, *tw_z = nullptr, *untangle = nullptr;
+    int ntw_x = 0, ntw_y = 0, ntw_z = 0;
+    int Wy = 0, Wz = 0;
+};
+
+static int ilog2(long v) {
+    int l = 0;
+    while ((1l << l) < v) ++l;
+    return l;
+}
+
+bool fftconv_supported(int64_t Z, int64_t Y, int64_t X) {
+    auto pow2 = [](int64_t v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (!pow2(Z) || !pow2(Y) || !pow2(X)) return false;
+    if (X < 64 || X > 2048) return false;          // M = X/2 in [32, 1024]: (M+1)*17*8 + tables <= 160 KiB
+    if (Y < 2 * 16 || Y / 2 > 2048) return false;   // Y/2 rows x >= 8 columns per tile, whole groups of 16 rows
+    if (Z < 4 || Z > 2048) return false;
+    if ((Y % FC_XR) != 0) return false;
+    const int M = (int)X / 2;
+    const size_t xlds = (size_t)(M + 1) * FC_XPITCH * 8 + (size_t)twiddle_count(M) * 8 + (size_t)M * 8;
+    return xlds <= 160 * 1024;
+}
+
+static std::map<std::tuple<int, int64_t, int64_t, int64_t>, ConvPlan> g_plans;
+
+static int upload(const std::vector<cf>& h, cf** dptr) {
+    BH_CHECK_HIP(hipMalloc(dptr, h.size() * sizeof(cf) + 16));
+    BH_CHECK_HIP(hipMemcpy(*dptr, h.data(), h.size() * sizeof(cf), hipMemcpyHostToDevice));
+    return BH_OK;
+}
+
+int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
+    auto key = std::make_tuple(ctx->device, Z, Y, X);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) {
+        *out = &it->second;
+        return BH_OK;
+    }
+    ConvPlan pl;
+    pl.d.Z = (int)Z;
+    pl.d.Y = (int)Y;
+    pl.d.X = (int)X;
+    pl.d.M = (int)X / 2;
+    pl.d.XP = (int)X / 2 + 16;
+    pl.d.logM = ilog2(X / 2);
+    pl.d.logYh = ilog2(Y / 2);
+    pl.d.logZ = ilog2(Z);
+    std::vector<cf> h;
+    make_twiddles(pl.d.M, h);
+    pl.ntw_x = (int)h.size();
+    BH_TRY(upload(h, &pl.tw_x));
+    make_twiddles((int)Y / 2, h);
+    pl.ntw_y = (int)h.size();
+    BH_TRY(upload(h, &pl.tw_y));
+    make_twiddles((int)Z, h);
+    pl.ntw_z = (int)h.size();
+    BH_TRY(upload(h, &pl.tw_z));
+    h.resize(pl.d.M);
+    for (int pp = 0; pp < pl.d.M; ++pp) {
+        int k = 0;
+        for (int b = 0; b < pl.d.logM; ++b)
+            if (pp & (1 << b)) k |= 1 << (pl.d.logM - 1 - b);
+        const double a = -2.0 * M_PI * k / (double)X;
+        h[pp] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    BH_TRY(upload(h, &pl.untangle));
+    auto tile_w = [&](int64_t N) {
+        int w = (int)(FC_TILE / N);
+        if (w > 64) w = 64;       // 512-B row segments are plenty
+        if (w > pl.d.XP) w = 16;
+        return w < 2 ? 2 : w;
+    };
+    pl.Wy = tile_w(Y / 2);
+    pl.Wz = tile_w(Z);
+    auto ins = g_plans.emplace(key, pl);
+    *out = &ins.first->second;
+    return BH_OK;
+}
+
+size_t fftconv_spectrum_elems(const ConvPlan& pl) {
+    return (size_t)pl.d.Z * pl.d.Y * pl.d.XP + 64;  // slack: a ragged last column tile reads past its row
+}
+
+static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf* S, const cf* otf, float scale) {
+    ColParams p;
+    p.S = S;
+    p.otf = otf;
+    p.XP = pl.d.XP;
+    p.scale = scale;
+    if (!zaxis) {
+        p.N = pl.d.Y / 2;
+        p.logN = pl.d.logYh;
+        p.W = pl.Wy;
+        p.tw = pl.tw_y;
+        p.ntw = pl.ntw_y;
+        p.row_stride = pl.d.XP;
+        p.outer_stride = (long)pl.d.Y * pl.d.XP;
+        p.sub_stride = (long)(pl.d.Y / 2) * pl.d.XP;
+        p.nsub = 2;
+        p.nouter = pl.d.Z * 2;
+    } else {
+        p.N = pl.d.Z;
+        p.logN = pl.d.logZ;
+        p.W = pl.Wz;
+        p.tw = pl.tw_z;
+        p.ntw = pl.ntw_z;
+        p.row_stride = (long)pl.d.Y * pl.d.XP;
+        p.outer_stride = pl.d.XP;
+        p.sub_stride = 0;
+        p.nsub = 1;
+        p.nouter = pl.d.Y;
+    }
+    p.logW = ilog2(p.W);
+    p.ncoltiles = (int)ceil_div(pl.d.XP, p.W);
+    BH_REQUIRE((long)p.N * p.W <= FC_TILE && (long)p.N * (p.W / 2) <= 8l * FC_NT && (FC_NT % (p.W / 2)) == 0,
+               "internal: column tile %dx%d unsupported", p.N, p.W);
+    const size_t lds = (size_t)p.N * p.W * 8 + (size_t)p.ntw * 8;
+    const long ntiles = (long)p.nouter * p.ncoltiles;
+    const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
+    auto run = [&](auto kern) -> int {
+        BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(FC_NT), lds, ctx->stream, p);
+        BH_CHECK_HIP(hipGetLastError());
+        return BH_OK;
+    };
+    const long per_round = (long)(FC_NT / (p.W / 2));
+    const int rounds = (int)ceil_div(p.N, per_round);
+#define BH_COL_DISPATCH(R)                                            \
+    switch (mode) {                                                   \
+        case COL_FWD: return run(col_pass_kernel<COL_FWD, R>);        \
+        case COL_INV: return run(col_pass_kernel<COL_INV, R>);        \
+        case COL_FWD_SCALE: return run(col_pass_kernel<COL_FWD_SCALE, R>); \
+        case COL_CONV: return run(col_pass_kernel<COL_CONV, R>);      \
+        default: return run(col_pass_kernel<COL_CORR, R>);            \
+    }
+    if (rounds <= 1) { BH_COL_DISPATCH(1) }
+    if (rounds <= 2) { BH_COL_DISPATCH(2) }
+    if (rounds <= 4) { BH_COL_DISPATCH(4) }
+    BH_COL_DISPATCH(8)
+#undef BH_COL_DISPATCH
+}
+
+static int launch_x(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, const float* in, cf* S, float* out,
+                    const float* aux, float eps) {
+    XParams p;
+    p.in = in;
+    p.S = S;
+    p.out = out;
+    p.aux = aux;
+    p.tw = pl.tw_x;
+    p.untangle = pl.untangle;
+    p.ntw = pl.ntw_x;
+    p.d = pl.d;
+    p.eps = eps;
+    const size_t lds = (size_t)(pl.d.M + 1) * FC_XPITCH * 8 + (size_t)pl.ntw_x * 8 + (size_t)pl.d.M * 8;
+    const long ntiles = (long)pl.d.Z * (pl.d.Y / FC_XR);
+    const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
+    auto run = [&](auto kern) -> int {
+        BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(FC_NT), lds, ctx->stream, p);
+        BH_CHECK_HIP(hipGetLastError());
+        return BH_OK;
+    };
+    const int QPR = pl.d.M / 2;
+    const int rounds = (int)ceil_div(FC_XR, std::max(1, FC_NT / QPR));
+#define BH_X_DISPATCH(R)                                                  \
+    if (!inverse) return run(x_fwd_kernel<R>);                            \
+    switch (epi) {                                                        \
+        case XE_STORE: return run(x_inv_kernel<XE_STORE, R>);             \
+        case XE_RATIO: return run(x_inv_kernel<XE_RATIO, R>);             \
+        default: return run(x_inv_kernel<XE_UPDATE, R>);                  \
+    }
+    if (rounds <= 1) { BH_X_DISPATCH(1) }
+    if (rounds <= 2) { BH_X_DISPATCH(2) }
+    if (rounds <= 4) { BH_X_DISPATCH(4) }
+    BH_X_DISPATCH(8)
+#undef BH_X_DISPATCH
+}
+
+// OTF (scrambled order, scaled by 2/V so that forward -> multiply -> inverse is a normalised convolution)
+int fftconv_make_otf(bh_ctx* ctx, const ConvPlan& pl, const float* padded_psf, cf* otf) {
+    const double V = (double)pl.d.Z * pl.d.Y * pl.d.X;
+    BH_TRY(launch_x(ctx, pl, false, 0, padded_psf, otf, nullptr, nullptr, 0.f));
+    BH_TRY(launch_col(ctx, pl, COL_FWD, false, otf, nullptr, 1.f));
+    BH_TRY(launch_col(ctx, pl, COL_FWD_SCALE, true, otf, nullptr, (float)(2.0 / V)));
+    return BH_OK;
+}
+
+// out = epilogue( irfft( rfft(in) * OTF or conj(OTF) ) )
+int fftconv_apply(bh_ctx* ctx, const ConvPlan& pl, const float* in, const cf* otf, bool correlate, cf* spec,
+                  int epilogue, const float* aux, float eps, float* out) {
+    BH_TRY(launch_x(ctx, pl, false, 0, in, spec, nullptr, nullptr, 0.f));
+    BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));
+    BH_TRY(launch_col(ctx, pl, correlate ? COL_CORR : COL_CONV, true, spec, otf, 1.f));
+    BH_TRY(launch_col(ctx, pl, COL_INV, false, spec, nullptr, 1.f));
+    BH_TRY(launch_x(ctx, pl, true, epilogue, nullptr, spec, out, aux, eps));
+    return BH_OK;
+}
+
+}  // namespace bh

@@ -298,3 +298,30 @@ def test_flip_involution_large(gpu):
     once = crop_flip_device(t, (0, 0, 0), t.shape[1:], True, True)
     assert torch.equal(once, t.flip([2, 3]))
     assert torch.equal(crop_flip_device(once, (0, 0, 0), t.shape[1:], True, True), t)
+
+
+# ----------------------------------------------------------------------------- fused FFT-convolution engine
+@pytest.mark.parametrize("shape,pshape", [
+    ((16, 32, 64), (5, 5, 5)),       # smallest supported tile shapes
+    ((8, 64, 128), (3, 7, 9)),       # log2(Z) odd, log2(Y/2) odd
+    ((64, 64, 64), (9, 9, 9)),
+    ((32, 128, 256), (9, 7, 7)),
+    ((4, 32, 512), (3, 5, 17)),
+    ((128, 32, 1024), (17, 5, 9)),
+])
+def test_richardson_lucy_fused_engine_vs_oracle(gpu, shape, pshape, monkeypatch):
+    """Power-of-two volumes take the fused engine (csrc/fftconv.hip); it must agree with the oracle and with
+    the hipFFT path (BH_FFT_BACKEND=hipfft) that the other shapes use."""
+    from biahub_amd.deconvolve import richardson_lucy
+
+    vol = O.synthetic_volume(shape, seed=5, n_blobs=10)
+    psf = O.gaussian_psf(pshape, tuple(max(p / 5.0, 0.7) for p in pshape))
+    psf[0, 0, 0] += 0.01  # break the PSF's symmetry so conj(OTF) != OTF is exercised
+    want = O.richardson_lucy_zyx(vol, psf, iterations=5, eps=1e-6)
+    v, pt = torch.from_numpy(vol).to(gpu), torch.from_numpy(psf).to(gpu)
+    got = richardson_lucy(v, pt, 5, 1e-6).cpu().numpy()
+    assert rel_err(got, want) <= FFT_TOL, rel_err(got, want)
+    monkeypatch.setenv("BH_FFT_BACKEND", "hipfft")
+    got_hipfft = richardson_lucy(v, pt, 5, 1e-6).cpu().numpy()
+    assert rel_err(got_hipfft, want) <= FFT_TOL
+    assert rel_err(got, got_hipfft) <= FFT_TOL
