@@ -51,84 +51,175 @@ __device__ __forceinline__ cf cscale(cf a, float s) { return make_float2(a.x * s
 // Twiddle table (see make_twiddles): [radix-2: w_N^j, j < N/2 (only if log2 N odd)] then for each
 // radix-4 step of half-size h (descending) and j < h/2: w_2h^j, w_2h^2j, w_2h^3j.
 // ------------------------------------------------------------------------------------------------
-template <bool INV>
+// CPT = complex columns per thread (1: float2 accesses, any pitch; 2: float4 accesses, pitch even and
+// 16-B aligned).  BPT = butterflies per thread and step, fully unrolled so that every LDS read of a step
+// is in flight before the first butterfly is computed.
+template <int CPT>
+struct CV;
+template <>
+struct CV<1> {
+    cf a;
+    __device__ __forceinline__ static CV ld(const cf* p) { return CV{*p}; }
+    __device__ __forceinline__ void st(cf* p) const { *p = a; }
+};
+template <>
+struct CV<2> {
+    cf a, b;
+    __device__ __forceinline__ static CV ld(const cf* p) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        return CV{make_float2(v.x, v.y), make_float2(v.z, v.w)};
+    }
+    __device__ __forceinline__ void st(cf* p) const { *reinterpret_cast<float4*>(p) = make_float4(a.x, a.y, b.x, b.y); }
+};
+
+#define BH_CV_OP1(name, f)                                                                  \
+    template <int CPT>                                                                      \
+    __device__ __forceinline__ CV<CPT> name(const CV<CPT>& x);                              \
+    template <>                                                                             \
+    __device__ __forceinline__ CV<1> name<1>(const CV<1>& x) { return CV<1>{f(x.a)}; }      \
+    template <>                                                                             \
+    __device__ __forceinline__ CV<2> name<2>(const CV<2>& x) { return CV<2>{f(x.a), f(x.b)}; }
+#define BH_CV_OP2(name, f)                                                                                    \
+    template <int CPT>                                                                                        \
+    __device__ __forceinline__ CV<CPT> name(const CV<CPT>& x, const CV<CPT>& y);                              \
+    template <>                                                                                               \
+    __device__ __forceinline__ CV<1> name<1>(const CV<1>& x, const CV<1>& y) { return CV<1>{f(x.a, y.a)}; }   \
+    template <>                                                                                               \
+    __device__ __forceinline__ CV<2> name<2>(const CV<2>& x, const CV<2>& y) {                                \
+        return CV<2>{f(x.a, y.a), f(x.b, y.b)};                                                               \
+    }
+#define BH_CV_OPT(name, f)                                                                             \
+    template <int CPT>                                                                                 \
+    __device__ __forceinline__ CV<CPT> name(const CV<CPT>& x, cf t);                                   \
+    template <>                                                                                        \
+    __device__ __forceinline__ CV<1> name<1>(const CV<1>& x, cf t) { return CV<1>{f(x.a, t)}; }        \
+    template <>                                                                                        \
+    __device__ __forceinline__ CV<2> name<2>(const CV<2>& x, cf t) { return CV<2>{f(x.a, t), f(x.b, t)}; }
+BH_CV_OP2(vadd, cadd)
+BH_CV_OP2(vsub, csub)
+BH_CV_OP1(vmul_mi, mul_mi)
+BH_CV_OP1(vmul_pi, mul_pi)
+BH_CV_OPT(vmul, cmul)
+BH_CV_OPT(vmulc, cmulc)
+#undef BH_CV_OP1
+#undef BH_CV_OP2
+#undef BH_CV_OPT
+
+template <bool INV, int BPT, int CPT>
 __device__ __forceinline__ void radix4_step(cf* buf, int N, int logW, int P, int h, const cf* t, int tid) {
     const int q = h >> 1;
-    const int W = 1 << logW;
-    const int total = (N >> 2) << logW;
-    for (int idx = tid; idx < total; idx += FC_NT) {
-        const int c = idx & (W - 1);
-        const int b = idx >> logW;
+    const int lw = logW - (CPT == 2 ? 1 : 0);       // log2 of column groups per row
+    const int total = (N >> 2) << lw;
+    const size_t qP = (size_t)q * P;
+    // all threads run the same number of groups; ragged tails clamp the index and skip the store
+    const bool ragged = (total % (BPT * FC_NT)) != 0;
+    for (int g0 = 0; g0 < total; g0 += BPT * FC_NT) {
+    CV<CPT> x0[BPT], x1[BPT], x2[BPT], x3[BPT];
+    cf t1[BPT], t2[BPT], t3[BPT];
+    cf* p0[BPT];
+#pragma unroll
+    for (int k = 0; k < BPT; ++k) {
+        const int idx = min(g0 + tid + k * FC_NT, total - 1);
+        const int c = (idx & ((1 << lw) - 1)) * CPT;
+        const int b = idx >> lw;
         const int j = b & (q - 1);
         const int i = ((b - j) << 2) + j;  // (b / q) * 2h + j
-        cf* p0 = buf + (size_t)i * P + c;
-        cf* p1 = p0 + (size_t)q * P;
-        cf* p2 = p1 + (size_t)q * P;
-        cf* p3 = p2 + (size_t)q * P;
-        const cf t1 = t[3 * j], t2 = t[3 * j + 1], t3 = t[3 * j + 2];
-        const cf x0 = *p0, x1 = *p1, x2 = *p2, x3 = *p3;
-        if (!INV) {
-            const cf s02 = cadd(x0, x2), d02 = csub(x0, x2);
-            const cf s13 = cadd(x1, x3), d13 = mul_mi(csub(x1, x3));
-            *p0 = cadd(s02, s13);
-            *p1 = cmul(csub(s02, s13), t2);
-            *p2 = cmul(cadd(d02, d13), t1);
-            *p3 = cmul(csub(d02, d13), t3);
-        } else {
-            const cf u1 = cmulc(x1, t2), u2 = cmulc(x2, t1), u3 = cmulc(x3, t3);
-            const cf A = cadd(x0, u1), B = csub(x0, u1);
-            const cf C = cadd(u2, u3), D = mul_pi(csub(u2, u3));
-            *p0 = cadd(A, C);
-            *p2 = csub(A, C);
-            *p1 = cadd(B, D);
-            *p3 = csub(B, D);
+        p0[k] = buf + (size_t)i * P + c;
+        x0[k] = CV<CPT>::ld(p0[k]);
+        x1[k] = CV<CPT>::ld(p0[k] + qP);
+        x2[k] = CV<CPT>::ld(p0[k] + 2 * qP);
+        x3[k] = CV<CPT>::ld(p0[k] + 3 * qP);
+        t1[k] = t[3 * j];
+        t2[k] = t[3 * j + 1];
+        t3[k] = t[3 * j + 2];
+    }
+    if (ragged) __syncthreads();  // clamped duplicates must all read before anyone writes
+#pragma unroll
+    for (int k = 0; k < BPT; ++k) {
+        if (g0 + tid + k * FC_NT < total) {
+            if (!INV) {
+                const CV<CPT> s02 = vadd<CPT>(x0[k], x2[k]), d02 = vsub<CPT>(x0[k], x2[k]);
+                const CV<CPT> s13 = vadd<CPT>(x1[k], x3[k]), d13 = vmul_mi<CPT>(vsub<CPT>(x1[k], x3[k]));
+                vadd<CPT>(s02, s13).st(p0[k]);
+                vmul<CPT>(vsub<CPT>(s02, s13), t2[k]).st(p0[k] + qP);
+                vmul<CPT>(vadd<CPT>(d02, d13), t1[k]).st(p0[k] + 2 * qP);
+                vmul<CPT>(vsub<CPT>(d02, d13), t3[k]).st(p0[k] + 3 * qP);
+            } else {
+                const CV<CPT> u1 = vmulc<CPT>(x1[k], t2[k]), u2 = vmulc<CPT>(x2[k], t1[k]), u3 = vmulc<CPT>(x3[k], t3[k]);
+                const CV<CPT> A = vadd<CPT>(x0[k], u1), B = vsub<CPT>(x0[k], u1);
+                const CV<CPT> C = vadd<CPT>(u2, u3), D = vmul_pi<CPT>(vsub<CPT>(u2, u3));
+                vadd<CPT>(A, C).st(p0[k]);
+                vsub<CPT>(A, C).st(p0[k] + 2 * qP);
+                vadd<CPT>(B, D).st(p0[k] + qP);
+                vsub<CPT>(B, D).st(p0[k] + 3 * qP);
+            }
         }
+    }
+    if (ragged) __syncthreads();
     }
 }
 
-template <bool INV>
+template <bool INV, int BPT, int CPT>
 __device__ __forceinline__ void radix2_step(cf* buf, int N, int logW, int P, const cf* t, int tid) {
     const int h = N >> 1;
-    const int W = 1 << logW;
-    const int total = h << logW;
-    for (int idx = tid; idx < total; idx += FC_NT) {
-        const int c = idx & (W - 1);
-        const int j = idx >> logW;
-        cf* pa = buf + (size_t)j * P + c;
-        cf* pb = pa + (size_t)h * P;
-        const cf a = *pa, b = *pb, w = t[j];
-        if (!INV) {
-            *pa = cadd(a, b);
-            *pb = cmul(csub(a, b), w);
-        } else {
-            const cf ub = cmulc(b, w);
-            *pa = cadd(a, ub);
-            *pb = csub(a, ub);
+    const int lw = logW - (CPT == 2 ? 1 : 0);
+    const int total = h << lw;
+    const size_t hP = (size_t)h * P;
+    constexpr int B2 = 2 * BPT;  // a radix-2 step has twice the butterflies of a radix-4 step
+    const bool ragged = (total % (B2 * FC_NT)) != 0;
+    for (int g0 = 0; g0 < total; g0 += B2 * FC_NT) {
+    CV<CPT> a[B2], b[B2];
+    cf w[B2];
+    cf* pa[B2];
+#pragma unroll
+    for (int k = 0; k < B2; ++k) {
+        const int idx = min(g0 + tid + k * FC_NT, total - 1);
+        const int c = (idx & ((1 << lw) - 1)) * CPT;
+        const int j = idx >> lw;
+        pa[k] = buf + (size_t)j * P + c;
+        a[k] = CV<CPT>::ld(pa[k]);
+        b[k] = CV<CPT>::ld(pa[k] + hP);
+        w[k] = t[j];
+    }
+    if (ragged) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < B2; ++k) {
+        if (g0 + tid + k * FC_NT < total) {
+            if (!INV) {
+                vadd<CPT>(a[k], b[k]).st(pa[k]);
+                vmul<CPT>(vsub<CPT>(a[k], b[k]), w[k]).st(pa[k] + hP);
+            } else {
+                const CV<CPT> ub = vmulc<CPT>(b[k], w[k]);
+                vadd<CPT>(a[k], ub).st(pa[k]);
+                vsub<CPT>(a[k], ub).st(pa[k] + hP);
+            }
         }
+    }
+    if (ragged) __syncthreads();
     }
 }
 
-template <bool INV>
+template <bool INV, int BPT, int CPT>
 __device__ __forceinline__ void fft_lds(cf* buf, int N, int logN, int logW, int P, const cf* tw, int tid) {
     const bool odd = logN & 1;
     const int H0 = odd ? (N >> 2) : (N >> 1);
     const cf* t4 = tw + (odd ? (N >> 1) : 0);
     if (!INV) {
         if (odd) {
-            radix2_step<false>(buf, N, logW, P, tw, tid);
+            radix2_step<false, BPT, CPT>(buf, N, logW, P, tw, tid);
             __syncthreads();
         }
         for (int h = H0; h >= 2; h >>= 2) {
-            radix4_step<false>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
+            radix4_step<false, BPT, CPT>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
             __syncthreads();
         }
     } else {
         for (int h = 2; h <= H0; h <<= 2) {
-            radix4_step<true>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
+            radix4_step<true, BPT, CPT>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
             __syncthreads();
         }
         if (odd) {
-            radix2_step<true>(buf, N, logW, P, tw, tid);
+            radix2_step<true, BPT, CPT>(buf, N, logW, P, tw, tid);
             __syncthreads();
         }
     }
@@ -198,6 +289,10 @@ struct ColParams {
     float scale;
 };
 
+// The prefetch registers are eight named float4 (not an array: hipcc keeps a loop-carried float4[8]
+// in scratch memory here even with every index constant).
+#define BH_FOR8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+
 template <int MODE, int ROUNDS>
 __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -212,90 +307,94 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
     const int r0 = tid / LPS;
     const long ntiles = (long)p.nouter * p.ncoltiles;
     constexpr bool HAS_OTF = (MODE == COL_CONV || MODE == COL_CORR);
+    const int ncoltiles = p.ncoltiles, nsub = p.nsub, W_ = p.W, N_ = p.N, logN = p.logN, logW = p.logW, XP = p.XP;
+    const long outer_stride = p.outer_stride, sub_stride = p.sub_stride, row_stride = p.row_stride;
+    cf* const S = p.S;
+    const cf* const otf = p.otf;
+    const float scale = p.scale;
+    auto tile_base = [=](long tt) -> long {
+        const long ou = tt / ncoltiles;
+        const int ct = (int)(tt - ou * ncoltiles);
+        return (ou / nsub) * outer_stride + (ou % nsub) * sub_stride + (long)ct * W_ + 2 * lane;
+    };
 
-    float4 v[ROUNDS];
-    auto tile_base = [&](long t) -> long {
-        const long ou = t / p.ncoltiles;
-        const int ct = (int)(t - ou * p.ncoltiles);
-        return (ou / p.nsub) * p.outer_stride + (ou % p.nsub) * p.sub_stride + (long)ct * p.W + 2 * lane;
-    };
-    auto load_tile = [&](const cf* src, long t, float4* dst) {
-        const long base = tile_base(t);
-#pragma unroll
-        for (int u = 0; u < ROUNDS; ++u) {
-            const int r = min(r0 + u * RPR, p.N - 1);  // unconditional, clamped (see deskew.hip on predicated loads)
-            dst[u] = *reinterpret_cast<const float4*>(src + base + (long)r * p.row_stride);
-        }
-    };
+    float4 v0, v1, v2, v3, v4, v5, v6, v7;
+    v0 = v1 = v2 = v3 = v4 = v5 = v6 = v7 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // unconditional, clamped row loads (see deskew.hip on predicated loads)
+#define BH_LD(u) \
+    if (u < ROUNDS) v##u = *reinterpret_cast<const float4*>(src_ + (long)min(r0 + u * RPR, N_ - 1) * row_stride);
+#define BH_LOAD_TILE(SRC, T)                     \
+    {                                            \
+        const cf* src_ = (SRC) + tile_base(T);   \
+        BH_FOR8(BH_LD)                           \
+    }
+#define BH_TO_LDS(u)                                                                            \
+    if (u < ROUNDS && r0 + u * RPR < N_)                                                        \
+        *reinterpret_cast<float4*>(buf + (size_t)(r0 + u * RPR) * W_ + 2 * lane) = v##u;
+#define BH_OTF_MUL(u)                                                                           \
+    if (u < ROUNDS && r0 + u * RPR < N_) {                                                      \
+        float4* q_ = reinterpret_cast<float4*>(buf + (size_t)(r0 + u * RPR) * W_ + 2 * lane);   \
+        const float4 a = *q_;                                                                   \
+        const float4 b = v##u;                                                                  \
+        float4 c;                                                                               \
+        if (MODE == COL_CONV) {                                                                 \
+            c.x = a.x * b.x - a.y * b.y;                                                        \
+            c.y = a.x * b.y + a.y * b.x;                                                        \
+            c.z = a.z * b.z - a.w * b.w;                                                        \
+            c.w = a.z * b.w + a.w * b.z;                                                        \
+        } else {                                                                                \
+            c.x = a.x * b.x + a.y * b.y;                                                        \
+            c.y = a.y * b.x - a.x * b.y;                                                        \
+            c.z = a.z * b.z + a.w * b.w;                                                        \
+            c.w = a.w * b.z - a.z * b.w;                                                        \
+        }                                                                                       \
+        *q_ = c;                                                                                \
+    }
+#define BH_STORE(u)                                                                                        \
+    if (u < ROUNDS && r0 + u * RPR < N_ && col_ok) {                                                       \
+        float4 a = *reinterpret_cast<const float4*>(buf + (size_t)(r0 + u * RPR) * W_ + 2 * lane);         \
+        if (MODE == COL_FWD_SCALE) {                                                                       \
+            a.x *= scale;                                                                                  \
+            a.y *= scale;                                                                                  \
+            a.z *= scale;                                                                                  \
+            a.w *= scale;                                                                                  \
+        }                                                                                                  \
+        *reinterpret_cast<float4*>(S + base + (long)(r0 + u * RPR) * row_stride) = a;                      \
+    }
 
     long t = blockIdx.x;
-    if (t < ntiles) load_tile(p.S, t, v);
+    if (t < ntiles) BH_LOAD_TILE(S, t)
     for (; t < ntiles; t += gridDim.x) {
-        // registers -> LDS
-#pragma unroll
-        for (int u = 0; u < ROUNDS; ++u) {
-            const int r = r0 + u * RPR;
-            if (r < p.N) *reinterpret_cast<float4*>(buf + (size_t)r * p.W + 2 * lane) = v[u];
-        }
+        BH_FOR8(BH_TO_LDS)  // registers -> LDS
         const long base = tile_base(t);
-        const int ct = (int)(t % p.ncoltiles);
-        const bool col_ok = (ct * p.W + 2 * lane) < p.XP;  // pad columns of a ragged last tile are never stored
+        const int ct = (int)(t % ncoltiles);
+        const bool col_ok = (ct * W_ + 2 * lane) < XP;  // pad columns of a ragged last tile are never stored
         __syncthreads();
         const long tn = t + gridDim.x;
         if (HAS_OTF) {
             // this tile's OTF arrives behind the forward FFT; the next tile's data behind the inverse FFT
-            load_tile(p.otf, t, v);
-            fft_lds<false>(buf, p.N, p.logN, p.logW, p.W, tw, tid);
-#pragma unroll
-            for (int u = 0; u < ROUNDS; ++u) {
-                const int r = r0 + u * RPR;
-                if (r < p.N) {
-                    float4* q = reinterpret_cast<float4*>(buf + (size_t)r * p.W + 2 * lane);
-                    const float4 a = *q;
-                    const float4 b = v[u];
-                    float4 c;
-                    if (MODE == COL_CONV) {
-                        c.x = a.x * b.x - a.y * b.y;
-                        c.y = a.x * b.y + a.y * b.x;
-                        c.z = a.z * b.z - a.w * b.w;
-                        c.w = a.z * b.w + a.w * b.z;
-                    } else {
-                        c.x = a.x * b.x + a.y * b.y;
-                        c.y = a.y * b.x - a.x * b.y;
-                        c.z = a.z * b.z + a.w * b.w;
-                        c.w = a.w * b.z - a.z * b.w;
-                    }
-                    *q = c;
-                }
-            }
+            BH_LOAD_TILE(otf, t)
+            fft_lds<false, 1, 2>(buf, N_, logN, logW, W_, tw, tid);
+            BH_FOR8(BH_OTF_MUL)
             __syncthreads();
-            if (tn < ntiles) load_tile(p.S, tn, v);
-            fft_lds<true>(buf, p.N, p.logN, p.logW, p.W, tw, tid);
+            if (tn < ntiles) BH_LOAD_TILE(S, tn)
+            fft_lds<true, 1, 2>(buf, N_, logN, logW, W_, tw, tid);
         } else {
-            if (tn < ntiles) load_tile(p.S, tn, v);  // prefetch the next tile behind the FFT
+            if (tn < ntiles) BH_LOAD_TILE(S, tn)  // prefetch the next tile behind the FFT
             if (MODE == COL_INV) {
-                fft_lds<true>(buf, p.N, p.logN, p.logW, p.W, tw, tid);
+                fft_lds<true, 1, 2>(buf, N_, logN, logW, W_, tw, tid);
             } else {
-                fft_lds<false>(buf, p.N, p.logN, p.logW, p.W, tw, tid);
+                fft_lds<false, 1, 2>(buf, N_, logN, logW, W_, tw, tid);
             }
         }
-        // LDS -> global
-#pragma unroll
-        for (int u = 0; u < ROUNDS; ++u) {
-            const int r = r0 + u * RPR;
-            if (r < p.N && col_ok) {
-                float4 a = *reinterpret_cast<const float4*>(buf + (size_t)r * p.W + 2 * lane);
-                if (MODE == COL_FWD_SCALE) {
-                    a.x *= p.scale;
-                    a.y *= p.scale;
-                    a.z *= p.scale;
-                    a.w *= p.scale;
-                }
-                *reinterpret_cast<float4*>(p.S + base + (long)r * p.row_stride) = a;
-            }
-        }
+        BH_FOR8(BH_STORE)  // LDS -> global
         __syncthreads();
     }
+#undef BH_LD
+#undef BH_LOAD_TILE
+#undef BH_TO_LDS
+#undef BH_OTF_MUL
+#undef BH_STORE
 }
 
 // ================================================================================================
@@ -365,7 +464,7 @@ __global__ __launch_bounds__(FC_NT) void x_fwd_kernel(XParams p) {
         const long tn = t + gridDim.x;
         if (tn < ntiles) load_tile(tn);
 
-        fft_lds<false>(buf, M, d.logM, 4, FC_XPITCH, tw, tid);
+        fft_lds<false, 2, 1>(buf, M, d.logM, 4, FC_XPITCH, tw, tid);
 
         // untangle in place: pairs (p, mirror(p)); u = 0 handles p = 0 (DC + Nyquist) and p = 1
         for (int idx = tid; idx < (M >> 1) * FC_XR; idx += FC_NT) {
@@ -476,7 +575,7 @@ __global__ __launch_bounds__(FC_NT) void x_inv_kernel(XParams p) {
             }
         }
         __syncthreads();
-        fft_lds<true>(buf, M, d.logM, 4, FC_XPITCH, tw, tid);
+        fft_lds<true, 2, 1>(buf, M, d.logM, 4, FC_XPITCH, tw, tid);
         // natural order now: z[j] = x[2j] + i x[2j+1]; write real rows with the fused epilogue
 #pragma unroll
         for (int u = 0; u < ROUNDS; ++u) {
