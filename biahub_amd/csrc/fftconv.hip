@@ -409,6 +409,7 @@ struct XParams {
     const float* aux;     // inverse: d (ratio) or est (update)
     const cf* tw;         // twiddles for length M
     const cf* untangle;   // w_X^{brev(p)}, p < M
+    const cf* twy;        // w_Y^y, y < Y/2
     int ntw;
     ConvDims d;
     float eps;
@@ -421,6 +422,44 @@ __device__ __forceinline__ long x_row_index(const ConvDims& d, long tile, int c)
     const int g = (int)(tile - z * gpz);
     const int y = 8 * g + (c & 7) + ((c >> 3) ? d.Y / 2 : 0);
     return z * d.Y + y;
+}
+
+// untangle in place after the packed length-M FFT: pairs (p, mirror(p)); u = 0 handles DC + Nyquist and p = 1
+template <bool INV>
+__device__ __forceinline__ void untangle_lds(cf* buf, const cf* ut, int M, int tid) {
+    for (int idx = tid; idx < (M >> 1) * FC_XR; idx += FC_NT) {
+        const int c = idx % FC_XR;
+        const int u = idx / FC_XR;
+        if (u == 0) {
+            if (!INV) {
+                const cf z0 = buf[c];
+                buf[c] = make_float2(z0.x + z0.y, 0.0f);                          // X[0]
+                buf[(size_t)M * FC_XPITCH + c] = make_float2(z0.x - z0.y, 0.0f);  // X[M] (Nyquist)
+            } else {
+                const float x0 = buf[c].x, xm = buf[(size_t)M * FC_XPITCH + c].x;
+                buf[c] = make_float2(0.5f * (x0 + xm), 0.5f * (x0 - xm));
+            }
+            buf[FC_XPITCH + c] = cconj(buf[FC_XPITCH + c]);  // k = M/2: w^k = -i
+        } else {
+            const int top = 31 - __clz(u);
+            const int pp = (2 << top) + (u - (1 << top));
+            const int pm = 3 * (2 << top) - 1 - pp;
+            const cf a = buf[(size_t)pp * FC_XPITCH + c], b = buf[(size_t)pm * FC_XPITCH + c];
+            const cf E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));   // (a + conj b)/2
+            const cf Dm = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));  // (a - conj b)/2
+            if (!INV) {
+                // X[k] = E + w^k O, O = -i (a - conj b)/2 ; X[M-k] = conj(E - w^k O)
+                const cf wO = cmul(ut[pp], mul_mi(Dm));
+                buf[(size_t)pp * FC_XPITCH + c] = cadd(E, wO);
+                buf[(size_t)pm * FC_XPITCH + c] = cconj(csub(E, wO));
+            } else {
+                // Zf[k] = E + i O, O = (X[k] - conj X[M-k])/2 conj(w^k) ; Zf[M-k] = conj(E - i O)
+                const cf iO = mul_pi(cmulc(Dm, ut[pp]));
+                buf[(size_t)pp * FC_XPITCH + c] = cadd(E, iO);
+                buf[(size_t)pm * FC_XPITCH + c] = cconj(csub(E, iO));
+            }
+        }
+    }
 }
 
 template <int ROUNDS>
@@ -439,7 +478,9 @@ __global__ __launch_bounds__(FC_NT) void x_fwd_kernel(XParams p) {
     const int RPR = FC_NT / QPR;            // rows per round (QPR <= 512)
     const int q = tid % QPR;
     const int rr = tid / QPR;
-    const long ntiles = (long)d.Z * (d.Y / FC_XR);
+    const int gpz = d.Y / FC_XR;
+    const long ntiles = (long)d.Z * gpz;
+    constexpr int HALF = ROUNDS / 2;        // rounds u and u + HALF hold the rows y and y + Y/2
 
     float4 v[ROUNDS];
     auto load_tile = [&](long t) {
@@ -465,52 +506,54 @@ __global__ __launch_bounds__(FC_NT) void x_fwd_kernel(XParams p) {
         if (tn < ntiles) load_tile(tn);
 
         fft_lds<false, 2, 1>(buf, M, d.logM, 4, FC_XPITCH, tw, tid);
-
-        // untangle in place: pairs (p, mirror(p)); u = 0 handles p = 0 (DC + Nyquist) and p = 1
-        for (int idx = tid; idx < (M >> 1) * FC_XR; idx += FC_NT) {
-            const int c = idx % FC_XR;
-            const int u = idx / FC_XR;
-            if (u == 0) {
-                const cf z0 = buf[c];
-                buf[c] = make_float2(z0.x + z0.y, 0.0f);                              // X[0]
-                buf[(size_t)M * FC_XPITCH + c] = make_float2(z0.x - z0.y, 0.0f);      // X[M] (Nyquist)
-                if (M > 1) {
-                    const cf z1 = buf[FC_XPITCH + c];                                  // k = M/2: w^k = -i
-                    buf[FC_XPITCH + c] = cconj(z1);
-                }
-            } else {
-                const int top = 31 - __clz(u);
-                const int pp = (2 << top) + (u - (1 << top));
-                const int pm = 3 * (2 << top) - 1 - pp;
-                const cf a = buf[(size_t)pp * FC_XPITCH + c], b = buf[(size_t)pm * FC_XPITCH + c];
-                const cf E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));   // (a + conj b)/2
-                const cf Dm = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));  // (a - conj b)/2
-                const cf O = mul_mi(Dm);                                              // -i (a - conj b)/2
-                const cf wO = cmul(ut[pp], O);
-                buf[(size_t)pp * FC_XPITCH + c] = cadd(E, wO);
-                buf[(size_t)pm * FC_XPITCH + c] = cconj(csub(E, wO));
-            }
-        }
+        untangle_lds<false>(buf, ut, M, tid);
         __syncthreads();
 
-        // Y radix-2 step across the row pair + store rows (pad columns written as zero)
-        const int gpz = d.Y / FC_XR;
+        // Y radix-2 step across each row pair, then store the spectrum rows
         const long z = t / gpz;
         const int g = (int)(t - z * gpz);
-        for (int idx = tid; idx < 8 * d.XP; idx += FC_NT) {
-            const int pcol = idx % d.XP;
-            const int rp = idx / d.XP;
-            const int y = 8 * g + rp;
-            cf A = make_float2(0.f, 0.f), B = A;
-            if (pcol <= M) {
-                const cf xa = buf[(size_t)pcol * FC_XPITCH + rp], xb = buf[(size_t)pcol * FC_XPITCH + rp + 8];
-                float sn, cs;
-                sincospif(-2.0f * (float)y / (float)d.Y, &sn, &cs);
-                A = cadd(xa, xb);
-                B = cmul(csub(xa, xb), make_float2(cs, sn));
+        if (ROUNDS >= 2) {
+            // this thread's rounds u and u + HALF are exactly a pair (y, y + Y/2): two columns per lane, 16-B stores
+#pragma unroll
+            for (int u = 0; u < (HALF > 0 ? HALF : 1); ++u) {
+                const int c = rr + u * RPR;  // < 8
+                const int y = 8 * g + c;
+                const cf w = p.twy[y];
+                const cf xa0 = buf[(size_t)(2 * q) * FC_XPITCH + c], xb0 = buf[(size_t)(2 * q) * FC_XPITCH + c + 8];
+                const cf xa1 = buf[(size_t)(2 * q + 1) * FC_XPITCH + c], xb1 = buf[(size_t)(2 * q + 1) * FC_XPITCH + c + 8];
+                const cf A0 = cadd(xa0, xb0), A1 = cadd(xa1, xb1);
+                const cf B0 = cmul(csub(xa0, xb0), w), B1 = cmul(csub(xa1, xb1), w);
+                cf* rowA = p.S + ((long)z * d.Y + y) * d.XP + 2 * q;
+                cf* rowB = rowA + (long)(d.Y / 2) * d.XP;
+                *reinterpret_cast<float4*>(rowA) = make_float4(A0.x, A0.y, A1.x, A1.y);
+                *reinterpret_cast<float4*>(rowB) = make_float4(B0.x, B0.y, B1.x, B1.y);
             }
-            p.S[((long)z * d.Y + y) * d.XP + pcol] = A;
-            p.S[((long)z * d.Y + y + d.Y / 2) * d.XP + pcol] = B;
+            if (tid < 8 * 16) {  // Nyquist column + zero pad columns
+                const int rp = tid >> 4, col = M + (tid & 15);
+                const int y = 8 * g + rp;
+                cf A = make_float2(0.f, 0.f), B = A;
+                if (col == M) {
+                    const cf xa = buf[(size_t)M * FC_XPITCH + rp], xb = buf[(size_t)M * FC_XPITCH + rp + 8];
+                    A = cadd(xa, xb);
+                    B = cmul(csub(xa, xb), p.twy[y]);
+                }
+                p.S[((long)z * d.Y + y) * d.XP + col] = A;
+                p.S[((long)z * d.Y + y + d.Y / 2) * d.XP + col] = B;
+            }
+        } else {
+            for (int idx = tid; idx < 8 * d.XP; idx += FC_NT) {
+                const int pcol = idx % d.XP;
+                const int rp = idx / d.XP;
+                const int y = 8 * g + rp;
+                cf A = make_float2(0.f, 0.f), B = A;
+                if (pcol <= M) {
+                    const cf xa = buf[(size_t)pcol * FC_XPITCH + rp], xb = buf[(size_t)pcol * FC_XPITCH + rp + 8];
+                    A = cadd(xa, xb);
+                    B = cmul(csub(xa, xb), p.twy[y]);
+                }
+                p.S[((long)z * d.Y + y) * d.XP + pcol] = A;
+                p.S[((long)z * d.Y + y + d.Y / 2) * d.XP + pcol] = B;
+            }
         }
         __syncthreads();
     }
@@ -534,48 +577,73 @@ __global__ __launch_bounds__(FC_NT) void x_inv_kernel(XParams p) {
     const int rr = tid / QPR;
     const int gpz = d.Y / FC_XR;
     const long ntiles = (long)d.Z * gpz;
+    constexpr int HALF = ROUNDS / 2;
+    constexpr bool FAST = ROUNDS >= 2;
 
-    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // prefetch registers: the tile's spectrum rows (two columns per lane) + its Nyquist column
+    float4 v[ROUNDS];
+    cf nyA = make_float2(0.f, 0.f), nyB = nyA;
+    auto load_tile = [&](long t) {
+#pragma unroll
+        for (int u = 0; u < ROUNDS; ++u) {
+            const int c = min(rr + u * RPR, FC_XR - 1);
+            v[u] = *reinterpret_cast<const float4*>(p.S + x_row_index(d, t, c) * d.XP + 2 * q);
+        }
+        const int rp = tid & 7;  // every thread loads (16 distinct addresses per tile: cache hits), 8 use it
+        nyA = p.S[x_row_index(d, t, rp) * d.XP + M];
+        nyB = p.S[x_row_index(d, t, rp + 8) * d.XP + M];
+    };
+    long t = blockIdx.x;
+    if (FAST && t < ntiles) load_tile(t);
+    for (; t < ntiles; t += gridDim.x) {
         const long z = t / gpz;
         const int g = (int)(t - z * gpz);
-        // load spectrum rows of 8 pairs, undo the Y radix-2 step, write X[p] into LDS (transposed)
-        for (int idx = tid; idx < 8 * (M + 1); idx += FC_NT) {
-            const int pcol = idx % (M + 1);
-            const int rp = idx / (M + 1);
-            const int y = 8 * g + rp;
-            const cf A = p.S[((long)z * d.Y + y) * d.XP + pcol];
-            const cf B = p.S[((long)z * d.Y + y + d.Y / 2) * d.XP + pcol];
-            float sn, cs;
-            sincospif(-2.0f * (float)y / (float)d.Y, &sn, &cs);
-            const cf ub = cmulc(B, make_float2(cs, sn));
-            buf[(size_t)pcol * FC_XPITCH + rp] = cadd(A, ub);
-            buf[(size_t)pcol * FC_XPITCH + rp + 8] = csub(A, ub);
-        }
-        __syncthreads();
-        // inverse untangle in place: Zf[k] = E + i O, E = (X[k] + conj X[M-k])/2, O = (X[k] - conj X[M-k])/2 * conj(w^k)
-        for (int idx = tid; idx < (M >> 1) * FC_XR; idx += FC_NT) {
-            const int c = idx % FC_XR;
-            const int u = idx / FC_XR;
-            if (u == 0) {
-                const float x0 = buf[c].x, xm = buf[(size_t)M * FC_XPITCH + c].x;
-                buf[c] = make_float2(0.5f * (x0 + xm), 0.5f * (x0 - xm));
-                if (M > 1) buf[FC_XPITCH + c] = cconj(buf[FC_XPITCH + c]);
-            } else {
-                const int top = 31 - __clz(u);
-                const int pp = (2 << top) + (u - (1 << top));
-                const int pm = 3 * (2 << top) - 1 - pp;
-                const cf a = buf[(size_t)pp * FC_XPITCH + c], b = buf[(size_t)pm * FC_XPITCH + c];
-                const cf E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
-                const cf Dm = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
-                const cf O = cmulc(Dm, ut[pp]);
-                const cf iO = mul_pi(O);
-                buf[(size_t)pp * FC_XPITCH + c] = cadd(E, iO);
-                // partner: Zf[M-k] = conj(E) + i conj(O) = conj(E - i O)
-                buf[(size_t)pm * FC_XPITCH + c] = cconj(csub(E, iO));
+        if (FAST) {
+            // undo the Y radix-2 step in registers, write X[p] into LDS (transposed)
+#pragma unroll
+            for (int u = 0; u < (HALF > 0 ? HALF : 1); ++u) {
+                const int c = rr + u * RPR;  // < 8
+                const cf w = p.twy[8 * g + c];
+                const float4 A = v[u], B = v[(u + HALF) % ROUNDS];
+                const cf ub0 = cmulc(make_float2(B.x, B.y), w), ub1 = cmulc(make_float2(B.z, B.w), w);
+                const cf a0 = make_float2(A.x, A.y), a1 = make_float2(A.z, A.w);
+                buf[(size_t)(2 * q) * FC_XPITCH + c] = cadd(a0, ub0);
+                buf[(size_t)(2 * q) * FC_XPITCH + c + 8] = csub(a0, ub0);
+                buf[(size_t)(2 * q + 1) * FC_XPITCH + c] = cadd(a1, ub1);
+                buf[(size_t)(2 * q + 1) * FC_XPITCH + c + 8] = csub(a1, ub1);
+            }
+            if (tid < 8) {
+                const cf ub = cmulc(nyB, p.twy[8 * g + tid]);
+                buf[(size_t)M * FC_XPITCH + tid] = cadd(nyA, ub);
+                buf[(size_t)M * FC_XPITCH + tid + 8] = csub(nyA, ub);
+            }
+        } else {
+            for (int idx = tid; idx < 8 * (M + 1); idx += FC_NT) {
+                const int pcol = idx % (M + 1);
+                const int rp = idx / (M + 1);
+                const int y = 8 * g + rp;
+                const cf A = p.S[((long)z * d.Y + y) * d.XP + pcol];
+                const cf B = p.S[((long)z * d.Y + y + d.Y / 2) * d.XP + pcol];
+                const cf ub = cmulc(B, p.twy[y]);
+                buf[(size_t)pcol * FC_XPITCH + rp] = cadd(A, ub);
+                buf[(size_t)pcol * FC_XPITCH + rp + 8] = csub(A, ub);
             }
         }
         __syncthreads();
-        fft_lds<true, 2, 1>(buf, M, d.logM, 4, FC_XPITCH, tw, tid);
+        const long tn = t + gridDim.x;
+        if (FAST && tn < ntiles) load_tile(tn);  // next tile's spectrum behind the FFT
+        // this tile's d / est rows arrive behind the FFT too
+        float4 aux[ROUNDS];
+        if (EPI != XE_STORE) {
+#pragma unroll
+            for (int u = 0; u < ROUNDS; ++u) {
+                const int c = min(rr + u * RPR, FC_XR - 1);
+                aux[u] = *reinterpret_cast<const float4*>(p.aux + x_row_index(d, t, c) * d.X + 4 * q);
+            }
+        }
+        untangle_lds<true>(buf, ut, M, tid);
+        __syncthreads();
+        fft_lds<true, (EPI == XE_STORE ? 2 : 1), 1>(buf, M, d.logM, 4, FC_XPITCH, tw, tid);
         // natural order now: z[j] = x[2j] + i x[2j+1]; write real rows with the fused epilogue
 #pragma unroll
         for (int u = 0; u < ROUNDS; ++u) {
@@ -585,13 +653,13 @@ __global__ __launch_bounds__(FC_NT) void x_inv_kernel(XParams p) {
                 float4 r = make_float4(e0.x, e0.y, e1.x, e1.y);
                 const long off = x_row_index(d, t, c) * d.X + 4 * q;
                 if (EPI == XE_RATIO) {
-                    const float4 dd = *reinterpret_cast<const float4*>(p.aux + off);
+                    const float4 dd = aux[u];
                     r.x = dd.x / fmaxf(r.x, p.eps);
                     r.y = dd.y / fmaxf(r.y, p.eps);
                     r.z = dd.z / fmaxf(r.z, p.eps);
                     r.w = dd.w / fmaxf(r.w, p.eps);
                 } else if (EPI == XE_UPDATE) {
-                    const float4 e = *reinterpret_cast<const float4*>(p.aux + off);
+                    const float4 e = aux[u];
                     r.x = fmaxf(e.x * r.x, 0.0f);
                     r.y = fmaxf(e.y * r.y, 0.0f);
                     r.z = fmaxf(e.z * r.z, 0.0f);
@@ -609,7 +677,7 @@ __global__ __launch_bounds__(FC_NT) void x_inv_kernel(XParams p) {
 // ================================================================================================
 struct ConvPlan {
     ConvDims d;
-    cf *tw_x = nullptr, *tw_y = nullptr, *tw_z = nullptr, *untangle = nullptr;
+    cf *tw_x = nullptr, *tw_y = nullptr, *tw_z = nullptr, *untangle = nullptr, *twy = nullptr;
     int ntw_x = 0, ntw_y = 0, ntw_z = 0;
     int Wy = 0, Wz = 0;
 };
@@ -675,6 +743,12 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
         h[pp] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
     BH_TRY(upload(h, &pl.untangle));
+    h.resize(Y / 2);
+    for (int y = 0; y < (int)Y / 2; ++y) {
+        const double a = -2.0 * M_PI * y / (double)Y;
+        h[y] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    BH_TRY(upload(h, &pl.twy));
     auto tile_w = [&](int64_t N) {
         int w = (int)(FC_TILE / N);
         if (w > 64) w = 64;       // 512-B row segments are plenty
@@ -761,6 +835,7 @@ static int launch_x(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, cons
     p.aux = aux;
     p.tw = pl.tw_x;
     p.untangle = pl.untangle;
+    p.twy = pl.twy;
     p.ntw = pl.ntw_x;
     p.d = pl.d;
     p.eps = eps;
