@@ -28,7 +28,7 @@ import torch
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-from biahub_amd import _lib  # noqa: E402
+from biahub_amd import _lib, parallel  # noqa: E402
 from biahub_amd.deconvolve import richardson_lucy  # noqa: E402
 from biahub_amd.deskew import fast_deskew_zyx, get_deskewed_data_shape  # noqa: E402
 from biahub_amd.device import get_context  # noqa: E402
@@ -63,6 +63,19 @@ def synthetic_position(shape, seed, device):
     return vol.round_().clamp_(0, 65535)
 
 
+def pmc_traffic(key, shape):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01d_pmc_hbm_traffic.json: separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command, fetch doubled for gfx950 as
+    MI355X_MICROARCH.md prescribes).  Only valid for the shape it was collected on."""
+    f = ROOT / "profiles" / "r01d_pmc_hbm_traffic.json"
+    if not f.exists():
+        return None
+    rec = json.load(open(f))
+    if list(shape) != rec.get("shape"):
+        return None
+    return rec.get(key)
+
+
 def cpu_baseline(iterations):
     """The oracle (CPU restatement) timed on a bounded sample of the same workload, rank 0 only."""
     from oracle import oracle_np as O  # checker / baseline only — never the thing measured as `value`
@@ -95,18 +108,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local_rank, world = parallel.world_info()
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # RCCL ("nccl" backend on ROCm)
-
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    parallel.init("nccl", dev)  # RCCL; used only for the timing barrier / max-over-ranks, never on the data path
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # one synthetic position per rank and step: position index = rank (round-robin shard of a `world`-position plate)
+    my_positions = parallel.shard_positions(range(world), rank, world)
+    assert my_positions == [rank]
 
     shape = tuple(args.shape)
     V = int(np.prod(shape))
@@ -124,8 +134,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
+        parallel.barrier()
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
@@ -144,10 +153,7 @@ def main():
         del out
     fence()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = parallel.max_over_ranks(dt, dev)
 
     if rank == 0:
         rl_iter_s = float(np.mean(rl_ms)) / 1e3
@@ -176,13 +182,14 @@ def main():
                 "positions_per_step": world,
             },
             "roofline": {
-                "kernel": "one Richardson-Lucy iteration (4 hipFFT 3-D R2C/C2R + 4 fused pointwise kernels)",
+                "kernel": "one Richardson-Lucy iteration = 2 fused FFT convolutions x 5 in-place passes "
+                          "(x_fwd, col_pass Y, col_pass Z fwd*OTF*inv, col_pass Y inv, x_inv+epilogue; csrc/fftconv.hip)",
                 "bound": "hbm",
                 "achieved": rl_bytes / rl_iter_s / 1e9,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": rl_bytes / rl_iter_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic("rl_iteration", shape),
                 "algorithmic_bytes": rl_bytes,
                 "ms": rl_iter_s * 1e3,
             },
@@ -193,7 +200,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": dk_bytes / deskew_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic("deskew_kernel", shape),
                 "algorithmic_bytes": dk_bytes,
                 "ms": deskew_s * 1e3,
                 "fill_passes_ms": fill_s * 1e3,
@@ -203,9 +210,9 @@ def main():
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.iterations)
         print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if world > 1:
+        parallel.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
