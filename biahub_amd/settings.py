@@ -1,0 +1,124 @@
+"""Settings models of the hot-path steps — the YAML surface kept from ``biahub/settings.py``.
+
+Field names, defaults, rounding and validation errors follow the reference so the same YAML files load:
+``DeskewSettings`` (settings.py:348-383), ``RegistrationSettings`` (:386-415), ``DeconvolveSettings`` (:424-427),
+``StabilizationSettings`` (:624-650).  Unknown keys are rejected (``extra="forbid"``, :22-23).
+"""
+
+from __future__ import annotations
+
+from typing import Literal
+
+import numpy as np
+from pydantic import BaseModel, ConfigDict, NonNegativeInt, PositiveFloat, PositiveInt, field_validator, model_validator
+
+OmeZarrVersion = Literal["0.4", "0.5"]
+
+
+class _Strict(BaseModel):
+    model_config = ConfigDict(extra="forbid")
+
+
+class ProcessingSettings(_Strict):
+    fliplr: bool | None = False
+    flipud: bool | None = False
+    rot90: int | None = 0
+
+
+class DeskewSettings(_Strict):
+    pixel_size_um: PositiveFloat
+    ls_angle_deg: PositiveFloat
+    px_to_scan_ratio: PositiveFloat | None = None
+    scan_step_um: PositiveFloat | None = None
+    keep_overhang: bool = False
+    overhang_fill: Literal["mean"] | float = 0
+    average_n_slices: PositiveInt = 3
+    device: str = "cpu"
+    output_ome_zarr_version: OmeZarrVersion | None = None
+
+    @model_validator(mode="before")
+    @classmethod
+    def _derive_ratio(cls, data):
+        # px_to_scan_ratio defaults to pixel_size_um / scan_step_um, 3 decimals (settings.py:373-382)
+        if isinstance(data, dict) and data.get("px_to_scan_ratio") is None:
+            if data.get("scan_step_um") is None:
+                raise ValueError(
+                    "If px_to_scan_ratio is not provided, both pixel_size_um and scan_step_um must be provided"
+                )
+            data = dict(data)
+            data["px_to_scan_ratio"] = round(data["pixel_size_um"] / data["scan_step_um"], 3)
+        return data
+
+    @field_validator("ls_angle_deg")
+    @classmethod
+    def _angle(cls, v):
+        if v < 0 or v > 45:
+            raise ValueError("Light sheet angle must be be between 0 and 45 degrees")
+        return round(float(v), 2)
+
+    @field_validator("px_to_scan_ratio")
+    @classmethod
+    def _ratio(cls, v):
+        return None if v is None else round(float(v), 3)
+
+
+def _check_4x4(m, what):
+    a = np.asarray(m, dtype=object)
+    if not isinstance(m, list) or len(m) != 4 or any((not isinstance(r, list)) or len(r) != 4 for r in m):
+        raise ValueError(f"{what} must be a 4x4 nested list")
+    try:
+        np.asarray(m, dtype=float)
+    except (TypeError, ValueError):
+        raise ValueError("The array must contain valid numerical values.") from None
+    del a
+    return m
+
+
+class RegistrationSettings(_Strict):
+    source_channel_names: list[str]
+    target_channel_name: str
+    affine_transform_zyx: list
+    keep_overhang: bool = False
+    interpolation: str = "linear"
+    time_indices: NonNegativeInt | list[NonNegativeInt] | Literal["all"] = "all"
+    verbose: bool = False
+    output_ome_zarr_version: OmeZarrVersion | None = None
+
+    @field_validator("affine_transform_zyx")
+    @classmethod
+    def _affine(cls, v):
+        return _check_4x4(v, "affine_transform_zyx")
+
+
+class DeconvolveSettings(_Strict):
+    regularization_strength: PositiveFloat = 0.001
+    output_ome_zarr_version: OmeZarrVersion | None = None
+
+
+class RichardsonLucySettings(_Strict):
+    """North-star extension (no reference model): parameters of ``richardson_lucy_czyx``."""
+
+    iterations: PositiveInt = 10
+    eps: PositiveFloat = 1e-6
+    output_ome_zarr_version: OmeZarrVersion | None = None
+
+
+class StabilizationSettings(_Strict):
+    stabilization_estimation_channel: str
+    stabilization_type: Literal["z", "xy", "xyz", "affine"]
+    stabilization_method: Literal["beads", "phase-cross-corr", "focus-finding", "manual", "ants"] = "focus-finding"
+    stabilization_channels: list
+    affine_transform_zyx_list: list
+    time_indices: NonNegativeInt | list[NonNegativeInt] | Literal["all"] = "all"
+    output_voxel_size: list[PositiveFloat] = [1.0, 1.0, 1.0, 1.0, 1.0]
+    output_ome_zarr_version: OmeZarrVersion | None = None
+
+    @field_validator("affine_transform_zyx_list")
+    @classmethod
+    def _affines(cls, v):
+        if not isinstance(v, list):
+            raise ValueError("affine_transform_list must be a list")
+        for m in v:
+            if np.asarray(m).shape != (4, 4):
+                raise ValueError("Each element in affine_transform_list must be a 4x4 ndarray")
+        return v
