@@ -34,6 +34,10 @@ struct DeskewGeom {
     int XC;          // output-x chunk per workgroup (multiple of 256)
     int ZS;          // LDS z stride (odd)
     int ZC;          // max z-window length (<= ZS)
+    // fused overhang-fill prologue (FILL kernels): zero-mask bits + per-block sums
+    uint32_t* mask0;  // [Za*X][W32] one bit per output voxel (1 = exact zero)
+    double* psum;     // per-block partial sums of the outputs
+    int W32;          // mask words per output row (even)
 };
 
 // The reference's sample position along the scan axis, in its float32 operation order:
@@ -86,7 +90,7 @@ __device__ __forceinline__ float div_small(float a, float n, float rn) {
 // J = outputs per lane per row, so one wave covers the whole XC = 64*J output chunk and the NT/64
 // waves take different rows.  LDS tile is [k][z][TX+1]: the odd row pitch makes both the staging
 // stores (lanes along x) and the compute loads (lanes along z) bank-conflict free.
-template <typename TIN, int TX, int J, int NK, int NT, bool DMA>
+template <typename TIN, int TX, int J, int NK, int NT, bool DMA, bool FILL>
 __global__ __launch_bounds__(NT) void deskew_kernel(const TIN* __restrict__ in, float* __restrict__ out,
                                                     DeskewGeom g) {
 #pragma clang fp contract(off)
@@ -116,13 +120,23 @@ __global__ __launch_bounds__(NT) void deskew_kernel(const TIN* __restrict__ in, 
         for (int xl = tid >> 6; xl < TX; xl += NT / 64) {
             const int x = xt0 + xl;
             if (x >= g.X) break;
-            float* orow = out + ((size_t)a * g.X + (g.X - 1 - x)) * g.Xp;
+            const size_t orow_i = (size_t)a * g.X + (g.X - 1 - x);
+            float* orow = out + orow_i * g.Xp;
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const int xo = xo0 + lane0 + 64 * j;
-                if (xo < g.Xp) orow[xo] = 0.0f;
+                if (FILL) {
+                    // every voxel here is an exact zero: set the mask bits, leave the data to the fill pass
+                    const unsigned long long bits = __ballot(xo < g.Xp);
+                    if (lane0 == 0 && xo0 + 64 * j < g.Xp)
+                        *reinterpret_cast<unsigned long long*>(g.mask0 + orow_i * g.W32 + (xo0 + 64 * j) / 32) = bits;
+                } else if (xo < g.Xp) {
+                    orow[xo] = 0.0f;
+                }
             }
         }
+        if (FILL && tid == 0)
+            g.psum[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 0.0;
         return;
     }
 
@@ -236,11 +250,13 @@ __global__ __launch_bounds__(NT) void deskew_kernel(const TIN* __restrict__ in, 
     }
     const float fN = (float)N;
     const float rN = 1.0f / fN;
+    double tsum = 0.0;
     for (int xl = wave; xl < TX; xl += NT / 64) {
         const int x = xt0 + xl;
         if (x >= g.X) break;
         const int yo = g.X - 1 - x;
-        float* orow = out + ((size_t)a * g.X + yo) * g.Xp;
+        const size_t orow_i = (size_t)a * g.X + yo;
+        float* orow = out + orow_i * g.Xp;
         const float* tcol = tile + xl;
         float acc[J];
         if (NK > 0) {
@@ -275,7 +291,33 @@ __global__ __launch_bounds__(NT) void deskew_kernel(const TIN* __restrict__ in, 
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int xo = xbase + 64 * j;
-            if (xo < g.Xp) orow[xo] = (N > 1) ? div_small(acc[j], fN, rN) : acc[j];
+            const float val = (N > 1) ? div_small(acc[j], fN, rN) : acc[j];
+            if (FILL) {
+                // fused prologue of the overhang fill: zero-mask bits + running sum; exact zeros are not
+                // stored (the fill pass overwrites every masked voxel anyway)
+                const bool inb = xo < g.Xp;
+                const unsigned long long bits = __ballot(inb && val == 0.0f);
+                if (lane == 0 && xo0 + 64 * j < g.Xp)
+                    *reinterpret_cast<unsigned long long*>(g.mask0 + orow_i * g.W32 + (xo0 + 64 * j) / 32) = bits;
+                if (inb && val != 0.0f) {
+                    orow[xo] = val;
+                    tsum += (double)val;
+                }
+            } else if (xo < g.Xp) {
+                orow[xo] = val;
+            }
+        }
+    }
+    if (FILL) {
+        __shared__ double wsum[NT / 64];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tsum += __shfl_down(tsum, o, 64);
+        if (lane == 0) wsum[wave] = tsum;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < NT / 64; ++w) t += wsum[w];
+            g.psum[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
         }
     }
 }
@@ -319,7 +361,7 @@ static int max_window(const DeskewGeom& g, int XC) {
 }
 
 template <typename TIN, int TX, int J, int NT, bool DMA>
-static int launch_deskew_cfg(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g) {
+static int launch_deskew_cfg(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g, bool fill, int* nblocks) {
     constexpr int XC = 64 * J;
     g.XC = XC;
     g.ZC = max_window(g, XC);
@@ -330,6 +372,12 @@ static int launch_deskew_cfg(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom 
                lds, (double)g.px, g.N);
     dim3 grid((unsigned)ceil_div(g.X, TX), (unsigned)ceil_div(g.Xp, XC), (unsigned)g.Za);
     BH_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "deskew grid too large (%u,%u,%u)", grid.x, grid.y, grid.z);
+    const size_t nblk = (size_t)grid.x * grid.y * grid.z;
+    if (nblocks) *nblocks = (int)nblk;
+    if (fill) {
+        BH_REQUIRE(nblk < (1ull << 31), "deskew grid too large for the fused fill");
+        BH_TRY(get_scratch(ctx, "fill_pall", nblk * sizeof(double), (void**)&g.psum));
+    }
     auto run = [&](auto kern) -> int {
         if (lds > 64 * 1024)
             BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -339,11 +387,11 @@ static int launch_deskew_cfg(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom 
         return BH_OK;
     };
     switch (g.N) {
-        case 1: return run(deskew_kernel<TIN, TX, J, 1, NT, DMA>);
-        case 2: return run(deskew_kernel<TIN, TX, J, 2, NT, DMA>);
-        case 3: return run(deskew_kernel<TIN, TX, J, 3, NT, DMA>);
-        case 4: return run(deskew_kernel<TIN, TX, J, 4, NT, DMA>);
-        default: return run(deskew_kernel<TIN, TX, J, 0, NT, DMA>);
+        case 1: return fill ? run(deskew_kernel<TIN, TX, J, 1, NT, DMA, true>) : run(deskew_kernel<TIN, TX, J, 1, NT, DMA, false>);
+        case 2: return fill ? run(deskew_kernel<TIN, TX, J, 2, NT, DMA, true>) : run(deskew_kernel<TIN, TX, J, 2, NT, DMA, false>);
+        case 3: return fill ? run(deskew_kernel<TIN, TX, J, 3, NT, DMA, true>) : run(deskew_kernel<TIN, TX, J, 3, NT, DMA, false>);
+        case 4: return fill ? run(deskew_kernel<TIN, TX, J, 4, NT, DMA, true>) : run(deskew_kernel<TIN, TX, J, 4, NT, DMA, false>);
+        default: return fill ? run(deskew_kernel<TIN, TX, J, 0, NT, DMA, true>) : run(deskew_kernel<TIN, TX, J, 0, NT, DMA, false>);
     }
 }
 
@@ -353,7 +401,7 @@ static size_t cfg_lds(const DeskewGeom& g, int TX, int J) {
 }
 
 template <typename TIN>
-static int launch_deskew(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g) {
+static int launch_deskew(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g, bool fill, int* nblocks) {
     // Candidates (TX, J, threads, LDS-DMA staging) from fastest measured (profiles/, tools/tune_deskew.py:
     // 5.7 ms at 512x2048x2048 -> 683x2048x3034 for cfg 0) to smallest tile; take the first whose tile
     // lets two workgroups share a CU, else the first that fits.  BH_DESKEW_CFG=<n> forces one.
@@ -370,16 +418,17 @@ static int launch_deskew(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g) {
         if (cfg_lds(g, cand[i][0], cand[i][1]) <= 160 * 1024) pick = i;
     if (pick < 0) pick = NC - 1;
     switch (pick) {
-        case 0: return launch_deskew_cfg<TIN, 64, 4, 256, true>(ctx, in, out, g);
-        case 1: return launch_deskew_cfg<TIN, 64, 2, 256, true>(ctx, in, out, g);
-        case 2: return launch_deskew_cfg<TIN, 32, 4, 256, false>(ctx, in, out, g);
-        case 3: return launch_deskew_cfg<TIN, 64, 1, 256, true>(ctx, in, out, g);
-        default: return launch_deskew_cfg<TIN, 32, 1, 256, false>(ctx, in, out, g);
+        case 0: return launch_deskew_cfg<TIN, 64, 4, 256, true>(ctx, in, out, g, fill, nblocks);
+        case 1: return launch_deskew_cfg<TIN, 64, 2, 256, true>(ctx, in, out, g, fill, nblocks);
+        case 2: return launch_deskew_cfg<TIN, 32, 4, 256, false>(ctx, in, out, g, fill, nblocks);
+        case 3: return launch_deskew_cfg<TIN, 64, 1, 256, true>(ctx, in, out, g, fill, nblocks);
+        default: return launch_deskew_cfg<TIN, 32, 1, 256, false>(ctx, in, out, g, fill, nblocks);
     }
 }
 
 int fill_overhang_impl(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X, int fill_mode,
-                       float fill_value, int iterations, float* mean_out);
+                       float fill_value, int iterations, float* mean_out, int fused_partials);
+int fill_mask_buffers(bh_ctx* ctx, int64_t rows, int64_t X, uint32_t** m0, int* W32);
 
 }  // namespace bh
 
@@ -427,20 +476,23 @@ int bh_deskew(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, i
     BH_TRY(bh::deskew_geometry(Z, Y, X, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices, &g, os));
     BH_REQUIRE(os[2] < (1 << 24), "deskewed X extent %lld too large", (long long)os[2]);
     BH_CHECK_HIP(hipSetDevice(ctx->device));
+    // reference :538 — fill only when keep_overhang and (fill == "mean" or fill != 0)
+    const bool do_fill = keep_overhang && (fill_mode == BH_FILL_MEAN || (fill_mode == BH_FILL_CONSTANT && fill_value != 0.0f));
+    int nblocks = 0;
+    if (do_fill) BH_TRY(bh::fill_mask_buffers(ctx, os[0] * os[1], os[2], &g.mask0, &g.W32));
     {
         bh::ScopedTimer t(ctx, bh::T_DESKEW);
         switch (in_dtype) {
-            case BH_DT_F32: BH_TRY(bh::launch_deskew(ctx, (const float*)in, out, g)); break;
-            case BH_DT_U16: BH_TRY(bh::launch_deskew(ctx, (const uint16_t*)in, out, g)); break;
-            case BH_DT_U8: BH_TRY(bh::launch_deskew(ctx, (const uint8_t*)in, out, g)); break;
-            case BH_DT_I16: BH_TRY(bh::launch_deskew(ctx, (const int16_t*)in, out, g)); break;
+            case BH_DT_F32: BH_TRY(bh::launch_deskew(ctx, (const float*)in, out, g, do_fill, &nblocks)); break;
+            case BH_DT_U16: BH_TRY(bh::launch_deskew(ctx, (const uint16_t*)in, out, g, do_fill, &nblocks)); break;
+            case BH_DT_U8: BH_TRY(bh::launch_deskew(ctx, (const uint8_t*)in, out, g, do_fill, &nblocks)); break;
+            case BH_DT_I16: BH_TRY(bh::launch_deskew(ctx, (const int16_t*)in, out, g, do_fill, &nblocks)); break;
             default: BH_REQUIRE(false, "unsupported input dtype code %d", in_dtype);
         }
     }
-    // reference :538 — fill only when keep_overhang and (fill == "mean" or fill != 0)
-    const bool do_fill = keep_overhang && (fill_mode == BH_FILL_MEAN || (fill_mode == BH_FILL_CONSTANT && fill_value != 0.0f));
     if (do_fill) {
-        BH_TRY(bh::fill_overhang_impl(ctx, out, os[0], os[1], os[2], fill_mode, fill_value, 3, mean_out));
+        // the deskew kernel already produced the zero mask and the block sums (and skipped storing zeros)
+        BH_TRY(bh::fill_overhang_impl(ctx, out, os[0], os[1], os[2], fill_mode, fill_value, 3, mean_out, nblocks));
     } else if (mean_out) {
         *mean_out = 0.0f;
     }

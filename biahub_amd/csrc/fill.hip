@@ -189,8 +189,16 @@ __global__ __launch_bounds__(256) void apply_fill_kernel(float* __restrict__ dat
     }
 }
 
+// mask buffer shared with the fused deskew prologue
+int fill_mask_buffers(bh_ctx* ctx, int64_t rows, int64_t X, uint32_t** m0, int* W32) {
+    *W32 = (int)(ceil_div(X, 64) * 2);
+    return get_scratch(ctx, "fill_m0", (size_t)rows * *W32 * 4, (void**)m0);
+}
+
+// fused_partials > 0: the zero mask ("fill_m0") and that many block sums ("fill_pall") were already written by
+// the deskew kernel, which also skipped storing exact zeros; otherwise both come from mask0_kernel here.
 int fill_overhang_impl(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X, int fill_mode, float fill_value,
-                       int iterations, float* mean_out) {
+                       int iterations, float* mean_out, int fused_partials) {
     BH_REQUIRE(iterations >= 0 && iterations < 32, "dilation_iterations must be in [0,31], got %d", iterations);
     BH_REQUIRE(X < (1ll << 31) && Y < (1ll << 31) && Z < (1ll << 31), "volume too large");
     ScopedTimer timer(ctx, T_FILL);
@@ -205,12 +213,14 @@ int fill_overhang_impl(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X
     BH_TRY(get_scratch(ctx, "fill_m0", nwords * 4, (void**)&m0));
     BH_TRY(get_scratch(ctx, "fill_mA", nwords * 4, (void**)&mA));
     BH_TRY(get_scratch(ctx, "fill_mB", nwords * 4, (void**)&mB));
-    BH_TRY(get_scratch(ctx, "fill_pall", nblk * sizeof(double), (void**)&p_all));
+    const int n_all = fused_partials > 0 ? fused_partials : nblk;
+    BH_TRY(get_scratch(ctx, "fill_pall", (size_t)n_all * sizeof(double), (void**)&p_all));
     BH_TRY(get_scratch(ctx, "fill_pshell", nblk * sizeof(double), (void**)&p_shell));
     BH_TRY(get_scratch(ctx, "fill_pcnt", nblk * sizeof(unsigned long long), (void**)&p_cnt));
     BH_TRY(get_scratch(ctx, "fill_stats", sizeof(FillStats), (void**)&st));
     hipStream_t s = ctx->stream;
-    hipLaunchKernelGGL(mask0_kernel, dim3(nblk), dim3(256), 0, s, data, m0, p_all, rows, (int)X, W32);
+    if (fused_partials <= 0)
+        hipLaunchKernelGGL(mask0_kernel, dim3(nblk), dim3(256), 0, s, data, m0, p_all, rows, (int)X, W32);
     const int tb = 256;
     const int gb = (int)std::min<int64_t>(ceil_div(nwords, tb), (int64_t)ctx->num_cus * 16);
     const uint32_t* md = m0;
@@ -223,7 +233,7 @@ int fill_overhang_impl(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X
         md = mA;
     }
     hipLaunchKernelGGL(shell_kernel, dim3(nblk), dim3(256), 0, s, data, m0, md, p_shell, p_cnt, nwords, (int)X, W32);
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, p_all, nblk, p_shell, p_cnt, nblk, st,
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, p_all, n_all, p_shell, p_cnt, nblk, st,
                        (unsigned long long)(rows * X), fill_mode, fill_value);
     hipLaunchKernelGGL(apply_fill_kernel, dim3(nblk), dim3(256), 0, s, data, md, st, rows, (int)X, W32);
     BH_CHECK_HIP(hipGetLastError());
@@ -244,5 +254,5 @@ extern "C" int bh_overhang_fill(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, 
     BH_REQUIRE(Z > 0 && Y > 0 && X > 0, "invalid shape");
     BH_REQUIRE(fill_mode == BH_FILL_CONSTANT || fill_mode == BH_FILL_MEAN, "fill_mode must be CONSTANT or MEAN");
     BH_CHECK_HIP(hipSetDevice(ctx->device));
-    return bh::fill_overhang_impl(ctx, data, Z, Y, X, fill_mode, fill_value, dilation_iterations, mean_out);
+    return bh::fill_overhang_impl(ctx, data, Z, Y, X, fill_mode, fill_value, dilation_iterations, mean_out, 0);
 }
