@@ -7,7 +7,7 @@
 // ants.from_numpy) and scipy.ndimage.affine_transform (core/transform.py:384-396).  NaN -> 0
 // (register.py:254) is folded into the load.
 //
-// A workgroup owns a 8 x 4 x 64 (z, y, x) output tile.  It maps the tile's corners through M,
+// A workgroup owns a 8 x 8 x 64 (z, y, x) output tile.  It maps the tile's corners through M,
 // stages the source bounding box (clipped to the volume) into LDS with row-contiguous reads and
 // samples from LDS; when the box does not fit (strong scale/rotation) it gathers from global
 // memory through L2 instead.  Coordinates are float64 (ITK and SciPy both use doubles), weights
@@ -16,8 +16,8 @@
 
 namespace bh {
 
-constexpr int ATX = 64, ATY = 4, ATZ = 8;
-constexpr int A_LDS_FLOATS = 12288;  // 48 KiB -> three workgroups per CU
+constexpr int ATX = 64, ATY = 8, ATZ = 8;
+constexpr int A_LDS_FLOATS = 9216;   // 36 KiB -> four workgroups per CU
 
 struct AffineParams {
     double m[12];
@@ -46,7 +46,24 @@ __device__ __forceinline__ void map_point(const double* m, double z, double y, d
     c[2] = m[8] * z + m[9] * y + m[10] * x + m[11];
 }
 
-template <typename TIN>
+// per-axis interpolation plan: clamped neighbour indices and their weights
+template <int BOUNDARY>
+__device__ __forceinline__ void axis_plan(double c, int n, int& j0, int& j1, float& w0, float& w1) {
+    const double fl = floor(c);
+    const int i0 = (int)fl;
+    const float f = (float)(c - fl);
+    w0 = 1.0f - f;
+    w1 = f;
+    if (BOUNDARY == BH_BOUNDARY_ZEROS) {  // out-of-range neighbours contribute cval, not data
+        if (i0 < 0 || i0 >= n) w0 = 0.0f;
+        if (i0 + 1 < 0 || i0 + 1 >= n) w1 = 0.0f;
+    }
+    j0 = max(0, min(i0, n - 1));
+    j1 = max(0, min(i0 + 1, n - 1));
+}
+
+// INTERP / BOUNDARY are compile-time so the sampling loop carries no mode branches.
+template <typename TIN, int INTERP, int BOUNDARY>
 __global__ __launch_bounds__(256) void affine_kernel(const TIN* __restrict__ in, float* __restrict__ out,
                                                      AffineParams p) {
     __shared__ float tile[A_LDS_FLOATS];
@@ -55,107 +72,173 @@ __global__ __launch_bounds__(256) void affine_kernel(const TIN* __restrict__ in,
     const int ty = threadIdx.x >> 6;
     const int ox0 = blockIdx.x * ATX, oy0 = blockIdx.y * ATY, oz0 = blockIdx.z * ATZ;
 
-    // source bounding box of this tile (uniform across the block)
-    if (threadIdx.x == 0) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    // source bounding box of this tile (uniform across the block): an affine map of a box is bounded per axis by
+    // base + sum of the negative / positive edge extents; threads 0..2 take one source axis each.  A relative
+    // 1e-9 slack absorbs the rounding difference to the per-voxel evaluation below.
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
         const int z1 = min(oz0 + ATZ, p.Zo) - 1, y1 = min(oy0 + ATY, p.Yo) - 1, x1 = min(ox0 + ATX, p.Xo) - 1;
-        for (int c = 0; c < 8; ++c) {
-            double q[3];
-            map_point(p.m, (double)((c & 4 ? z1 : oz0) + p.cz), (double)((c & 2 ? y1 : oy0) + p.cy),
-                      (double)((c & 1 ? x1 : ox0) + p.cx), q);
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = fmin(lo[a], q[a]);
-                hi[a] = fmax(hi[a], q[a]);
-            }
-        }
-        const int dims[3] = {p.Zi, p.Yi, p.Xi};
-        for (int a = 0; a < 3; ++a) {
-            // nearest needs floor(c+0.5); linear needs floor(c) and floor(c)+1: [floor(lo), floor(hi)+1] covers both
-            double l = floor(lo[a]), h = floor(hi[a]) + 1.0;
-            l = fmax(l, 0.0);
-            h = fmin(h, (double)(dims[a] - 1));
-            box[a] = (int)l;
-            box[3 + a] = (h >= l) ? (int)(h - l) + 1 : 0;
-        }
+        const double base = p.m[4 * a] * (double)(oz0 + p.cz) + p.m[4 * a + 1] * (double)(oy0 + p.cy) +
+                            p.m[4 * a + 2] * (double)(ox0 + p.cx) + p.m[4 * a + 3];
+        const double ez = p.m[4 * a] * (double)(z1 - oz0), ey = p.m[4 * a + 1] * (double)(y1 - oy0),
+                     ex = p.m[4 * a + 2] * (double)(x1 - ox0);
+        double lo = base + fmin(ez, 0.0) + fmin(ey, 0.0) + fmin(ex, 0.0);
+        double hi = base + fmax(ez, 0.0) + fmax(ey, 0.0) + fmax(ex, 0.0);
+        const double slack = 1e-9 * (fabs(lo) + fabs(hi) + 1.0);
+        lo -= slack;
+        hi += slack;
+        const int n = a == 0 ? p.Zi : (a == 1 ? p.Yi : p.Xi);
+        // nearest needs floor(c+0.5); linear needs floor(c) and floor(c)+1: [floor(lo), floor(hi)+1] covers both
+        double l = fmax(floor(lo), 0.0), h = fmin(floor(hi) + 1.0, (double)(n - 1));
+        box[a] = (int)l;
+        box[3 + a] = (h >= l) ? (int)(h - l) + 1 : 0;
     }
     __syncthreads();
     const int bz = box[0], by = box[1], bx = box[2];
     const int dz = box[3], dy = box[4], dx = box[5];
     const int64_t nbox = (int64_t)dz * dy * dx;
-    const bool staged = nbox > 0 && nbox <= A_LDS_FLOATS;
+    const int ox = ox0 + tx;
+    if (nbox == 0) {  // no source voxel can contribute to this tile
+        for (int yy = ty; yy < ATY; yy += 4) {
+            const int oy = oy0 + yy;
+            if (oy < p.Yo && ox < p.Xo)
+                for (int k = 0; k < ATZ && oz0 + k < p.Zo; ++k)
+                    out[((size_t)(oz0 + k) * p.Yo + oy) * p.Xo + ox] = p.cval;
+        }
+        return;
+    }
+    const bool staged = nbox <= A_LDS_FLOATS;
     const size_t sY = (size_t)p.Xi, sZ = (size_t)p.Yi * p.Xi;
     if (staged) {
-        const int n = (int)nbox;
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const int x = i % dx, y = (i / dx) % dy, z = i / (dx * dy);
-            tile[i] = load_clean(in + (size_t)(bz + z) * sZ + (size_t)(by + y) * sY + (bx + x));
+        // rows of the box are contiguous in x: one wave per row, lanes along x (coalesced)
+        const int nrows = dz * dy;
+        if (sizeof(TIN) == 4) {
+            // float32: LDS-DMA, every row of this wave in flight at once, no VGPR staging
+            const int wv = __builtin_amdgcn_readfirstlane(ty);
+            int z = wv / dy, y = wv - z * dy;  // row r = z * dy + y, advanced by 4 rows per step
+            const int qz = 4 / dy, qy = 4 - qz * dy;
+            for (int r = wv; r < nrows; r += 4) {
+                const TIN* rowp = in + (size_t)(bz + z) * sZ + (size_t)(by + y) * sY + bx;
+                for (int x0 = 0; x0 < dx; x0 += 64) {
+                    if (x0 + tx < dx) {
+                        const TIN* src = rowp + x0 + tx;
+                        const unsigned lds_dst = (unsigned)(size_t)(tile + r * dx + x0);
+                        unsigned keep;
+                        asm volatile(
+                            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                            : "=&s"(keep)
+                            : "v"(src), "s"(lds_dst)
+                            : "memory");
+                    }
+                }
+                z += qz;
+                y += qy;
+                if (y >= dy) {
+                    y -= dy;
+                    ++z;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // np.nan_to_num on the staged copy
+            for (int i = threadIdx.x; i < (int)nbox; i += 256) tile[i] = load_clean(tile + i);
+        } else {
+            constexpr int U = 8;
+            for (int rb = ty; rb < nrows; rb += 4 * U) {
+                for (int x0 = 0; x0 < dx; x0 += 64) {
+                    const int x = min(x0 + tx, dx - 1);
+                    float v[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int r = min(rb + 4 * u, nrows - 1);
+                        const int z = r / dy, y = r - z * dy;
+                        v[u] = load_clean(in + (size_t)(bz + z) * sZ + (size_t)(by + y) * sY + bx + x);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int r = rb + 4 * u;
+                        if (r < nrows && x0 + tx < dx) tile[r * dx + x0 + tx] = v[u];
+                    }
+                }
+            }
         }
     }
     __syncthreads();
+    if (ox >= p.Xo) return;
 
-    auto fetch = [&](int iz, int iy, int ix) -> float {  // indices guaranteed inside the volume
-        if (staged) return tile[((iz - bz) * dy + (iy - by)) * dx + (ix - bx)];
+    // strides / origin of whichever copy of the source we sample from
+    const int fsz = staged ? dy * dx : 0, fsy = staged ? dx : 0;
+    auto fetch = [&](int iz, int iy, int ix) -> float {  // indices inside the volume (and inside the box when staged)
+        if (staged) return tile[(iz - bz) * fsz + (iy - by) * fsy + (ix - bx)];
         return load_clean(in + (size_t)iz * sZ + (size_t)iy * sY + ix);
     };
-
-    const int oy = oy0 + ty, ox = ox0 + tx;
-    if (oy >= p.Yo || ox >= p.Xo) return;
-    for (int k = 0; k < ATZ; ++k) {
-        const int oz = oz0 + k;
-        if (oz >= p.Zo) break;
-        double c[3];
-        map_point(p.m, (double)(oz + p.cz), (double)(oy + p.cy), (double)(ox + p.cx), c);
-        const int dims[3] = {p.Zi, p.Yi, p.Xi};
-        bool inside = true;
-        if (p.boundary == BH_BOUNDARY_ITK) {
-            for (int a = 0; a < 3; ++a) inside = inside && (c[a] >= -0.5) && (c[a] < (double)dims[a] - 0.5);
-        } else if (p.boundary == BH_BOUNDARY_SCIPY_CONSTANT) {
-            for (int a = 0; a < 3; ++a) inside = inside && (c[a] >= 0.0) && (c[a] <= (double)(dims[a] - 1));
-        } else {
-            // guard the int conversions below; anything this far out has no in-range neighbour
-            for (int a = 0; a < 3; ++a) inside = inside && (c[a] > -2.0) && (c[a] < (double)dims[a] + 1.0);
-        }
-        float r = p.cval;
-        if (inside) {
-            if (p.interp == BH_INTERP_NEAREST) {
-                int i[3];
-                bool ok = true;
-                for (int a = 0; a < 3; ++a) {
-                    i[a] = (int)floor(c[a] + 0.5);
-                    if (p.boundary == BH_BOUNDARY_ITK) i[a] = max(0, min(i[a], dims[a] - 1));
-                    ok = ok && i[a] >= 0 && i[a] < dims[a];
-                }
-                r = ok ? fetch(i[0], i[1], i[2]) : p.cval;
-            } else {
-                int b[3];
-                float f[3];
-                for (int a = 0; a < 3; ++a) {
-                    const double fl = floor(c[a]);
-                    b[a] = (int)fl;
-                    f[a] = (float)(c[a] - fl);
-                }
-                float acc = 0.0f;
-#pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    const int qz = n >> 2, qy = (n >> 1) & 1, qx = n & 1;
-                    int iz = b[0] + qz, iy = b[1] + qy, ix = b[2] + qx;
-                    const float w = (qz ? f[0] : 1.0f - f[0]) * (qy ? f[1] : 1.0f - f[1]) * (qx ? f[2] : 1.0f - f[2]);
-                    const bool ok = iz >= 0 && iz < p.Zi && iy >= 0 && iy < p.Yi && ix >= 0 && ix < p.Xi;
-                    float v;
-                    if (p.boundary == BH_BOUNDARY_ZEROS) {
-                        v = ok ? fetch(iz, iy, ix) : p.cval;
-                    } else {  // clamp: weight of an out-of-range neighbour is zero or it repeats the edge
-                        iz = max(0, min(iz, p.Zi - 1));
-                        iy = max(0, min(iy, p.Yi - 1));
-                        ix = max(0, min(ix, p.Xi - 1));
-                        v = fetch(iz, iy, ix);
-                    }
-                    acc += w * v;
-                }
-                r = acc;
+    const int dims[3] = {p.Zi, p.Yi, p.Xi};
+    for (int yy = ty; yy < ATY; yy += 4) {
+        const int oy = oy0 + yy;
+        if (oy >= p.Yo) break;
+        // numpy / ITK association: ((m0*z + m1*y) + m2*x) + m3 — the y and x products are per-row constants
+        double py[3], px[3];
+        {
+#pragma clang fp contract(off)
+            const double yd = (double)(oy + p.cy), xd = (double)(ox + p.cx);
+            for (int a = 0; a < 3; ++a) {
+                py[a] = p.m[4 * a + 1] * yd;
+                px[a] = p.m[4 * a + 2] * xd;
             }
         }
-        out[((size_t)oz * p.Yo + oy) * p.Xo + ox] = r;
+        for (int k = 0; k < ATZ; ++k) {
+            const int oz = oz0 + k;
+            if (oz >= p.Zo) break;
+            double c[3];
+            {
+#pragma clang fp contract(off)
+                const double zd = (double)(oz + p.cz);
+                for (int a = 0; a < 3; ++a) c[a] = ((p.m[4 * a] * zd + py[a]) + px[a]) + p.m[4 * a + 3];
+            }
+            bool inside = true;
+            if (BOUNDARY == BH_BOUNDARY_ITK) {
+                for (int a = 0; a < 3; ++a) inside = inside && (c[a] >= -0.5) && (c[a] < (double)dims[a] - 0.5);
+            } else if (BOUNDARY == BH_BOUNDARY_SCIPY_CONSTANT) {
+                for (int a = 0; a < 3; ++a) inside = inside && (c[a] >= 0.0) && (c[a] <= (double)(dims[a] - 1));
+            } else {  // guard the int conversions; anything this far out has no in-range neighbour
+                for (int a = 0; a < 3; ++a) inside = inside && (c[a] > -2.0) && (c[a] < (double)dims[a] + 1.0);
+            }
+            float r = p.cval;
+            if (inside) {
+                if (INTERP == BH_INTERP_NEAREST) {
+                    int i[3];
+                    bool ok = true;
+                    for (int a = 0; a < 3; ++a) {
+                        i[a] = (int)floor(c[a] + 0.5);
+                        if (BOUNDARY == BH_BOUNDARY_ITK) i[a] = max(0, min(i[a], dims[a] - 1));
+                        ok = ok && i[a] >= 0 && i[a] < dims[a];
+                    }
+                    if (ok) r = fetch(i[0], i[1], i[2]);
+                } else {
+                    int z0, z1, y0, y1, x0, x1;
+                    float wz0, wz1, wy0, wy1, wx0, wx1;
+                    axis_plan<BOUNDARY>(c[0], p.Zi, z0, z1, wz0, wz1);
+                    axis_plan<BOUNDARY>(c[1], p.Yi, y0, y1, wy0, wy1);
+                    axis_plan<BOUNDARY>(c[2], p.Xi, x0, x1, wx0, wx1);
+                    // same accumulation order as the oracle: dz outer, dy, dx inner
+                    float acc = 0.0f;
+                    acc += (wz0 * wy0 * wx0) * fetch(z0, y0, x0);
+                    acc += (wz0 * wy0 * wx1) * fetch(z0, y0, x1);
+                    acc += (wz0 * wy1 * wx0) * fetch(z0, y1, x0);
+                    acc += (wz0 * wy1 * wx1) * fetch(z0, y1, x1);
+                    acc += (wz1 * wy0 * wx0) * fetch(z1, y0, x0);
+                    acc += (wz1 * wy0 * wx1) * fetch(z1, y0, x1);
+                    acc += (wz1 * wy1 * wx0) * fetch(z1, y1, x0);
+                    acc += (wz1 * wy1 * wx1) * fetch(z1, y1, x1);
+                    if (BOUNDARY == BH_BOUNDARY_ZEROS) {
+                        const float cover = (wz0 + wz1) * (wy0 + wy1) * (wx0 + wx1);
+                        acc += (1.0f - cover) * p.cval;
+                    }
+                    r = acc;
+                }
+            }
+            out[((size_t)oz * p.Yo + oy) * p.Xo + ox] = r;
+        }
     }
 }
 
@@ -163,9 +246,21 @@ template <typename TIN>
 static int launch_affine(bh_ctx* ctx, const TIN* in, float* out, const AffineParams& p) {
     dim3 grid((unsigned)ceil_div(p.Xo, ATX), (unsigned)ceil_div(p.Yo, ATY), (unsigned)ceil_div(p.Zo, ATZ));
     BH_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "affine grid too large");
-    hipLaunchKernelGGL(affine_kernel<TIN>, grid, dim3(256), 0, ctx->stream, in, out, p);
-    BH_CHECK_HIP(hipGetLastError());
-    return BH_OK;
+    auto run = [&](auto kern) -> int {
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, ctx->stream, in, out, p);
+        BH_CHECK_HIP(hipGetLastError());
+        return BH_OK;
+    };
+#define BH_AFF(I, B) return run(affine_kernel<TIN, I, B>)
+    if (p.interp == BH_INTERP_NEAREST) {
+        if (p.boundary == BH_BOUNDARY_ITK) BH_AFF(BH_INTERP_NEAREST, BH_BOUNDARY_ITK);
+        if (p.boundary == BH_BOUNDARY_SCIPY_CONSTANT) BH_AFF(BH_INTERP_NEAREST, BH_BOUNDARY_SCIPY_CONSTANT);
+        BH_AFF(BH_INTERP_NEAREST, BH_BOUNDARY_ZEROS);
+    }
+    if (p.boundary == BH_BOUNDARY_ITK) BH_AFF(BH_INTERP_LINEAR, BH_BOUNDARY_ITK);
+    if (p.boundary == BH_BOUNDARY_SCIPY_CONSTANT) BH_AFF(BH_INTERP_LINEAR, BH_BOUNDARY_SCIPY_CONSTANT);
+    BH_AFF(BH_INTERP_LINEAR, BH_BOUNDARY_ZEROS);
+#undef BH_AFF
 }
 
 }  // namespace bh

@@ -228,6 +228,8 @@ size_t fftconv_spectrum_elems(const ConvPlan& pl);
 int fftconv_make_otf(bh_ctx* ctx, const ConvPlan& pl, const float* padded_psf, cf* otf);
 int fftconv_apply(bh_ctx* ctx, const ConvPlan& pl, const float* in, const cf* otf, bool correlate, cf* spec,
                   int epilogue, const float* aux, float eps, float* out);
+int fftconv_tikhonov(bh_ctx* ctx, const ConvPlan& pl, const float* in, const float* tf_full, float reg, cf* spec,
+                     float* filt, float* out);
 
 static bool use_fused_engine(int64_t Z, int64_t Y, int64_t X) {
     if (const char* e = getenv("BH_FFT_BACKEND"))
@@ -344,6 +346,16 @@ int bh_tikhonov(bh_ctx* ctx, const float* in, const float* tf_full, int64_t Z, i
     BH_REQUIRE(Z > 0 && Y > 0 && X > 0, "invalid shape");
     BH_CHECK_HIP(hipSetDevice(ctx->device));
     ScopedTimer timer(ctx, T_TIKHONOV);
+    if (use_fused_engine(Z, Y, X)) {
+        ConvPlan* cp;
+        BH_TRY(fftconv_plan(ctx, Z, Y, X, &cp));
+        const size_t NSf = fftconv_spectrum_elems(*cp);
+        cf* fspec;
+        float* filt;
+        BH_TRY(get_scratch(ctx, "fc_spec", NSf * sizeof(cf), (void**)&fspec));
+        BH_TRY(get_scratch(ctx, "fc_filter", NSf * sizeof(float), (void**)&filt));
+        return fftconv_tikhonov(ctx, *cp, in, tf_full, (float)regularization_strength, fspec, filt, out);
+    }
     FftPlans* pl;
     BH_TRY(get_plans(ctx, Z, Y, X, &pl));
     const int64_t V = Z * Y * X, Xh = X / 2 + 1, NS = Z * Y * Xh;

@@ -271,7 +271,7 @@ struct ConvDims {
 // ================================================================================================
 // Column passes (Y: two length-Y/2 halves per z; Z: fused forward x OTF x inverse)
 // ================================================================================================
-enum ColMode { COL_FWD = 0, COL_INV = 1, COL_FWD_SCALE = 2, COL_CONV = 3, COL_CORR = 4 };
+enum ColMode { COL_FWD = 0, COL_INV = 1, COL_FWD_SCALE = 2, COL_CONV = 3, COL_CORR = 4, COL_FILTER = 5 };
 
 struct ColParams {
     cf* S;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
     const int lane = tid % LPS;
     const int r0 = tid / LPS;
     const long ntiles = (long)p.nouter * p.ncoltiles;
-    constexpr bool HAS_OTF = (MODE == COL_CONV || MODE == COL_CORR);
+    constexpr bool HAS_OTF = (MODE == COL_CONV || MODE == COL_CORR || MODE == COL_FILTER);
     const int ncoltiles = p.ncoltiles, nsub = p.nsub, W_ = p.W, N_ = p.N, logN = p.logN, logW = p.logW, XP = p.XP;
     const long outer_stride = p.outer_stride, sub_stride = p.sub_stride, row_stride = p.row_stride;
     cf* const S = p.S;
@@ -328,6 +328,17 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
         const cf* src_ = (SRC) + tile_base(T);   \
         BH_FOR8(BH_LD)                           \
     }
+    // real filter (Tikhonov): one float per complex element, same [z][y][p] indexing
+#define BH_LDF(u)                                                                                          \
+    if (u < ROUNDS) {                                                                                      \
+        const float2 f_ = *reinterpret_cast<const float2*>(fsrc_ + (long)min(r0 + u * RPR, N_ - 1) * row_stride); \
+        v##u = make_float4(f_.x, f_.x, f_.y, f_.y);                                                        \
+    }
+#define BH_LOAD_FILTER(T)                                                      \
+    {                                                                          \
+        const float* fsrc_ = reinterpret_cast<const float*>(otf) + tile_base(T); \
+        BH_FOR8(BH_LDF)                                                        \
+    }
 #define BH_TO_LDS(u)                                                                            \
     if (u < ROUNDS && r0 + u * RPR < N_)                                                        \
         *reinterpret_cast<float4*>(buf + (size_t)(r0 + u * RPR) * W_ + 2 * lane) = v##u;
@@ -337,7 +348,12 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
         const float4 a = *q_;                                                                   \
         const float4 b = v##u;                                                                  \
         float4 c;                                                                               \
-        if (MODE == COL_CONV) {                                                                 \
+        if (MODE == COL_FILTER) {                                                               \
+            c.x = a.x * b.x;                                                                    \
+            c.y = a.y * b.y;                                                                    \
+            c.z = a.z * b.z;                                                                    \
+            c.w = a.w * b.w;                                                                    \
+        } else if (MODE == COL_CONV) {                                                          \
             c.x = a.x * b.x - a.y * b.y;                                                        \
             c.y = a.x * b.y + a.y * b.x;                                                        \
             c.z = a.z * b.z - a.w * b.w;                                                        \
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
         const long tn = t + gridDim.x;
         if (HAS_OTF) {
             // this tile's OTF arrives behind the forward FFT; the next tile's data behind the inverse FFT
-            BH_LOAD_TILE(otf, t)
+            if (MODE == COL_FILTER) BH_LOAD_FILTER(t) else BH_LOAD_TILE(otf, t)
             fft_lds<false, 1, 2>(buf, N_, logN, logW, W_, tw, tid);
             BH_FOR8(BH_OTF_MUL)
             __syncthreads();
@@ -391,6 +407,8 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
         __syncthreads();
     }
 #undef BH_LD
+#undef BH_LDF
+#undef BH_LOAD_FILTER
 #undef BH_LOAD_TILE
 #undef BH_TO_LDS
 #undef BH_OTF_MUL
@@ -817,6 +835,7 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
         case COL_INV: return run(col_pass_kernel<COL_INV, R>);        \
         case COL_FWD_SCALE: return run(col_pass_kernel<COL_FWD_SCALE, R>); \
         case COL_CONV: return run(col_pass_kernel<COL_CONV, R>);      \
+        case COL_FILTER: return run(col_pass_kernel<COL_FILTER, R>);  \
         default: return run(col_pass_kernel<COL_CORR, R>);            \
     }
     if (rounds <= 1) { BH_COL_DISPATCH(1) }
@@ -882,6 +901,51 @@ int fftconv_apply(bh_ctx* ctx, const ConvPlan& pl, const float* in, const cf* ot
     BH_TRY(launch_col(ctx, pl, correlate ? COL_CORR : COL_CONV, true, spec, otf, 1.f));
     BH_TRY(launch_col(ctx, pl, COL_INV, false, spec, nullptr, 1.f));
     BH_TRY(launch_x(ctx, pl, true, epilogue, nullptr, spec, out, aux, eps));
+    return BH_OK;
+}
+
+
+// Tikhonov filter H/(H^2 + reg) * 2/V from the reference's natural-order full-spectrum H, written in the
+// engine's scrambled half-spectrum layout.  One workgroup per spectrum row: coalesced read of tf[kz][ky][0..M],
+// bit-reversal permutation through LDS, coalesced write of filt[zs][ys][0..XP).
+__global__ __launch_bounds__(256) void tikhonov_filter_rows_kernel(const float* __restrict__ tf, float* __restrict__ filt,
+                                                                   ConvDims d, float reg, float scale) {
+    extern __shared__ float rowbuf[];  // [XP]
+    const int Yh = d.Y / 2;
+    for (long row = blockIdx.x; row < (long)d.Z * d.Y; row += gridDim.x) {
+        const int zs = (int)(row / d.Y), ys = (int)(row - (long)zs * d.Y);
+        const int kz = (int)(__brev((unsigned)zs) >> (32 - d.logZ));
+        const int half = ys / Yh, r = ys - half * Yh;
+        const int ky = 2 * (int)(__brev((unsigned)r) >> (32 - d.logYh)) + half;
+        const float* src = tf + ((long)kz * d.Y + ky) * d.X;
+        for (int kx = threadIdx.x; kx < d.XP; kx += 256) {
+            float f = 0.0f;
+            if (kx <= d.M) {
+                const float h = src[kx];
+                f = (h / (h * h + reg)) * scale;
+            }
+            const int ps = kx < d.M ? (int)(__brev((unsigned)kx) >> (32 - d.logM)) : kx;
+            rowbuf[ps] = f;
+        }
+        __syncthreads();
+        for (int ps = threadIdx.x; ps < d.XP; ps += 256) filt[row * d.XP + ps] = rowbuf[ps];
+        __syncthreads();
+    }
+}
+
+// out = irfft( rfft(in) * H/(H^2+reg) ), H = tf_full (natural order, real, even)
+int fftconv_tikhonov(bh_ctx* ctx, const ConvPlan& pl, const float* in, const float* tf_full, float reg, cf* spec,
+                     float* filt, float* out) {
+    const double V = (double)pl.d.Z * pl.d.Y * pl.d.X;
+    const int grid = ctx->num_cus * 8;
+    hipLaunchKernelGGL(tikhonov_filter_rows_kernel, dim3(grid), dim3(256), pl.d.XP * sizeof(float), ctx->stream, tf_full,
+                       filt, pl.d, reg, (float)(2.0 / V));
+    BH_CHECK_HIP(hipGetLastError());
+    BH_TRY(launch_x(ctx, pl, false, 0, in, spec, nullptr, nullptr, 0.f));
+    BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));
+    BH_TRY(launch_col(ctx, pl, COL_FILTER, true, spec, reinterpret_cast<const cf*>(filt), 1.f));
+    BH_TRY(launch_col(ctx, pl, COL_INV, false, spec, nullptr, 1.f));
+    BH_TRY(launch_x(ctx, pl, true, XE_STORE, nullptr, spec, out, nullptr, 0.f));
     return BH_OK;
 }
 

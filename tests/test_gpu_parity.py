@@ -325,3 +325,19 @@ def test_richardson_lucy_fused_engine_vs_oracle(gpu, shape, pshape, monkeypatch)
     got_hipfft = richardson_lucy(v, pt, 5, 1e-6).cpu().numpy()
     assert rel_err(got_hipfft, want) <= FFT_TOL
     assert rel_err(got, got_hipfft) <= FFT_TOL
+
+
+@pytest.mark.parametrize("shape", [(16, 32, 64), (8, 64, 128), (32, 128, 256), (128, 32, 1024)])
+def test_tikhonov_fused_engine_vs_oracle(gpu, shape, monkeypatch):
+    from biahub_amd.deconvolve import compute_tranfser_function, deconvolve
+
+    rng = np.random.default_rng(21)
+    psf = O.gaussian_psf((7, 5, 9), (1.5, 1.0, 2.0))
+    czyx = rng.random((2,) + shape, dtype=np.float32) * 100
+    tf = compute_tranfser_function(psf, shape)
+    want = O.deconvolve_czyx(czyx, tf, 1e-3)
+    got = deconvolve(czyx, transfer_function=tf, regularization_strength=1e-3)
+    assert rel_err(got, want) <= FFT_TOL, rel_err(got, want)
+    monkeypatch.setenv("BH_FFT_BACKEND", "hipfft")
+    got2 = deconvolve(czyx, transfer_function=tf, regularization_strength=1e-3)
+    assert rel_err(got, got2) <= FFT_TOL
