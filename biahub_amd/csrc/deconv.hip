@@ -228,6 +228,8 @@ size_t fftconv_spectrum_elems(const ConvPlan& pl);
 int fftconv_make_otf(bh_ctx* ctx, const ConvPlan& pl, const float* padded_psf, cf* otf);
 int fftconv_apply(bh_ctx* ctx, const ConvPlan& pl, const float* in, const cf* otf, bool correlate, cf* spec,
                   int epilogue, const float* aux, float eps, float* out);
+int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, const cf* otf, cf* spec, int iterations,
+                            float eps, float* est);
 int fftconv_tikhonov(bh_ctx* ctx, const ConvPlan& pl, const float* in, const float* tf_full, float reg, cf* spec,
                      float* filt, float* out);
 
@@ -280,12 +282,7 @@ static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, 
         BH_CHECK_HIP(hipEventCreate(&e1));
         BH_CHECK_HIP(hipEventRecord(e0, s));
     }
-    for (int it = 0; it < iterations; ++it) {
-        // ratio = d / max(h * est, eps)            (XE_RATIO = 1)
-        BH_TRY(fftconv_apply(ctx, *pl, out, otf, false, spec, 1, d, eps, real));
-        // est = max(est * (h~ * ratio), 0)          (XE_UPDATE = 2, aux = est, in place)
-        BH_TRY(fftconv_apply(ctx, *pl, real, otf, true, spec, 2, out, eps, out));
-    }
+    BH_TRY(fftconv_richardson_lucy(ctx, *pl, d, otf, spec, iterations, eps, out));
     if (e0) {
         BH_CHECK_HIP(hipEventRecord(e1, s));
         BH_CHECK_HIP(hipEventSynchronize(e1));
