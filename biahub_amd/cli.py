@@ -1,0 +1,297 @@
+"""Command-line surface of the hot-path steps: ``python -m biahub_amd <step> ...``.
+
+Command names, options and the side contracts (``RESOURCES:{json}`` line, ``--init``, ``--cluster debug`` /
+``--local``, output paths mirroring ``row/col/fov``, ``slurm_output/submitit_jobs_ids.log``) follow the reference
+CLIs (biahub/deskew.py:772-780, deconvolve.py:69-83, register.py:401-408, stabilize.py:327-333, flip.py:8-11,
+cli/parsing.py).  Execution is in-process on the visible GPU(s): under ``torchrun`` the positions are sharded over
+ranks (biahub_amd/parallel.py); ``--cluster slurm`` is refused — this package does not submit jobs.
+"""
+
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import click
+import numpy as np
+
+from . import parallel
+from .io import create_empty_plate, open_ome_zarr, process_single_position
+from .settings import (DeconvolveSettings, DeskewSettings, RegistrationSettings, RichardsonLucySettings,
+                       StabilizationSettings)
+from .utils.cluster import echo_resources, estimate_resources, get_submitit_cluster
+from .utils.config import settings_fingerprint, yaml_to_model
+from .utils.paths import get_output_paths, sbatch_to_submitit
+
+_MULTI = {"-i", "--input-position-dirpaths", "-s", "--source-position-dirpaths", "-t", "--target-position-dirpaths"}
+
+
+def expand_eat_all(argv: list[str]) -> list[str]:
+    """``-i a b c`` -> ``-i a -i b -i c`` (the reference lets ``-i`` swallow a shell glob)."""
+    out, i = [], 0
+    while i < len(argv):
+        tok = argv[i]
+        out.append(tok)
+        i += 1
+        if tok in _MULTI:
+            first = True
+            while i < len(argv) and not argv[i].startswith("-"):
+                if not first:
+                    out.append(tok)
+                out.append(argv[i])
+                first = False
+                i += 1
+    return out
+
+
+def _positions(ctx, param, value):
+    paths = [Path(v) for v in value]
+    for p in paths:
+        if not (p / ".zgroup").exists():
+            raise click.BadParameter(f"{p} is not an OME-Zarr position")
+    return sorted(paths)
+
+
+def _resolve_cluster(cluster: str | None, local: bool = False) -> str:
+    resolved = get_submitit_cluster(local=local, cluster=cluster)
+    if resolved == "slurm":
+        raise click.UsageError("biahub_amd runs in-process on local GPUs: use --cluster debug/local (or --local)")
+    return resolved
+
+
+def _run_positions(step: str, inputs, outputs, make_job, out_parent: Path):
+    """Shard positions over ranks, run them in the foreground, write the job-id log the reference writes."""
+    rank, world = parallel.init()
+    pairs = list(zip(inputs, outputs))
+    log_dir = out_parent / "slurm_output"
+    if rank == 0:
+        log_dir.mkdir(exist_ok=True)
+        (log_dir / "submitit_jobs_ids.log").write_text("\n".join(f"{step}-{i}" for i in range(len(pairs))))
+
+    def one(pair):
+        src, dst = pair
+        make_job(src, dst)
+        click.echo(f"{step.capitalize()} complete: {src}")
+        with open_ome_zarr(dst) as d:
+            return float(np.prod(d.data.shape))
+
+    st = parallel.process_positions(pairs, one, rank, world)
+    parallel.barrier()
+    rows = parallel.gather_stats(st)
+    if rank == 0 and sum(r.n_failed for r in rows):
+        raise click.ClickException(f"{sum(r.n_failed for r in rows)} position(s) failed")
+
+
+@click.group()
+def cli():
+    """MI355X-native per-position reconstruction steps (biahub-compatible)."""
+
+
+def _common(f):
+    f = click.option("--input-position-dirpaths", "-i", multiple=True, required=True, callback=_positions,
+                     help='Paths to input positions, e.g. "input.zarr/*/*/*"')(f)
+    f = click.option("--output-dirpath", "-o", required=True, type=click.Path(path_type=Path), help="Path to output.zarr")(f)
+    f = click.option("--sbatch-filepath", "-sb", default=None, type=click.Path(exists=True),
+                     help="Accepted for compatibility; Slurm parameters are parsed and ignored.")(f)
+    f = click.option("--monitor", "-m", is_flag=True, default=False, help="Accepted for compatibility.")(f)
+    return f
+
+
+def _config(f):
+    return click.option("--config-filepath", "-c", required=True, type=click.Path(exists=True, path_type=Path),
+                        help="Path to YAML configuration file")(f)
+
+
+@cli.command("deskew")
+@_common
+@_config
+@click.option("--cluster", type=click.Choice(["slurm", "local", "debug"], case_sensitive=False), default="debug",
+              show_default=True)
+@click.option("--init", "init_only", is_flag=True, default=False, help="Only initialize the output store and exit.")
+@click.option("--resume/--no-resume", "resume", default=False, show_default=True)
+def deskew_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor, config_filepath, cluster, init_only,
+               resume):
+    """Deskew oblique light-sheet positions (reference: ``biahub deskew``)."""
+    from .deskew import _fast_deskew_czyx, get_deskewed_data_shape
+
+    settings = yaml_to_model(config_filepath, DeskewSettings)
+    with open_ome_zarr(input_position_dirpaths[0]) as ds:
+        channel_names, (T, C, Z, Y, X) = ds.channel_names, ds.data.shape
+        if not np.isclose(settings.pixel_size_um, ds.scale[-1], rtol=0.05):
+            click.echo(f"Warning: config pixel_size_um={settings.pixel_size_um} differs from the input zarr XY scale "
+                       f"({ds.scale[-1]:.4f}).", err=True)
+        version = settings.output_ome_zarr_version or ds.version
+    out_shape, voxel = get_deskewed_data_shape((Z, Y, X), settings.ls_angle_deg, settings.px_to_scan_ratio,
+                                               settings.keep_overhang, settings.average_n_slices, settings.pixel_size_um)
+    create_empty_plate(output_dirpath, [p.parts[-3:] for p in input_position_dirpaths], channel_names,
+                       (T, C) + tuple(out_shape), scale=(1, 1) + tuple(voxel), version=version)
+    minutes, cpus, gb = estimate_resources((T, C, Z, Y, X), ram_multiplier=8, time_multiplier=0.5, max_num_cpus=16)
+    echo_resources(cpus, cpus * gb, minutes)
+    if init_only:
+        click.echo(f"Initialized {output_dirpath} ({len(input_position_dirpaths)} positions)")
+        return
+    if sbatch_filepath:
+        sbatch_to_submitit(sbatch_filepath)
+    _resolve_cluster(cluster)
+    kw = dict(ls_angle_deg=settings.ls_angle_deg, px_to_scan_ratio=settings.px_to_scan_ratio,
+              keep_overhang=settings.keep_overhang, average_n_slices=settings.average_n_slices,
+              overhang_fill=settings.overhang_fill, device="cuda",
+              extra_metadata={"biahub-deskew": settings.model_dump()})
+    outs = get_output_paths(input_position_dirpaths, output_dirpath)
+    _run_positions("deskew", input_position_dirpaths, outs,
+                   lambda s, d: process_single_position(_fast_deskew_czyx, s, d, resume=resume,
+                                                        resume_token=settings_fingerprint(settings), **kw),
+                   Path(output_dirpath).parent)
+
+
+def _same_shape_plate(inputs, output_dirpath, version_override, dtype=np.float32):
+    with open_ome_zarr(inputs[0]) as ds:
+        names, shape, scale, version = ds.channel_names, ds.data.shape, ds.scale, version_override or ds.version
+    create_empty_plate(output_dirpath, [p.parts[-3:] for p in inputs], names, shape, scale=scale, version=version,
+                       dtype=dtype)
+    return names, shape, scale
+
+
+@cli.command("deconvolve")
+@_common
+@_config
+@click.option("--psf-dirpath", "-p", required=True, type=click.Path(exists=True, file_okay=False, path_type=Path),
+              help="Path to psf.zarr")
+@click.option("--local", "-l", is_flag=True, default=False)
+def deconvolve_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor, config_filepath, psf_dirpath,
+                   local):
+    """Tikhonov deconvolution across T and C with a PSF (reference: ``biahub deconvolve``)."""
+    from .deconvolve import compute_tranfser_function, deconvolve
+
+    settings = yaml_to_model(config_filepath, DeconvolveSettings)
+    _, shape, scale = _same_shape_plate(input_position_dirpaths, output_dirpath, settings.output_ome_zarr_version)
+    _resolve_cluster(None, local=True)  # the reference's --local flag; there is no Slurm path here
+    with open_ome_zarr(Path(psf_dirpath, "0/0/0")) as psf_ds:
+        if scale[-3:] != psf_ds.scale[-3:]:
+            click.echo(f"Warning: PSF scale {psf_ds.scale[-3:]} does not match data scale {scale[-3:]}.", err=True)
+        psf = psf_ds.data[0, 0]
+    click.echo("Computing transfer function...")
+    tf = compute_tranfser_function(psf, tuple(shape[-3:]))
+    tf_store = Path(output_dirpath).parent / "transfer_function.zarr"
+    from .io import create_empty_position
+
+    create_empty_position(tf_store, ["PSF"], (1, 1) + tuple(shape[-3:]), chunks=(1, 1, min(256, shape[-3])) + tuple(shape[-2:]),
+                          scale=scale)
+    open_ome_zarr(tf_store).data[0, 0] = tf
+    outs = get_output_paths(input_position_dirpaths, output_dirpath)
+    _run_positions("deconvolve", input_position_dirpaths, outs,
+                   lambda s, d: process_single_position(deconvolve, s, d, transfer_function=tf,
+                                                        regularization_strength=float(settings.regularization_strength)),
+                   Path(output_dirpath).parent)
+
+
+@cli.command("rl-deconvolve")
+@_common
+@_config
+@click.option("--psf-dirpath", "-p", required=True, type=click.Path(exists=True, file_okay=False, path_type=Path))
+def rl_deconvolve_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor, config_filepath, psf_dirpath):
+    """Richardson-Lucy deconvolution (north-star extension; same layout as ``deconvolve``)."""
+    from .deconvolve import richardson_lucy_czyx
+
+    settings = yaml_to_model(config_filepath, RichardsonLucySettings)
+    _same_shape_plate(input_position_dirpaths, output_dirpath, settings.output_ome_zarr_version)
+    psf = open_ome_zarr(Path(psf_dirpath, "0/0/0")).data[0, 0]
+    outs = get_output_paths(input_position_dirpaths, output_dirpath)
+    _run_positions("rl-deconvolve", input_position_dirpaths, outs,
+                   lambda s, d: process_single_position(richardson_lucy_czyx, s, d, psf_zyx=psf,
+                                                        iterations=settings.iterations, eps=settings.eps),
+                   Path(output_dirpath).parent)
+
+
+@cli.command("stabilize")
+@_common
+@_config
+@click.option("--local", "-l", is_flag=True, default=False)
+def stabilize_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor, config_filepath, local):
+    """Apply per-timepoint affines to every listed channel (reference: ``biahub stabilize``)."""
+    from .stabilize import apply_stabilization_transform
+
+    settings = yaml_to_model(config_filepath, StabilizationSettings)
+    matrices = [np.asarray(m, dtype=np.float64) for m in settings.affine_transform_zyx_list]
+    names, shape, _ = _same_shape_plate(input_position_dirpaths, output_dirpath, settings.output_ome_zarr_version)
+    T = shape[0]
+    if len(matrices) < T:
+        raise click.ClickException(f"{len(matrices)} transforms for {T} time points")
+    chans = [names.index(c) for c in settings.stabilization_channels]
+    tidx = list(range(T)) if settings.time_indices == "all" else list(np.atleast_1d(settings.time_indices))
+    outs = get_output_paths(input_position_dirpaths, output_dirpath)
+    _run_positions("stabilize", input_position_dirpaths, outs,
+                   lambda s, d: process_single_position(apply_stabilization_transform, s, d,
+                                                        input_channel_indices=[[c] for c in chans],
+                                                        output_channel_indices=[[c] for c in chans],
+                                                        input_time_indices=tidx, output_time_indices=tidx,
+                                                        list_of_shifts=matrices, output_shape=tuple(shape[-3:])),
+                   Path(output_dirpath).parent)
+
+
+@cli.command("register")
+@click.option("--source-position-dirpaths", "-s", multiple=True, required=True, callback=_positions)
+@click.option("--target-position-dirpaths", "-t", multiple=True, required=True, callback=_positions)
+@_config
+@click.option("--output-dirpath", "-o", required=True, type=click.Path(path_type=Path))
+@click.option("--local", "-l", is_flag=True, default=False)
+def register_cli(source_position_dirpaths, target_position_dirpaths, config_filepath, output_dirpath, local):
+    """Warp source channels onto the target grid and copy the target channel (reference: ``biahub register``;
+    ``keep_overhang`` is honoured by registering onto the full target grid — the LIR crop estimate is out of scope)."""
+    from .array_ops import copy_n_paste_czyx
+    from .register import apply_affine_transform, rescale_voxel_size
+
+    settings = yaml_to_model(config_filepath, RegistrationSettings)
+    M = np.asarray(settings.affine_transform_zyx, dtype=np.float64)
+    with open_ome_zarr(source_position_dirpaths[0]) as src, open_ome_zarr(target_position_dirpaths[0]) as tgt:
+        src_names, tgt_names = src.channel_names, tgt.channel_names
+        T = min(src.data.shape[0], tgt.data.shape[0])
+        tgt_shape = tgt.data.shape[-3:]
+        out_scale = (1, 1) + tuple(rescale_voxel_size(M[:3, :3], np.asarray(src.scale[-3:])))
+    out_names = list(dict.fromkeys(list(settings.source_channel_names) + [settings.target_channel_name]))
+    create_empty_plate(output_dirpath, [p.parts[-3:] for p in source_position_dirpaths], out_names,
+                       (T, len(out_names)) + tuple(tgt_shape), scale=out_scale)
+    outs = get_output_paths(source_position_dirpaths, output_dirpath)
+    tidx = list(range(T)) if settings.time_indices == "all" else list(np.atleast_1d(settings.time_indices))
+
+    def job(pair_src, dst):
+        tpath = target_position_dirpaths[list(source_position_dirpaths).index(pair_src)]
+        for name in settings.source_channel_names:
+            process_single_position(apply_affine_transform, pair_src, dst,
+                                    input_channel_indices=[[src_names.index(name)]],
+                                    output_channel_indices=[[out_names.index(name)]], input_time_indices=tidx,
+                                    output_time_indices=tidx, matrix=M, output_shape_zyx=tuple(tgt_shape),
+                                    interpolation=settings.interpolation)
+        if settings.target_channel_name not in settings.source_channel_names:
+            full = [slice(0, n) for n in tgt_shape]
+            process_single_position(copy_n_paste_czyx, tpath, dst,
+                                    input_channel_indices=[[tgt_names.index(settings.target_channel_name)]],
+                                    output_channel_indices=[[out_names.index(settings.target_channel_name)]],
+                                    input_time_indices=tidx, output_time_indices=tidx, czyx_slicing_params=full)
+
+    _run_positions("register", source_position_dirpaths, outs, job, Path(output_dirpath).parent)
+
+
+@cli.command("flip")
+@click.option("--input-position-dirpaths", "-i", multiple=True, required=True, callback=_positions)
+@click.option("-x", is_flag=True, help="Flip along x.")
+@click.option("-y", is_flag=True, help="Flip along y.")
+def flip_cli(input_position_dirpaths, x, y):
+    """Flip every (t, c) volume of the positions in place (reference: ``biahub flip``)."""
+    from .array_ops import flip_zyx
+
+    for p in input_position_dirpaths:
+        click.echo(f"Flipping {p}")
+        arr = open_ome_zarr(p).data
+        for t in range(arr.shape[0]):
+            for c in range(arr.shape[1]):
+                arr[t, c] = flip_zyx(arr[t, c], x=x, y=y)
+
+
+def main(argv=None):
+    argv = expand_eat_all(list(sys.argv[1:] if argv is None else argv))
+    return cli.main(args=argv, standalone_mode=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,294 @@
+"""Minimal OME-Zarr (NGFF 0.4, zarr v2 directory store) reader/writer and the per-position driver.
+
+iohub / zarr / numcodecs are not available in this image, and the reference reaches them only through
+``open_ome_zarr``, ``create_empty_plate`` and ``process_single_position`` (biahub/deskew.py:608-640,738-749).
+This module provides those three entry points with the argument names the reference uses, over plain files:
+HCS layout ``plate.zarr/<row>/<col>/<fov>/0`` with one 5-D ``(T,C,Z,Y,X)`` array per position, chunks
+``(1,1,zc,Y,X)``, "/" dimension separator, uncompressed or stdlib-zlib chunks.  (blosc/zstd stores written by
+iohub need numcodecs and are refused with a clear error — the codec pipeline is I/O, out of scope here.)
+"""
+
+from __future__ import annotations
+
+import inspect
+import json
+import os
+import zlib
+from pathlib import Path
+
+import numpy as np
+
+from .array_ops import _check_nan_n_zeros
+
+_AXES = [
+    {"name": "T", "type": "time", "unit": "second"},
+    {"name": "C", "type": "channel"},
+    {"name": "Z", "type": "space", "unit": "micrometer"},
+    {"name": "Y", "type": "space", "unit": "micrometer"},
+    {"name": "X", "type": "space", "unit": "micrometer"},
+]
+
+
+def _write_json(path: Path, obj) -> None:
+    tmp = path.with_suffix(path.suffix + ".tmp")
+    tmp.write_text(json.dumps(obj, indent=1))
+    os.replace(tmp, path)
+
+
+class ZarrArray:
+    """5-D zarr v2 array, whole (t, c) volumes in and out."""
+
+    def __init__(self, path: Path):
+        self.path = Path(path)
+        meta = json.loads((self.path / ".zarray").read_text())
+        if meta.get("zarr_format") != 2:
+            raise ValueError(f"{path}: only zarr v2 arrays are supported")
+        comp = meta.get("compressor")
+        if comp is not None and comp.get("id") != "zlib":
+            raise NotImplementedError(
+                f"{path}: compressor {comp.get('id')!r} needs numcodecs; this reader handles uncompressed and zlib chunks"
+            )
+        if meta.get("filters"):
+            raise NotImplementedError(f"{path}: zarr filters are not supported")
+        self.shape = tuple(meta["shape"])
+        self.chunks = tuple(meta["chunks"])
+        self.dtype = np.dtype(meta["dtype"])
+        self.fill_value = meta.get("fill_value", 0) or 0
+        self.compressor = comp
+        self.sep = meta.get("dimension_separator", ".")
+        if len(self.shape) != 5 or self.chunks[0] != 1 or self.chunks[1] != 1 or self.chunks[3:] != self.shape[3:]:
+            raise NotImplementedError(f"{path}: expected a (T,C,Z,Y,X) array chunked (1,1,zc,Y,X), got {self.chunks}")
+
+    def _chunk_path(self, t, c, zi) -> Path:
+        return self.path / self.sep.join(str(v) for v in (t, c, zi, 0, 0))
+
+    def read_volume(self, t: int, c: int) -> np.ndarray:
+        T, C, Z, Y, X = self.shape
+        zc = self.chunks[2]
+        out = np.empty((Z, Y, X), dtype=self.dtype)
+        for zi in range(-(-Z // zc)):
+            f = self._chunk_path(t, c, zi)
+            z0, z1 = zi * zc, min(Z, (zi + 1) * zc)
+            if not f.exists():
+                out[z0:z1] = self.fill_value
+                continue
+            raw = f.read_bytes()
+            if self.compressor is not None:
+                raw = zlib.decompress(raw)
+            out[z0:z1] = np.frombuffer(raw, dtype=self.dtype).reshape(zc, Y, X)[: z1 - z0]
+        return out
+
+    def write_volume(self, t: int, c: int, vol: np.ndarray) -> None:
+        T, C, Z, Y, X = self.shape
+        if vol.shape != (Z, Y, X):
+            raise ValueError(f"volume shape {vol.shape} does not match array {(Z, Y, X)}")
+        zc = self.chunks[2]
+        vol = np.ascontiguousarray(vol, dtype=self.dtype)
+        for zi in range(-(-Z // zc)):
+            z0, z1 = zi * zc, min(Z, (zi + 1) * zc)
+            chunk = vol[z0:z1]
+            if z1 - z0 < zc:  # zarr stores full chunks
+                pad = np.full((zc - (z1 - z0), Y, X), self.fill_value, dtype=self.dtype)
+                chunk = np.concatenate([chunk, pad])
+            raw = chunk.tobytes()
+            if self.compressor is not None:
+                raw = zlib.compress(raw, self.compressor.get("level", 1))
+            f = self._chunk_path(t, c, zi)
+            f.parent.mkdir(parents=True, exist_ok=True)
+            tmp = f.with_name(f.name + ".tmp")
+            tmp.write_bytes(raw)
+            os.replace(tmp, f)
+
+    def __getitem__(self, key) -> np.ndarray:
+        t, c = key[0], key[1]
+        rest = key[2:] if len(key) > 2 else ()
+        if isinstance(c, (list, tuple, np.ndarray)):
+            vol = np.stack([self.read_volume(int(t), int(ci)) for ci in c])
+            return vol[(slice(None),) + tuple(rest)] if rest else vol
+        vol = self.read_volume(int(t), int(c))
+        return vol[tuple(rest)] if rest else vol
+
+    def __setitem__(self, key, value) -> None:
+        t, c = key[0], key[1]
+        if isinstance(c, (list, tuple, np.ndarray)):
+            for ci, v in zip(c, value):
+                self.write_volume(int(t), int(ci), v)
+        else:
+            self.write_volume(int(t), int(c), np.asarray(value))
+
+
+class Position:
+    """One FOV group: ``<store>/<row>/<col>/<fov>`` with array "0" (what ``open_ome_zarr(position_path)`` yields)."""
+
+    def __init__(self, path):
+        self.path = Path(path)
+        if not (self.path / ".zgroup").exists():
+            raise FileNotFoundError(f"{path} is not a zarr group")
+        self.zattrs = json.loads((self.path / ".zattrs").read_text()) if (self.path / ".zattrs").exists() else {}
+        self.data = ZarrArray(self.path / "0")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def __getitem__(self, name):
+        if str(name) != "0":
+            raise KeyError(name)
+        return self.data
+
+    @property
+    def channel_names(self) -> list[str]:
+        return [ch["label"] for ch in self.zattrs.get("omero", {}).get("channels", [])]
+
+    @property
+    def scale(self) -> list[float]:
+        ds = self.zattrs["multiscales"][0]["datasets"][0]
+        for tr in ds.get("coordinateTransformations", []):
+            if tr.get("type") == "scale":
+                return [float(v) for v in tr["scale"]]
+        return [1.0] * 5
+
+    @property
+    def version(self) -> str:
+        return str(self.zattrs.get("multiscales", [{}])[0].get("version", "0.4"))
+
+    def update_zattrs(self, extra: dict) -> None:
+        self.zattrs.update(extra)
+        _write_json(self.path / ".zattrs", self.zattrs)
+
+
+def open_ome_zarr(path, mode: str = "r", layout: str = "auto") -> Position:
+    """Open one position (``layout="fov"`` and HCS positions look the same on disk below the FOV group)."""
+    return Position(path)
+
+
+def read_fov_array(path) -> ZarrArray:
+    return Position(path).data
+
+
+def _position_zattrs(channel_names, scale, version, extra=None):
+    z = {
+        "multiscales": [{
+            "version": version,
+            "axes": _AXES,
+            "datasets": [{"path": "0", "coordinateTransformations": [{"type": "scale", "scale": [float(s) for s in scale]}]}],
+            "name": "0",
+        }],
+        "omero": {"version": version, "channels": [{"label": n, "active": True, "color": "FFFFFF",
+                                                   "window": {"start": 0, "end": 65535, "min": 0, "max": 65535}}
+                                                  for n in channel_names]},
+    }
+    if extra:
+        z.update(extra)
+    return z
+
+
+def create_empty_position(path, channel_names, shape, chunks=None, scale=(1, 1, 1, 1, 1), dtype=np.float32,
+                          version="0.4", compressor=None, metadata=None) -> None:
+    """Idempotent: an existing position with the same shape is left alone (reference: deskew.py:608-610)."""
+    path = Path(path)
+    T, C, Z, Y, X = (int(s) for s in shape)
+    if len(channel_names) != C:
+        raise ValueError(f"{len(channel_names)} channel names for C={C}")
+    if (path / "0" / ".zarray").exists():
+        if tuple(json.loads((path / "0" / ".zarray").read_text())["shape"]) == (T, C, Z, Y, X):
+            return
+        raise ValueError(f"{path} exists with a different shape")
+    if chunks is None:
+        zc = max(1, min(Z, (64 << 20) // max(1, Y * X * np.dtype(dtype).itemsize)))
+        chunks = (1, 1, zc, Y, X)
+    (path / "0").mkdir(parents=True, exist_ok=True)
+    _write_json(path / ".zgroup", {"zarr_format": 2})
+    _write_json(path / ".zattrs", _position_zattrs(channel_names, scale, version, metadata))
+    _write_json(path / "0" / ".zarray", {
+        "zarr_format": 2, "shape": [T, C, Z, Y, X], "chunks": [int(c) for c in chunks],
+        "dtype": np.dtype(dtype).str, "compressor": compressor, "fill_value": 0, "filters": None, "order": "C",
+        "dimension_separator": "/"})
+
+
+def create_empty_plate(store_path, position_keys, channel_names, shape, chunks=None, scale=(1, 1, 1, 1, 1),
+                       dtype=np.float32, version="0.4", compressor=None, metadata=None) -> None:
+    """HCS plate with empty positions — argument names follow iohub's ``create_empty_plate`` as the reference calls
+    it (biahub/deskew.py:629-640, register.py:488-504)."""
+    store = Path(store_path)
+    store.mkdir(parents=True, exist_ok=True)
+    _write_json(store / ".zgroup", {"zarr_format": 2})
+    attrs = json.loads((store / ".zattrs").read_text()) if (store / ".zattrs").exists() else {}
+    plate = attrs.get("plate", {"version": version, "rows": [], "columns": [], "wells": []})
+    for key in position_keys:
+        row, col, fov = (str(k) for k in key)
+        if {"name": row} not in plate["rows"]:
+            plate["rows"].append({"name": row})
+        if {"name": col} not in plate["columns"]:
+            plate["columns"].append({"name": col})
+        wpath = f"{row}/{col}"
+        if not any(w["path"] == wpath for w in plate["wells"]):
+            plate["wells"].append({"path": wpath, "rowIndex": [r["name"] for r in plate["rows"]].index(row),
+                                   "columnIndex": [c["name"] for c in plate["columns"]].index(col)})
+        (store / row).mkdir(exist_ok=True)
+        _write_json(store / row / ".zgroup", {"zarr_format": 2})
+        well = store / row / col
+        well.mkdir(exist_ok=True)
+        _write_json(well / ".zgroup", {"zarr_format": 2})
+        wattrs = json.loads((well / ".zattrs").read_text()) if (well / ".zattrs").exists() else {"well": {"version": version, "images": []}}
+        if not any(i["path"] == fov for i in wattrs["well"]["images"]):
+            wattrs["well"]["images"].append({"path": fov})
+        _write_json(well / ".zattrs", wattrs)
+        create_empty_position(well / fov, channel_names, shape, chunks, scale, dtype, version, compressor, metadata)
+    attrs["plate"] = plate
+    _write_json(store / ".zattrs", attrs)
+
+
+def process_single_position(func, input_position_path, output_position_path, input_channel_indices=None,
+                            output_channel_indices=None, input_time_indices=None, output_time_indices=None,
+                            num_workers: int = 1, resume: bool = False, resume_token: str | None = None, **kwargs):
+    """Apply ``func(czyx, **kwargs) -> czyx`` to every (time, channel-group) unit of one position.
+
+    Mirrors how the reference drives its operators (call sites biahub/deskew.py:738-749,
+    register.py:556-574, stabilize.py:287-300): one channel per call by default, all-zero/NaN inputs skipped,
+    ``input_time_index`` injected when ``func`` declares it, ``extra_metadata`` moved into the output zattrs,
+    finished units recorded for ``resume`` under the ``resume_token``.  Units run serially in this process:
+    the GPU is the parallel resource here, not a pool of CPU workers (``num_workers`` is accepted and ignored).
+    """
+    extra_metadata = kwargs.pop("extra_metadata", None)
+    src, dst = Position(input_position_path), Position(output_position_path)
+    T, C = src.data.shape[:2]
+    in_t = list(range(T)) if input_time_indices is None else list(input_time_indices)
+    out_t = in_t if output_time_indices is None else list(output_time_indices)
+    in_c = [[c] for c in range(C)] if input_channel_indices is None else [list(g) for g in input_channel_indices]
+    out_c = in_c if output_channel_indices is None else [list(g) for g in output_channel_indices]
+    if len(in_t) != len(out_t) or len(in_c) != len(out_c):
+        raise ValueError("input and output index lists must have the same length")
+    wants_t = "input_time_index" in inspect.signature(func).parameters
+    done_file = dst.path / ".biahub_amd_done.json"
+    done = {}
+    if resume and done_file.exists():
+        rec = json.loads(done_file.read_text())
+        if rec.get("token") == resume_token:
+            done = rec.get("units", {})
+    n_run = 0
+    for ti, to in zip(in_t, out_t):
+        for gi, go in zip(in_c, out_c):
+            key = f"{to}:{','.join(map(str, go))}"
+            if resume and done.get(key):
+                continue
+            czyx = np.stack([src.data.read_volume(ti, c) for c in gi])
+            if not _check_nan_n_zeros(czyx):
+                call_kw = dict(kwargs)
+                if wants_t:
+                    call_kw["input_time_index"] = ti
+                res = np.asarray(func(czyx, **call_kw))
+                if res.shape[0] != len(go):
+                    raise ValueError(f"operator returned {res.shape[0]} channels for {len(go)} output channels")
+                for c, vol in zip(go, res):
+                    dst.data.write_volume(to, c, vol)
+                n_run += 1
+            done[key] = True
+            _write_json(done_file, {"token": resume_token, "units": done})
+    if extra_metadata:
+        merged = dict(dst.zattrs.get("extra_metadata", {}))
+        merged.update(extra_metadata)
+        dst.update_zattrs({"extra_metadata": merged})
+    return n_run
