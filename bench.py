@@ -64,10 +64,10 @@ def synthetic_position(shape, seed, device):
 
 
 def pmc_traffic(key, shape):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01d_pmc_hbm_traffic.json: separate
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json: separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command, fetch doubled for gfx950 as
     MI355X_MICROARCH.md prescribes).  Only valid for the shape it was collected on."""
-    f = ROOT / "profiles" / "r01d_pmc_hbm_traffic.json"
+    f = ROOT / "profiles" / "r01_pmc_hbm_traffic.json"
     if not f.exists():
         return None
     rec = json.load(open(f))
@@ -110,6 +110,7 @@ def main():
 
     rank, local_rank, world = parallel.world_info()
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    local_rank %= max(1, torch.cuda.device_count())  # one rank per GPU; wraps only in a BH_DIST_BACKEND=gloo rehearsal
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     parallel.init("nccl", dev)  # RCCL; used only for the timing barrier / max-over-ranks, never on the data path
@@ -182,8 +183,8 @@ def main():
                 "positions_per_step": world,
             },
             "roofline": {
-                "kernel": "one Richardson-Lucy iteration = 2 fused FFT convolutions x 5 in-place passes "
-                          "(x_fwd, col_pass Y, col_pass Z fwd*OTF*inv, col_pass Y inv, x_inv+epilogue; csrc/fftconv.hip)",
+                "kernel": "one Richardson-Lucy iteration = 8 in-place passes of csrc/fftconv.hip: 2 x (col_pass Y fwd, "
+                          "col_pass Z fwd*OTF*inv, col_pass Y inv, x_inv_kernel<FUSE>: inverse X + RL epilogue + next forward X)",
                 "bound": "hbm",
                 "achieved": rl_bytes / rl_iter_s / 1e9,
                 "peak": HBM_PEAK_GBS,

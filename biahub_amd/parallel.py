@@ -41,7 +41,8 @@ def init(backend: str | None = None, device: torch.device | None = None):
     """Initialise torch.distributed when WORLD_SIZE > 1 ('nccl' == RCCL on GPUs, 'gloo' on CPU)."""
     rank, _, world = world_info()
     if world > 1 and not dist.is_initialized():
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # BH_DIST_BACKEND=gloo lets a multi-rank run be rehearsed on a box with fewer GPUs than ranks
+        backend = os.environ.get("BH_DIST_BACKEND") or backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world
@@ -52,11 +53,18 @@ def barrier(device=None):
         dist.barrier()
 
 
+def _comm_device(device):
+    """Collectives run on the GPU for RCCL and on the host for gloo."""
+    if device is None or (dist.is_initialized() and dist.get_backend() == "gloo"):
+        return "cpu"
+    return device
+
+
 def max_over_ranks(value: float, device=None) -> float:
     """The slowest rank's value (bench.py's timing contract)."""
     if not dist.is_initialized():
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -64,7 +72,7 @@ def max_over_ranks(value: float, device=None) -> float:
 def gather_stats(stats: RankStats, device=None):
     """all_gather of 4 doubles per rank; every rank gets the list (rank 0 writes the plate metadata)."""
     mine = torch.tensor([stats.n_done, stats.n_failed, stats.seconds, stats.voxels], dtype=torch.float64,
-                        device=device if device is not None else "cpu")
+                        device=_comm_device(device))
     if not dist.is_initialized():
         rows = [mine]
     else:
