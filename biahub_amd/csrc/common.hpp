@@ -79,6 +79,10 @@ struct bh_ctx {
     std::map<std::tuple<int64_t, int64_t, int64_t>, bh::FftPlans> plans;
     std::map<std::string, bh::Scratch> scratch;
     int num_cus = 256;
+    // Richardson-Lucy OTF cache: the OTF in "fc_otf" belongs to the PSF with this content hash / these shapes
+    bool otf_valid = false;
+    unsigned long long otf_hash = 0;
+    int64_t otf_dims[6] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace bh {

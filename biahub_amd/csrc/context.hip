@@ -104,6 +104,7 @@ int bh_ctx_release_workspace(bh_ctx* ctx) {
     for (auto& kv : ctx->scratch)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     ctx->scratch.clear();
+    ctx->otf_valid = false;
     return BH_OK;
 }
 

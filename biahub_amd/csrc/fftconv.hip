@@ -667,6 +667,13 @@ __global__ __launch_bounds__(FC_NT) void x_fwd_kernel(XParams p) {
         for (int u = 0; u < ROUNDS; ++u) {
             const int c = rr + u * RPR;
             if (c < FC_XR) {
+                if (p.out) {  // Richardson-Lucy start: e0 = max(d, 0) is stored and transformed in one pass
+                    v[u].x = fmaxf(v[u].x, 0.0f);
+                    v[u].y = fmaxf(v[u].y, 0.0f);
+                    v[u].z = fmaxf(v[u].z, 0.0f);
+                    v[u].w = fmaxf(v[u].w, 0.0f);
+                    *reinterpret_cast<float4*>(p.out + x_row_index(d, t, c) * d.X + 4 * q) = v[u];
+                }
                 buf[(size_t)(2 * q) * FC_XPITCH + c] = make_float2(v[u].x, v[u].y);
                 buf[(size_t)(2 * q + 1) * FC_XPITCH + c] = make_float2(v[u].z, v[u].w);
             }
@@ -1060,10 +1067,11 @@ __global__ __launch_bounds__(256) void tikhonov_filter_rows_kernel(const float* 
 //   S = Xfwd(est);  repeat { Y, Z*OTF, Yinv ; [Xinv -> d/max(.,eps) -> Xfwd] ; Y, Z*conj(OTF), Yinv ;
 //                            [Xinv -> est = max(est*.,0) (stored) -> Xfwd] }   (last iteration: no trailing Xfwd)
 // 8 passes and 84 B/voxel per iteration instead of 10 passes and 96 B/voxel.
+// `est` is output only: the first pass fills it with max(d, 0).
 int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, const cf* otf, cf* spec, int iterations,
                             float eps, float* est) {
     if (iterations <= 0) return BH_OK;
-    BH_TRY(launch_x(ctx, pl, false, 0, est, spec, nullptr, nullptr, 0.f));
+    BH_TRY(launch_x(ctx, pl, false, 0, d, spec, est, nullptr, 0.f));  // est = max(d, 0) written by the same pass
     for (int it = 0; it < iterations; ++it) {
         BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));
         BH_TRY(launch_col(ctx, pl, COL_CONV, true, spec, otf, 1.f));

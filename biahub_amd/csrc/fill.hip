@@ -172,20 +172,33 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict_
 __global__ __launch_bounds__(256) void apply_fill_kernel(float* __restrict__ data, const uint32_t* __restrict__ md,
                                                          const FillStats* __restrict__ st, int64_t rows, int X,
                                                          int W32) {
+    // One coalesced load fetches the 64-bit mask words of 64 consecutive segments (one per lane); the wave then
+    // walks them with the word broadcast from its lane, so the masked stores are not serialised behind a dependent
+    // mask load per segment.
     const float fill = st->fill;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int W64 = W32 / 2;
     const int64_t nseg = rows * W64;
-    for (int64_t seg = (int64_t)blockIdx.x * 4 + wave; seg < nseg; seg += (int64_t)gridDim.x * 4) {
-        const int64_t row = seg / W64;
-        const int wq = (int)(seg % W64);
-        const uint32_t lo = md[row * W32 + wq * 2];
-        const uint32_t hi = md[row * W32 + wq * 2 + 1];
-        if ((lo | hi) == 0u) continue;
-        const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-        const int x = wq * 64 + lane;
-        if (x < X && ((m >> lane) & 1ull)) data[row * X + x] = fill;
+    const unsigned long long* md64 = reinterpret_cast<const unsigned long long*>(md);
+    for (int64_t s0 = ((int64_t)blockIdx.x * 4 + wave) * 64; s0 < nseg; s0 += (int64_t)gridDim.x * 4 * 64) {
+        const int64_t mine = s0 + lane;
+        const unsigned long long w = mine < nseg ? md64[mine] : 0ull;
+        if (__ballot(w != 0ull) == 0ull) continue;
+        int64_t row = s0 / W64;
+        int wq = (int)(s0 - row * W64);
+        const int cnt = (int)min((int64_t)64, nseg - s0);
+        for (int k = 0; k < cnt; ++k) {
+            const unsigned long long m = __shfl(w, k, 64);
+            if (m != 0ull) {
+                const int x = wq * 64 + lane;
+                if (x < X && ((m >> lane) & 1ull)) data[row * X + x] = fill;
+            }
+            if (++wq == W64) {
+                wq = 0;
+                ++row;
+            }
+        }
     }
 }
 
