@@ -526,13 +526,28 @@ struct XParams {
     float eps;
 };
 
-// tile = (z, group g): rows c < 8 -> y = 8g + c ; rows c >= 8 -> y = 8g + (c - 8) + Y/2
-__device__ __forceinline__ long x_row_index(const ConvDims& d, long tile, int c) {
+// tile = (z, group g): rows c < 8 -> y = 8g + c ; rows c >= 8 -> y = 8g + (c - 8) + Y/2.
+// row0 = z * Y + 8 g is computed ONCE per tile (a 64-bit division per row load costs more than the FFT's index math).
+__device__ __forceinline__ long x_tile_row0(const ConvDims& d, long tile) {
     const int gpz = d.Y / FC_XR;  // groups per z
-    const long z = tile / gpz;
-    const int g = (int)(tile - z * gpz);
-    const int y = 8 * g + (c & 7) + ((c >> 3) ? d.Y / 2 : 0);
-    return z * d.Y + y;
+    const int ti = (int)tile;     // host guarantees < 2^31 tiles
+    const int z = ti / gpz;
+    const int g = ti - z * gpz;
+    return (long)z * d.Y + 8 * g;
+}
+__device__ __forceinline__ long x_row_index(const ConvDims& d, long row0, int c) {
+    return row0 + (c & 7) + ((c >> 3) ? d.Y / 2 : 0);
+}
+// 32-bit element offset of (tile row c, column col) from the tile's first row, for a row pitch `pitch`
+// ((Y/2 + 8) * pitch < 2^31 for every supported shape)
+__device__ __forceinline__ unsigned x_row_off(const ConvDims& d, int c, int pitch, int col) {
+    return (unsigned)(((c & 7) + ((c >> 3) ? d.Y / 2 : 0)) * pitch + col);
+}
+// opaque copy of a per-thread value: address math built on it stays inside the tile loop instead of being
+// hoisted into (scarce) registers for the whole kernel
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
 }
 
 // untangle in place after the packed length-M FFT: pairs (p, mirror(p)); u = 0 handles DC + Nyquist and p = 1
@@ -586,8 +601,8 @@ __device__ __forceinline__ void x_forward_from_lds(cf* buf, const cf* tw, const 
 
     // Y radix-2 step across each row pair, then store the spectrum rows
     const int gpz = d.Y / FC_XR;
-    const long z = t / gpz;
-    const int g = (int)(t - z * gpz);
+    const int z = (int)t / gpz;
+    const int g = (int)t - z * gpz;
     if (ROUNDS >= 2) {
         // this thread's rounds u and u + HALF are exactly a pair (y, y + Y/2): two columns per lane, 16-B stores
 #pragma unroll
@@ -654,15 +669,18 @@ __global__ __launch_bounds__(FC_NT) void x_fwd_kernel(XParams p) {
 
     float4 v[ROUNDS];
     auto load_tile = [&](long t) {
+        const float* base = p.in + x_tile_row0(d, t) * d.X;
+        const int rro = opaque(rr);
 #pragma unroll
         for (int u = 0; u < ROUNDS; ++u) {
-            const int c = min(rr + u * RPR, FC_XR - 1);
-            v[u] = *reinterpret_cast<const float4*>(p.in + x_row_index(d, t, c) * d.X + 4 * q);
+            const int c = min(rro + u * RPR, FC_XR - 1);
+            v[u] = *reinterpret_cast<const float4*>(base + x_row_off(d, c, d.X, 4 * q));
         }
     };
     long t = blockIdx.x;
     if (t < ntiles) load_tile(t);
     for (; t < ntiles; t += gridDim.x) {
+        float* obase = p.out ? p.out + x_tile_row0(d, t) * d.X : nullptr;
 #pragma unroll
         for (int u = 0; u < ROUNDS; ++u) {
             const int c = rr + u * RPR;
@@ -672,7 +690,7 @@ __global__ __launch_bounds__(FC_NT) void x_fwd_kernel(XParams p) {
                     v[u].y = fmaxf(v[u].y, 0.0f);
                     v[u].z = fmaxf(v[u].z, 0.0f);
                     v[u].w = fmaxf(v[u].w, 0.0f);
-                    *reinterpret_cast<float4*>(p.out + x_row_index(d, t, c) * d.X + 4 * q) = v[u];
+                    *reinterpret_cast<float4*>(obase + x_row_off(d, c, d.X, 4 * q)) = v[u];
                 }
                 buf[(size_t)(2 * q) * FC_XPITCH + c] = make_float2(v[u].x, v[u].y);
                 buf[(size_t)(2 * q + 1) * FC_XPITCH + c] = make_float2(v[u].z, v[u].w);
@@ -712,20 +730,23 @@ __global__ __launch_bounds__(FC_NT) void x_inv_kernel(XParams p) {
     float4 v[ROUNDS];
     cf nyA = make_float2(0.f, 0.f), nyB = nyA;
     auto load_tile = [&](long t) {
+        const cf* base = p.S + x_tile_row0(d, t) * d.XP;
+        const int rro = opaque(rr);
 #pragma unroll
         for (int u = 0; u < ROUNDS; ++u) {
-            const int c = min(rr + u * RPR, FC_XR - 1);
-            v[u] = *reinterpret_cast<const float4*>(p.S + x_row_index(d, t, c) * d.XP + 2 * q);
+            const int c = min(rro + u * RPR, FC_XR - 1);
+            v[u] = *reinterpret_cast<const float4*>(base + x_row_off(d, c, d.XP, 2 * q));
         }
-        const int rp = tid & 7;  // every thread loads (16 distinct addresses per tile: cache hits), 8 use it
-        nyA = p.S[x_row_index(d, t, rp) * d.XP + M];
-        nyB = p.S[x_row_index(d, t, rp + 8) * d.XP + M];
+        const int rp = opaque(tid) & 7;  // every thread loads (16 distinct addresses per tile: cache hits), 8 use it
+        nyA = base[x_row_off(d, rp, d.XP, M)];
+        nyB = base[x_row_off(d, rp + 8, d.XP, M)];
     };
     long t = blockIdx.x;
     if (FAST && t < ntiles) load_tile(t);
     for (; t < ntiles; t += gridDim.x) {
-        const long z = t / gpz;
-        const int g = (int)(t - z * gpz);
+        const int z = (int)t / gpz;
+        const int g = (int)t - z * gpz;
+        const long trow0 = (long)z * d.Y + 8 * g;
         if (FAST) {
             // undo the Y radix-2 step in registers, write X[p] into LDS (transposed)
 #pragma unroll
@@ -766,8 +787,8 @@ __global__ __launch_bounds__(FC_NT) void x_inv_kernel(XParams p) {
         auto load_aux = [&]() {
 #pragma unroll
             for (int u = 0; u < ROUNDS; ++u) {
-                const int c = min(rr + u * RPR, FC_XR - 1);
-                aux[u] = *reinterpret_cast<const float4*>(p.aux + x_row_index(d, t, c) * d.X + 4 * q);
+                const int c = min(opaque(rr) + u * RPR, FC_XR - 1);
+                aux[u] = *reinterpret_cast<const float4*>(p.aux + trow0 * d.X + x_row_off(d, c, d.X, 4 * q));
             }
         };
         if (FUSE) {
@@ -782,8 +803,9 @@ __global__ __launch_bounds__(FC_NT) void x_inv_kernel(XParams p) {
         // natural order now: z[j] = x[2j] + i x[2j+1]; apply the fused epilogue to the real rows
 #pragma unroll
         for (int u = 0; u < ROUNDS; ++u) {
-            const int c = min(rr + u * RPR, FC_XR - 1);
-            const bool mine = rr + u * RPR < FC_XR;
+            const int rro = opaque(rr);
+            const int c = min(rro + u * RPR, FC_XR - 1);
+            const bool mine = rro + u * RPR < FC_XR;
             const cf e0 = buf[(size_t)(2 * q) * FC_XPITCH + c], e1 = buf[(size_t)(2 * q + 1) * FC_XPITCH + c];
             float4 r = make_float4(e0.x, e0.y, e1.x, e1.y);
             if (EPI == XE_RATIO) {
@@ -801,7 +823,7 @@ __global__ __launch_bounds__(FC_NT) void x_inv_kernel(XParams p) {
             }
             // the ratio of a fused pass never leaves the chip; everything else is written out
             if (mine && !(FUSE && EPI == XE_RATIO))
-                *reinterpret_cast<float4*>(p.out + x_row_index(d, t, c) * d.X + 4 * q) = r;
+                *reinterpret_cast<float4*>(p.out + trow0 * d.X + x_row_off(d, c, d.X, 4 * q)) = r;
             // fused: the rows feed the next convolution's forward X pass straight from LDS (no HBM round trip);
             // each thread overwrites exactly the two packed elements it just read
             if (FUSE && mine) {
