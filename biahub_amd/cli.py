@@ -236,10 +236,11 @@ def stabilize_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, moni
 @click.option("--output-dirpath", "-o", required=True, type=click.Path(path_type=Path))
 @click.option("--local", "-l", is_flag=True, default=False)
 def register_cli(source_position_dirpaths, target_position_dirpaths, config_filepath, output_dirpath, local):
-    """Warp source channels onto the target grid and copy the target channel (reference: ``biahub register``;
-    ``keep_overhang`` is honoured by registering onto the full target grid — the LIR crop estimate is out of scope)."""
+    """Warp source channels onto the target grid and copy the target channel (reference: ``biahub register``).
+    With ``keep_overhang: false`` the output is cropped to the largest interior cuboid of the overlap
+    (register.py:469-478)."""
     from .array_ops import copy_n_paste_czyx
-    from .register import apply_affine_transform, rescale_voxel_size
+    from .register import apply_affine_transform, find_overlapping_volume, rescale_voxel_size
 
     settings = yaml_to_model(config_filepath, RegistrationSettings)
     M = np.asarray(settings.affine_transform_zyx, dtype=np.float64)
@@ -247,10 +248,17 @@ def register_cli(source_position_dirpaths, target_position_dirpaths, config_file
         src_names, tgt_names = src.channel_names, tgt.channel_names
         T = min(src.data.shape[0], tgt.data.shape[0])
         tgt_shape = tgt.data.shape[-3:]
+        src_shape = src.data.shape[-3:]
         out_scale = (1, 1) + tuple(rescale_voxel_size(M[:3, :3], np.asarray(src.scale[-3:])))
+    crop = None
+    out_zyx = tuple(tgt_shape)
+    if not settings.keep_overhang:
+        crop = find_overlapping_volume(src_shape, tgt_shape, M)
+        out_zyx = tuple(s.stop - s.start for s in crop)
+        click.echo(f"Cropping to the overlapping volume: {crop}")
     out_names = list(dict.fromkeys(list(settings.source_channel_names) + [settings.target_channel_name]))
     create_empty_plate(output_dirpath, [p.parts[-3:] for p in source_position_dirpaths], out_names,
-                       (T, len(out_names)) + tuple(tgt_shape), scale=out_scale)
+                       (T, len(out_names)) + out_zyx, scale=out_scale)
     outs = get_output_paths(source_position_dirpaths, output_dirpath)
     tidx = list(range(T)) if settings.time_indices == "all" else list(np.atleast_1d(settings.time_indices))
 
@@ -261,9 +269,9 @@ def register_cli(source_position_dirpaths, target_position_dirpaths, config_file
                                     input_channel_indices=[[src_names.index(name)]],
                                     output_channel_indices=[[out_names.index(name)]], input_time_indices=tidx,
                                     output_time_indices=tidx, matrix=M, output_shape_zyx=tuple(tgt_shape),
-                                    interpolation=settings.interpolation)
+                                    interpolation=settings.interpolation, crop_output_slicing=crop)
         if settings.target_channel_name not in settings.source_channel_names:
-            full = [slice(0, n) for n in tgt_shape]
+            full = list(crop) if crop is not None else [slice(0, n) for n in tgt_shape]
             process_single_position(copy_n_paste_czyx, tpath, dst,
                                     input_channel_indices=[[tgt_names.index(settings.target_channel_name)]],
                                     output_channel_indices=[[out_names.index(settings.target_channel_name)]],

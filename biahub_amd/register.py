@@ -92,6 +92,65 @@ def affine_device(vol, matrix, output_shape_zyx, interpolation="linear", boundar
     return out
 
 
+def largest_interior_rectangle(mask2d: np.ndarray):
+    """(x, y, width, height) of the largest axis-aligned all-True rectangle of a 2-D boolean grid.
+
+    Stands in for ``largestinteriorrectangle.lir`` (0.2.1, uv.lock:2327 — absent here) as the reference uses it
+    (register.py:289-308): maximal-rectangle-under-histogram sweep, O(H*W); among equal areas the first found in
+    row-major order of the bottom-right corner wins.
+    """
+    m = np.asarray(mask2d, dtype=bool)
+    H, W = m.shape
+    heights = np.zeros(W + 1, dtype=np.int64)
+    best = (0, 0, 0, 0, 0)  # area, x, y, w, h
+    for r in range(H):
+        heights[:W] = np.where(m[r], heights[:W] + 1, 0)
+        stack = []
+        for c in range(W + 1):
+            h = heights[c]
+            start = c
+            while stack and stack[-1][1] > h:
+                s0, sh = stack.pop()
+                area = sh * (c - s0)
+                if area > best[0]:
+                    best = (area, s0, r - sh + 1, c - s0, sh)
+                start = s0
+            if not stack or stack[-1][1] < h:
+                stack.append((start, h))
+    return best[1], best[2], best[3], best[4]
+
+
+def find_lir(registered_zyx: np.ndarray, plot: bool = False) -> tuple:
+    """Largest interior cuboid of a registered mask, the reference's heuristic (register.py:284-342): LIR of the
+    mid-Z YX plane, then the Z extent common to six probe ZY / ZX slices through that rectangle."""
+    reg = np.asarray(registered_zyx, dtype=bool)
+    x, y, width, height = largest_interior_rectangle(reg[reg.shape[0] // 2])
+    x_start, x_stop, y_start, y_stop = x, x + width, y, y + height
+    x_slice, y_slice = slice(x_start, x_stop), slice(y_start, y_stop)
+    spans = []
+    for _x in (x_start, x_start + (x_stop - x_start) // 2, x_stop - 1):
+        _, z, _, depth = largest_interior_rectangle(reg[:, y_slice, _x])
+        spans.append((z, z + depth))
+    for _y in (y_start, y_start + (y_stop - y_start) // 2, y_stop - 1):
+        _, z, _, depth = largest_interior_rectangle(reg[:, _y, x_slice])
+        spans.append((z, z + depth))
+    spans = np.asarray(spans)
+    return slice(int(spans[:, 0].max()), int(spans[:, 1].min())), y_slice, x_slice
+
+
+def find_overlapping_volume(input_zyx_shape: tuple, target_zyx_shape: tuple, transformation_matrix: np.ndarray,
+                            method: str = "LIR", plot: bool = False, device="cuda") -> tuple:
+    """ZYX slices of the cuboid covered by the warped source inside the target grid (register.py:345-394): an
+    all-ones volume is warped on the GPU (ITK boundary rule, like ANTs) and the LIR heuristic runs on the mask."""
+    if method != "LIR":
+        raise ValueError(f"Unknown method {method}")
+    dev = resolve_device(device)
+    ones = torch.ones(tuple(int(s) for s in input_zyx_shape), dtype=torch.float32, device=dev)
+    warped = affine_device(ones, transformation_matrix, tuple(int(s) for s in target_zyx_shape), "linear",
+                           _lib.BOUNDARY_ITK, 0.0, device=dev)
+    return find_lir((warped > 0).cpu().numpy(), plot=plot)
+
+
 def _slice_bounds(sl: slice, n: int):
     start, stop, step = sl.indices(n)
     if step != 1:

@@ -341,3 +341,37 @@ def test_tikhonov_fused_engine_vs_oracle(gpu, shape, monkeypatch):
     monkeypatch.setenv("BH_FFT_BACKEND", "hipfft")
     got2 = deconvolve(czyx, transfer_function=tf, regularization_strength=1e-3)
     assert rel_err(got, got2) <= FFT_TOL
+
+
+def test_find_overlapping_volume(gpu):
+    from biahub_amd.register import apply_affine_transform, find_overlapping_volume
+
+    m = np.eye(4)
+    m[:3, 3] = [-3, 1, 4]  # the reference's integer-shift case: valid region [3:10, 0:9, 0:6]
+    assert find_overlapping_volume((10, 10, 10), (10, 10, 10), m) == (slice(3, 10), slice(0, 9), slice(0, 6))
+    M = _similarity(5.0, 1.0, (1.5, -3.0, 6.0))
+    zs, ys, xs = find_overlapping_volume((24, 40, 72), (20, 44, 80), M)
+    warped = apply_affine_transform(np.ones((24, 40, 72), np.float32), M, (20, 44, 80), crop_output_slicing=(zs, ys, xs))
+    assert warped.size > 0 and np.all(warped > 0)  # the cuboid lies inside the covered region
+    with pytest.raises(ValueError, match="Unknown method"):
+        find_overlapping_volume((4, 4, 4), (4, 4, 4), m, method="hull")
+
+
+def test_richardson_lucy_properties_large(gpu, monkeypatch):
+    """Size-independent properties at a size the oracle would not finish quickly (BASELINE config 3/4 volume)."""
+    from biahub_amd.deconvolve import richardson_lucy
+
+    shape = (256, 1024, 1024)
+    g = torch.Generator(device=gpu).manual_seed(7)
+    vol = (torch.rand(shape, generator=g, device=gpu) * 300 + 100).round_()
+    psf = torch.from_numpy(O.gaussian_psf((33, 17, 17), (3.0, 1.5, 1.5))).to(gpu)
+    est = richardson_lucy(vol, psf, 5, 1e-6)
+    assert float(est.min()) >= 0.0 and bool(torch.isfinite(est).all())
+    flux_in, flux_out = float(vol.double().sum()), float(est.double().sum())
+    assert abs(flux_out - flux_in) / flux_in < 1e-4                      # R-L with a unit-sum PSF conserves flux
+    assert float(est.var()) > float(vol.var())                            # and sharpens
+    flat = richardson_lucy(torch.full(shape, 42.0, device=gpu), psf, 3, 1e-6)
+    assert float((flat - 42.0).abs().max()) < 1e-2                        # a constant image is a fixed point
+    monkeypatch.setenv("BH_FFT_BACKEND", "hipfft")                        # the two FFT back-ends agree at full size
+    est_ref = richardson_lucy(vol, psf, 5, 1e-6)
+    assert float((est - est_ref).abs().max()) <= FFT_TOL * float(est_ref.abs().max())

@@ -88,3 +88,18 @@ def test_matrix_builders(helpers_golden):
     p = register.convert_transform_to_ants(np.arange(16.0).reshape(4, 4))
     np.testing.assert_array_equal(p, [0, 1, 2, 4, 5, 6, 8, 9, 10, 3, 7, 11])
     np.testing.assert_allclose(register.convert_transform_to_numpy(p)[:3], np.arange(16.0).reshape(4, 4)[:3])
+
+
+def test_find_lir_reference_known_answer():
+    # tests/test_cli/test_register_cli.py:75-86 of the reference
+    data = np.zeros((10, 10, 10))
+    data[2:8, 0:9, 3:10] = 1
+    z_slice, y_slice, x_slice = register.find_lir(data)
+    assert (z_slice, y_slice, x_slice) == (slice(2, 8), slice(0, 9), slice(3, 10))
+    assert register.largest_interior_rectangle(np.ones((4, 7), bool)) == (0, 0, 7, 4)
+    m = np.zeros((6, 8), bool)
+    m[1:5, 2:7] = True
+    m[1, 2] = False  # a notch: the best rectangle avoids it
+    x, y, w, h = register.largest_interior_rectangle(m)
+    assert w * h == 16 and m[y:y + h, x:x + w].all()
+    assert register.largest_interior_rectangle(np.zeros((3, 3), bool))[2:] == (0, 0)
