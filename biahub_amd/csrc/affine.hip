@@ -14,6 +14,8 @@
 // and accumulation float32.
 #include "common.hpp"
 
+#include <cmath>
+
 namespace bh {
 
 constexpr int ATX = 64, ATY = 8, ATZ = 8;
@@ -21,6 +23,7 @@ constexpr int A_LDS_FLOATS = 9216;   // 36 KiB -> four workgroups per CU
 
 struct AffineParams {
     double m[12];
+    long long mq[12];  // the same matrix in Q32.32 fixed point (linear interior fast path)
     int Zi, Yi, Xi;
     int Zo, Yo, Xo;
     int cz, cy, cx;
@@ -67,7 +70,7 @@ template <typename TIN, int INTERP, int BOUNDARY>
 __global__ __launch_bounds__(256) void affine_kernel(const TIN* __restrict__ in, float* __restrict__ out,
                                                      AffineParams p) {
     __shared__ float tile[A_LDS_FLOATS];
-    __shared__ int box[6];
+    __shared__ int box[9];  // origin[3], extent[3], interior flag per axis[3]
     const int tx = threadIdx.x & 63;
     const int ty = threadIdx.x >> 6;
     const int ox0 = blockIdx.x * ATX, oy0 = blockIdx.y * ATY, oz0 = blockIdx.z * ATZ;
@@ -92,6 +95,8 @@ __global__ __launch_bounds__(256) void affine_kernel(const TIN* __restrict__ in,
         double l = fmax(floor(lo), 0.0), h = fmin(floor(hi) + 1.0, (double)(n - 1));
         box[a] = (int)l;
         box[3 + a] = (h >= l) ? (int)(h - l) + 1 : 0;
+        // interior: every floor(c) and floor(c)+1 of this tile is a valid index on this axis (no clamp, no test)
+        box[6 + a] = (floor(lo) >= 0.0 && floor(hi) + 1.0 <= (double)(n - 1)) ? 1 : 0;
     }
     __syncthreads();
     const int bz = box[0], by = box[1], bx = box[2];
@@ -173,6 +178,75 @@ __global__ __launch_bounds__(256) void affine_kernel(const TIN* __restrict__ in,
         return load_clean(in + (size_t)iz * sZ + (size_t)iy * sY + ix);
     };
     const int dims[3] = {p.Zi, p.Yi, p.Xi};
+    if (INTERP == BH_INTERP_LINEAR && BOUNDARY != BH_BOUNDARY_ZEROS) {
+        // Linear with edge clamp (ITK / SciPy rules).  Coordinates in Q32.32 fixed point: the integer part is
+        // floor(c) for free and the next z is one 64-bit add per axis; the eight taps are combined as three nested
+        // lerps.  Tiles whose source box is strictly inside the volume (the bulk of a registration warp) skip all
+        // bounds handling and read the taps as paired LDS loads; the arithmetic is identical in both branches, so a
+        // voxel's value does not depend on which tile (or crop) computed it.
+        const bool interior = staged && box[6] && box[7] && box[8];
+        const int sxy = dy * dx;
+        for (int yy = ty; yy < ATY; yy += 4) {
+            const int oy = oy0 + yy;
+            if (oy >= p.Yo) break;
+            long long c0[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                c0[a] = p.mq[4 * a] * (long long)(oz0 + p.cz) + p.mq[4 * a + 1] * (long long)(oy + p.cy) +
+                        p.mq[4 * a + 2] * (long long)(ox + p.cx) + p.mq[4 * a + 3];
+            float* o = out + ((size_t)oz0 * p.Yo + oy) * p.Xo + ox;
+            const size_t ostep = (size_t)p.Yo * p.Xo;
+            for (int k = 0; k < ATZ && oz0 + k < p.Zo; ++k) {
+                const int iz = (int)(c0[0] >> 32), iy = (int)(c0[1] >> 32), ix = (int)(c0[2] >> 32);
+                const float fz = (float)(unsigned)(c0[0] & 0xffffffffll) * 2.3283064365386963e-10f;
+                const float fy = (float)(unsigned)(c0[1] & 0xffffffffll) * 2.3283064365386963e-10f;
+                const float fx = (float)(unsigned)(c0[2] & 0xffffffffll) * 2.3283064365386963e-10f;
+                float v000, v001, v010, v011, v100, v101, v110, v111;
+                bool inside = true;
+                if (interior) {
+                    const float* t0 = tile + ((iz - bz) * sxy + (iy - by) * dx + (ix - bx));
+                    const float* t1 = t0 + sxy;
+                    v000 = t0[0], v001 = t0[1], v010 = t0[dx], v011 = t0[dx + 1];
+                    v100 = t1[0], v101 = t1[1], v110 = t1[dx], v111 = t1[dx + 1];
+                } else {
+                    // The inside/outside decision at the volume faces uses the float64 coordinate in numpy / ITK
+                    // association (ties such as c == -0.5 exactly must fall like the reference's); only boundary
+                    // tiles pay for it.
+                    {
+#pragma clang fp contract(off)
+                        const double zd = (double)(oz0 + k + p.cz), yd = (double)(oy + p.cy), xd = (double)(ox + p.cx);
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const double ca = p.m[4 * a] * zd + p.m[4 * a + 1] * yd + p.m[4 * a + 2] * xd + p.m[4 * a + 3];
+                            if (BOUNDARY == BH_BOUNDARY_ITK)
+                                inside = inside && ca >= -0.5 && ca < (double)dims[a] - 0.5;
+                            else
+                                inside = inside && ca >= 0.0 && ca <= (double)(dims[a] - 1);
+                        }
+                    }
+                    if (inside) {
+                        const int z0 = max(0, min(iz, p.Zi - 1)), z1 = max(0, min(iz + 1, p.Zi - 1));
+                        const int y0 = max(0, min(iy, p.Yi - 1)), y1 = max(0, min(iy + 1, p.Yi - 1));
+                        const int x0 = max(0, min(ix, p.Xi - 1)), x1 = max(0, min(ix + 1, p.Xi - 1));
+                        v000 = fetch(z0, y0, x0), v001 = fetch(z0, y0, x1), v010 = fetch(z0, y1, x0), v011 = fetch(z0, y1, x1);
+                        v100 = fetch(z1, y0, x0), v101 = fetch(z1, y0, x1), v110 = fetch(z1, y1, x0), v111 = fetch(z1, y1, x1);
+                    } else {
+                        v000 = v001 = v010 = v011 = v100 = v101 = v110 = v111 = 0.0f;
+                    }
+                }
+                const float a00 = v000 + fx * (v001 - v000);
+                const float a01 = v010 + fx * (v011 - v010);
+                const float a10 = v100 + fx * (v101 - v100);
+                const float a11 = v110 + fx * (v111 - v110);
+                const float b0 = a00 + fy * (a01 - a00);
+                const float b1 = a10 + fy * (a11 - a10);
+                o[k * ostep] = inside ? b0 + fz * (b1 - b0) : p.cval;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) c0[a] += p.mq[4 * a];
+            }
+        }
+        return;
+    }
     for (int yy = ty; yy < ATY; yy += 4) {
         const int oy = oy0 + yy;
         if (oy >= p.Yo) break;
@@ -280,7 +354,11 @@ extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, 
     for (int i = 0; i < 12; ++i) BH_REQUIRE(matrix[i] == matrix[i], "matrix contains NaN");
     BH_CHECK_HIP(hipSetDevice(ctx->device));
     AffineParams p;
-    for (int i = 0; i < 12; ++i) p.m[i] = matrix[i];
+    for (int i = 0; i < 12; ++i) {
+        p.m[i] = matrix[i];
+        BH_REQUIRE(std::fabs(matrix[i]) < 1073741824.0, "matrix entry %d out of range", i);
+        p.mq[i] = std::llround(matrix[i] * 4294967296.0);
+    }
     p.Zi = (int)Zi;
     p.Yi = (int)Yi;
     p.Xi = (int)Xi;
