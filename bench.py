@@ -208,7 +208,7 @@ def main():
             },
             "workspace_gb": ctx.workspace_bytes() / 1e9,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             result["cpu_baseline"] = cpu_baseline(args.iterations)
         print(json.dumps(result), flush=True)
     if world > 1:
