@@ -19,6 +19,7 @@ DT_U8, DT_U16, DT_F32, DT_I16 = 0, 1, 2, 3
 FILL_NONE, FILL_CONSTANT, FILL_MEAN = 0, 1, 2
 INTERP_NEAREST, INTERP_LINEAR = 0, 1
 BOUNDARY_ITK, BOUNDARY_SCIPY_CONSTANT, BOUNDARY_ZEROS = 0, 1, 2
+PCC_NORM = {None: 0, "magnitude": 1, "classic": 2}
 (T_DESKEW, T_FILL, T_RL_TOTAL, T_TIKHONOV, T_AFFINE, T_CROPFLIP, T_RL_ITER, T_TF) = range(8)
 
 _i64, _f64, _f32, _int, _vp = C.c_int64, C.c_double, C.c_float, C.c_int, C.c_void_p
@@ -45,6 +46,7 @@ SIGNATURES = {
     "bh_transfer_function": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "bh_tikhonov": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f64, _vp]),
     "bh_richardson_lucy": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _f32, _vp]),
+    "bh_phase_cross_corr": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, C.POINTER(_f32), _vp]),
     "bh_affine": (_int, [_vp, _vp, _int, _i64, _i64, _i64, C.POINTER(_f64), _int, _int, _f32, _vp, _i64, _i64,
                          _i64, C.POINTER(_i64)]),
     "bh_crop_flip": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, C.POINTER(_i64), _i64, _i64, _i64, _int,

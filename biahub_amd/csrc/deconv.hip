@@ -212,6 +212,66 @@ __global__ void clip_copy_kernel(const float* __restrict__ in, float* __restrict
         out[i] = fmaxf(in[i], 0.0f);
 }
 
+// ---- phase cross-correlation (estimate_stabilization.py:199-256) -------------------------------------------
+// prod = F1 * conj(F2) / norm / V   (the 1/V makes the C2R a normalised irfftn)
+__global__ void pcc_product_kernel(cf* __restrict__ f1, const cf* __restrict__ f2, int64_t n, int mode, float inv_v) {
+    const float eps = 1.1920929e-07f;  // np.finfo(complex64).eps
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cf a = f1[i], b = f2[i];
+        cf p = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+        float nrm = 1.0f;
+        if (mode == BH_PCC_NORM_MAGNITUDE) nrm = fmaxf(hypotf(p.x, p.y), eps);
+        if (mode == BH_PCC_NORM_CLASSIC) nrm = hypotf(a.x, a.y) * hypotf(b.x, b.y);
+        p.x = (p.x / nrm) * inv_v;
+        p.y = (p.y / nrm) * inv_v;
+        f1[i] = p;
+    }
+}
+
+struct ArgMax {
+    float v;
+    long long i;
+};
+__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {  // np.argmax: first occurrence of the maximum
+    if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+// |corr| argmax (first occurrence) + optional fftshift(|corr|) output, one pass
+__global__ __launch_bounds__(256) void pcc_argmax_kernel(const float* __restrict__ corr, float* __restrict__ shifted,
+                                                         int64_t Z, int64_t Y, int64_t X, ArgMax* partial) {
+    const int64_t n = Z * Y * X;
+    ArgMax best = {-1.0f, 0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = fabsf(corr[i]);
+        if (a > best.v) best = ArgMax{a, i};  // i ascends within a thread: '>' keeps the first occurrence
+        if (shifted) {
+            const int64_t x = i % X, y = (i / X) % Y, z = i / (X * Y);
+            const int64_t sx = (x + X / 2) % X, sy = (y + Y / 2) % Y, sz = (z + Z / 2) % Z;  // np.fft.fftshift
+            shifted[(sz * Y + sy) * X + sx] = a;
+        }
+    }
+    __shared__ ArgMax sh[256];
+    sh[threadIdx.x] = best;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] = better(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void pcc_argmax_final_kernel(const ArgMax* partial, int n, ArgMax* out) {
+    __shared__ ArgMax sh[256];
+    ArgMax best = {-1.0f, 0};
+    for (int i = threadIdx.x; i < n; i += 256) best = better(best, partial[i]);
+    sh[threadIdx.x] = best;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] = better(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+
 static inline dim3 grid_for(bh_ctx* ctx, int64_t n, int tb = 256) {
     int64_t g = ceil_div(n, tb);
     const int64_t cap = (int64_t)ctx->num_cus * 8;
@@ -372,6 +432,53 @@ int bh_transfer_function(bh_ctx* ctx, const float* psf, int64_t pz, int64_t py, 
     hipLaunchKernelGGL(abs_max_kernel, grid_for(ctx, NS), dim3(256), 0, s, spec, mag, NS, gmax);
     hipLaunchKernelGGL(tf_expand_kernel, grid_for(ctx, V), dim3(256), 0, s, mag, tf_full, Z, Y, X, gmax);
     BH_CHECK_HIP(hipGetLastError());
+    return BH_OK;
+}
+
+int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t Z, int64_t Y, int64_t X,
+                        int normalization, float shift[3], float* corr_shifted) {
+    BH_REQUIRE(ctx && ref && mov && shift, "NULL argument");
+    BH_REQUIRE(Z > 0 && Y > 0 && X > 0, "invalid shape");
+    BH_REQUIRE(normalization >= BH_PCC_NORM_NONE && normalization <= BH_PCC_NORM_CLASSIC, "unknown normalization %d",
+               normalization);
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    // The reference calls irfftn without a shape (estimate_stabilization.py:240), so for an odd X the correlation
+    // volume comes back with X - 1 columns; the same half spectrum is inverted by a (Z, Y, Xc) plan here.
+    const int64_t Xc = (X & 1) ? X - 1 : X;
+    BH_REQUIRE(Xc >= 2, "X must be at least 2");
+    FftPlans *pl, *plc;
+    BH_TRY(get_plans(ctx, Z, Y, X, &pl));
+    BH_TRY(get_plans(ctx, Z, Y, Xc, &plc));
+    const int64_t V = Z * Y * Xc, Xh = X / 2 + 1, NS = Z * Y * Xh;
+    cf *s1, *s2;
+    float* corr;
+    ArgMax *partial, *result;
+    const int nblk = ctx->num_cus * 8;
+    BH_TRY(get_scratch(ctx, "fft_spec", NS * sizeof(cf), (void**)&s1));
+    BH_TRY(get_scratch(ctx, "pcc_spec2", NS * sizeof(cf), (void**)&s2));
+    BH_TRY(get_scratch(ctx, "fft_real", Z * Y * X * sizeof(float), (void**)&corr));
+    BH_TRY(get_scratch(ctx, "pcc_partial", (nblk + 1) * sizeof(ArgMax), (void**)&partial));
+    result = partial + nblk;
+    hipStream_t s = ctx->stream;
+    BH_CHECK_FFT(hipfftExecR2C(pl->r2c, const_cast<float*>(ref), (hipfftComplex*)s1));
+    BH_CHECK_FFT(hipfftExecR2C(pl->r2c, const_cast<float*>(mov), (hipfftComplex*)s2));
+    hipLaunchKernelGGL(pcc_product_kernel, grid_for(ctx, NS), dim3(256), 0, s, s1, s2, NS, normalization,
+                       (float)(1.0 / (double)V));
+    BH_CHECK_FFT(hipfftExecC2R(plc->c2r, (hipfftComplex*)s1, corr));
+    hipLaunchKernelGGL(pcc_argmax_kernel, dim3(nblk), dim3(256), 0, s, corr, corr_shifted, Z, Y, Xc, partial);
+    hipLaunchKernelGGL(pcc_argmax_final_kernel, dim3(1), dim3(256), 0, s, partial, nblk, result);
+    BH_CHECK_HIP(hipGetLastError());
+    ArgMax h;
+    BH_CHECK_HIP(hipMemcpyAsync(&h, result, sizeof(h), hipMemcpyDeviceToHost, s));
+    BH_CHECK_HIP(hipStreamSynchronize(s));
+    const int64_t dims[3] = {Z, Y, Xc};
+    int64_t idx[3] = {h.i / (Y * Xc), (h.i / Xc) % Y, h.i % Xc};
+    for (int a = 0; a < 3; ++a) {
+        // shift[shift > fix(n/2)] -= n   (estimate_stabilization.py:246-252)
+        float sft = (float)idx[a];
+        if (sft > (float)(dims[a] / 2)) sft -= (float)dims[a];
+        shift[a] = sft;
+    }
     return BH_OK;
 }
 

@@ -11,6 +11,7 @@
  *   bh_transfer_function   <- biahub/deconvolve.py:30-43 compute_tranfser_function
  *   bh_tikhonov            <- biahub/deconvolve.py:46-66 deconvolve (waveorder Tikhonov)
  *   bh_richardson_lucy     <- (north-star extension; no reference function)
+ *   bh_phase_cross_corr    <- biahub/estimate_stabilization.py:199-256 phase_cross_corr
  *   bh_affine              <- biahub/register.py:202-281 apply_affine_transform,
  *                             biahub/stabilize.py:32-90 apply_stabilization_transform,
  *                             biahub/core/transform.py:374-396 Transform._apply_scipy
@@ -124,6 +125,17 @@ int bh_tikhonov(bh_ctx* ctx, const float* in, const float* tf_full, int64_t Z, i
 int bh_richardson_lucy(bh_ctx* ctx, const float* in, const float* psf, int64_t pz, int64_t py,
                        int64_t px, int64_t Z, int64_t Y, int64_t X, int iterations, float eps,
                        float* out);
+
+/* Phase cross-correlation of two equally shaped float32 volumes (biahub/estimate_stabilization.py:199-256
+ * phase_cross_corr): corr = irfftn(F1 conj(F2) / norm), norm = 1 | max(|F1 conj F2|, eps) | |F1||F2|.
+ * shift (host, 3 floats) = argmax |corr| folded to the signed range like the reference; corr_shifted (device,
+ * Z*Y*Xc floats with Xc = X - (X & 1), may be NULL) = fftshift(|corr|): the reference inverts without a shape, so
+ * an odd last axis comes back one shorter.  Synchronises (the shift is returned to the host). */
+#define BH_PCC_NORM_NONE 0
+#define BH_PCC_NORM_MAGNITUDE 1
+#define BH_PCC_NORM_CLASSIC 2
+int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t Z, int64_t Y, int64_t X,
+                        int normalization, float shift[3], float* corr_shifted);
 
 /* ---- affine warp ------------------------------------------------------------------- */
 /* out(p) = in(M p), M = 3x4 row-major pull matrix (rows z,y,x; last column translation) in ZYX

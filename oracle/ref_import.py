@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import importlib
 import importlib.metadata
+import importlib.util
 import sys
 import types
 
@@ -38,10 +39,31 @@ _STUBS = [
     "waveorder.cli",
     "ants",
     "largestinteriorrectangle",
+    # only needed by biahub.estimate_stabilization (phase cross-correlation)
+    "dask",
+    "dask.array",
+    "pystackreg",
+    "matplotlib",
+    "matplotlib.pyplot",
+    "skimage",
+    "skimage.transform",
+    "skimage.feature",
+    "skimage.filters",
+    "skimage.measure",
+    "skimage.registration",
+    "sklearn",
+    "sklearn.neighbors",
 ]
 
 
-class _Dummy:
+class _DummyMeta(type):
+    def __getattr__(cls, name):  # `da.Array` in an annotation is a CLASS attribute lookup
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return cls
+
+
+class _Dummy(metaclass=_DummyMeta):
     def __init__(self, *a, **k):
         pass
 
@@ -66,11 +88,18 @@ def load_reference():
     sys.dont_write_bytecode = True
     for name in _STUBS:
         if name not in sys.modules:
+            try:  # never shadow a package that is really installed
+                if importlib.util.find_spec(name.split(".")[0]) is not None:
+                    continue
+            except (ImportError, ValueError):
+                pass
             m = _StubModule(name)
             m.__path__ = []  # behave as a package
             sys.modules[name] = m
-    sys.modules["natsort"].natsorted = sorted
-    sys.modules["tqdm"].tqdm = lambda x, *a, **k: x
+    if isinstance(sys.modules.get("natsort"), _StubModule):
+        sys.modules["natsort"].natsorted = sorted
+    if isinstance(sys.modules.get("tqdm"), _StubModule):
+        sys.modules["tqdm"].tqdm = lambda x, *a, **k: x
 
     real_version = importlib.metadata.version
 

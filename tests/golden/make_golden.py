@@ -16,6 +16,7 @@ Fixtures written:
   average_n_slices.npz    _average_n_slices known answers
   transfer_function.npz   compute_tranfser_function (odd/even psf x odd/even volume)
   transform_scipy.npz     core.transform.Transform.apply (SciPy), orders 0/1
+  phase_cross_corr.npz    estimate_stabilization.phase_cross_corr (three normalisations)
   helpers.json            settings dumps, fingerprints, estimate_resources, output paths,
                           sbatch parsing, matrix builders
 """
@@ -162,6 +163,19 @@ def main():
     tr["points_out"] = t.apply_points(pts)
     tr["shift_int"] = Transform.from_translation([-3.0, 1.0, 4.0]).apply(np.ones((10, 10, 10), np.float32))
     np.savez_compressed(HERE / "transform_scipy.npz", **tr)
+
+    # ---- 6b. phase cross-correlation (estimate_stabilization.py:199-256) ---------------
+    import biahub.estimate_stabilization as ES
+
+    pc = {}
+    for j, (shape, roll) in enumerate([((8, 12, 10), (1, -2, 3)), ((9, 7, 11), (-3, 2, 0)), ((16, 16, 16), (5, 0, -7))]):
+        ref = rng.random(shape, dtype=np.float32)
+        mov = np.roll(ref, roll, axis=(0, 1, 2)) + 0.05 * rng.random(shape, dtype=np.float32)
+        pc[f"ref{j}"], pc[f"mov{j}"] = ref, mov
+        for norm in (None, "magnitude", "classic"):
+            sh, corr = ES.phase_cross_corr(ref, mov, normalization=norm)
+            pc[f"shift{j}_{norm}"], pc[f"corr{j}_{norm}"] = np.asarray(sh), np.asarray(corr)
+    np.savez_compressed(HERE / "phase_cross_corr.npz", **pc)
 
     # ---- 7. settings / helpers ---------------------------------------------------------
     import biahub.register as R

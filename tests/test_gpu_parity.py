@@ -375,3 +375,26 @@ def test_richardson_lucy_properties_large(gpu, monkeypatch):
     monkeypatch.setenv("BH_FFT_BACKEND", "hipfft")                        # the two FFT back-ends agree at full size
     est_ref = richardson_lucy(vol, psf, 5, 1e-6)
     assert float((est - est_ref).abs().max()) <= FFT_TOL * float(est_ref.abs().max())
+
+
+def test_phase_cross_corr_golden_and_oracle(gpu):
+    """estimate_stabilization.phase_cross_corr: shifts exact, correlation volume within FFT tolerance."""
+    from biahub_amd.estimate_stabilization import phase_cross_corr
+
+    z = np.load(GOLDEN / "phase_cross_corr.npz")
+    for j in range(3):
+        for norm in (None, "magnitude", "classic"):
+            sh, corr = phase_cross_corr(z[f"ref{j}"], z[f"mov{j}"], normalization=norm)
+            assert sh.dtype == np.float32 and np.array_equal(sh, z[f"shift{j}_{norm}"]), (j, norm, sh)
+            assert rel_err(corr, z[f"corr{j}_{norm}"]) <= FFT_TOL, (j, norm)
+    rng = np.random.default_rng(1)
+    ref = rng.random((32, 48, 40), dtype=np.float32)
+    for roll in ((0, 0, 0), (15, -23, 19), (-16, 24, -20)):
+        mov = np.roll(ref, roll, axis=(0, 1, 2))
+        want, _ = O.phase_cross_corr(ref, mov, "magnitude")
+        got, corr = phase_cross_corr(ref, mov, normalization="magnitude")
+        assert np.array_equal(got, want) and corr.shape == ref.shape
+    with pytest.raises(ValueError):
+        phase_cross_corr(ref, ref[:-1], normalization=None)
+    with pytest.raises(ValueError):
+        phase_cross_corr(ref, ref, normalization="l2")

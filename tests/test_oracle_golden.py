@@ -123,3 +123,12 @@ def test_crop_flip_oracle():
     out = O.copy_n_paste(f, s)
     assert not np.isnan(out).any()
     assert np.array_equal(O.flip_zyx(a[0], x=True, y=True), a[0][:, ::-1, ::-1])
+
+
+def test_phase_cross_corr_oracle_matches_reference():
+    z = np.load(GOLDEN / "phase_cross_corr.npz")
+    for j in range(3):
+        for norm in (None, "magnitude", "classic"):
+            sh, corr = O.phase_cross_corr(z[f"ref{j}"], z[f"mov{j}"], norm)
+            assert np.array_equal(sh, z[f"shift{j}_{norm}"]), (j, norm)
+            assert rel_err(corr, z[f"corr{j}_{norm}"]) <= 1e-5, (j, norm)
