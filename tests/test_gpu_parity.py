@@ -235,6 +235,30 @@ def test_affine_itk_mode_vs_oracle(gpu, M, interp):
     assert got4.shape == (2,) + out_shape and np.array_equal(got4[0], got)
 
 
+@pytest.mark.parametrize("X", [200, 198])  # 16-B LDS-DMA staging / dword staging (rows not 16-B aligned)
+def test_affine_interior_tiles_nonfinite(gpu, X):
+    """Volume large enough that most tiles take the interior (branch-free) loop; NaN / +-inf taps inside them must
+    come out as np.nan_to_num'd values (register.py:254), whichever tile samples them."""
+    from biahub_amd.register import apply_affine_transform
+
+    rng = np.random.default_rng(21)
+    vol = rng.random((40, 48, X), dtype=np.float32) * 100
+    vol[20, 24, 100] = np.nan
+    vol[21, 30, 64] = np.inf      # on a tile seam in x
+    vol[16, 16, 128] = -np.inf    # on tile seams in z, y and x
+    M = _similarity(2.0, 1.02, (0.5, -1.25, 2.75))
+    for interp in ("linear", "nearestneighbor"):
+        want = O.apply_affine_transform(vol, M, vol.shape, interp)
+        got = apply_affine_transform(vol, M, vol.shape, interpolation=interp)
+        assert np.isfinite(got).all()
+        if interp == "linear":  # per element: the +-FLT_MAX taps would swamp a max-norm error
+            assert np.allclose(got, want, rtol=2e-5, atol=2e-3)
+        else:
+            assert np.array_equal(got, want)
+    u16 = rng.integers(0, 60000, vol.shape).astype(np.uint16)
+    assert rel_err(apply_affine_transform(u16, M, u16.shape), O.apply_affine_transform(u16, M, u16.shape, "linear")) <= 1e-5
+
+
 def test_affine_scipy_mode_golden(gpu):
     from biahub_amd.core.transform import Transform
 
