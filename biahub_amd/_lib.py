@@ -47,6 +47,12 @@ SIGNATURES = {
     "bh_tikhonov": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f64, _vp]),
     "bh_richardson_lucy": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _f32, _vp]),
     "bh_phase_cross_corr": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, C.POINTER(_f32), _vp]),
+    "bh_image_stats": (_int, [_vp, _vp, _i64, _i64, _i64, C.POINTER(_f64)]),
+    "bh_smooth_shrink": (_int, [_vp, _vp, _i64, _i64, _i64, C.POINTER(_f64), C.POINTER(_int), _vp, C.POINTER(_i64),
+                                C.POINTER(_i64)]),
+    "bh_mattes_mi": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, C.POINTER(_f64), C.POINTER(_f64), _int,
+                            _i64, _i64, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64)]),
+    "bh_sobel": (_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "bh_affine": (_int, [_vp, _vp, _int, _i64, _i64, _i64, C.POINTER(_f64), _int, _int, _f32, _vp, _i64, _i64,
                          _i64, C.POINTER(_i64)]),
     "bh_crop_flip": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, C.POINTER(_i64), _i64, _i64, _i64, _int,

@@ -17,10 +17,10 @@ import numpy as np
 
 from . import parallel
 from .io import create_empty_plate, open_ome_zarr, process_single_position
-from .settings import (DeconvolveSettings, DeskewSettings, RegistrationSettings, RichardsonLucySettings,
-                       StabilizationSettings)
+from .settings import (DeconvolveSettings, DeskewSettings, EstimateRegistrationSettings, RegistrationSettings,
+                       RichardsonLucySettings, StabilizationSettings)
 from .utils.cluster import echo_resources, estimate_resources, get_submitit_cluster
-from .utils.config import settings_fingerprint, yaml_to_model
+from .utils.config import model_to_yaml, settings_fingerprint, yaml_to_model
 from .utils.paths import get_output_paths, sbatch_to_submitit
 
 _MULTI = {"-i", "--input-position-dirpaths", "-s", "--source-position-dirpaths", "-t", "--target-position-dirpaths"}
@@ -278,6 +278,58 @@ def register_cli(source_position_dirpaths, target_position_dirpaths, config_file
                                     input_time_indices=tidx, output_time_indices=tidx, czyx_slicing_params=full)
 
     _run_positions("register", source_position_dirpaths, outs, job, Path(output_dirpath).parent)
+
+
+@cli.command("estimate-registration")
+@click.option("--source-position-dirpaths", "-s", multiple=True, required=True, callback=_positions)
+@click.option("--target-position-dirpaths", "-t", multiple=True, required=True, callback=_positions)
+@click.option("--output-filepath", "-o", required=True, type=click.Path(path_type=Path))
+@_config
+@click.option("--sbatch-filepath", "-sb", default=None, type=click.Path(path_type=Path))
+@click.option("--local", "-l", is_flag=True, default=False)
+@click.option("--registration-target-channel", "-rt", default=None, type=str)
+@click.option("--registration-source-channel", "-rs", multiple=True, type=str)
+def estimate_registration_cli(source_position_dirpaths, target_position_dirpaths, output_filepath, config_filepath,
+                              sbatch_filepath, local, registration_target_channel, registration_source_channel):
+    """Estimate the source -> target transform and save it as ``register`` / ``stabilize`` settings
+    (reference: ``biahub estimate-registration``, estimate_registration.py:358-536).  ``estimation_method: ants``
+    runs on the GPU (Mattes-MI similarity estimate); ``manual`` (napari) and ``beads`` are not part of this package."""
+    from .registration.ants import estimate_tczyx
+
+    output_filepath = Path(output_filepath)
+    output_dir = output_filepath.parent
+    output_dir.mkdir(parents=True, exist_ok=True)
+    settings = yaml_to_model(config_filepath, EstimateRegistrationSettings)
+    click.echo(f"Settings: {settings}")
+    if settings.estimation_method != "ants":
+        raise click.UsageError(f"estimation_method {settings.estimation_method!r} is not available in biahub_amd "
+                               "(only 'ants'); use the reference biahub package for 'manual' and 'beads'.")
+    target_channel_name, source_channel_name = settings.target_channel_name, settings.source_channel_name
+    reg_target = registration_target_channel or target_channel_name
+    reg_sources = list(registration_source_channel) or [source_channel_name]
+    click.echo(f"Target channel: {target_channel_name}")
+    click.echo(f"Source channel: {source_channel_name}")
+    with open_ome_zarr(source_position_dirpaths[0]) as src, open_ome_zarr(target_position_dirpaths[0]) as tgt:
+        source_channel_index = src.channel_names.index(source_channel_name)
+        target_channel_index = tgt.channel_names.index(target_channel_name)
+        voxel_size = list(tgt.scale)
+        transforms = estimate_tczyx(
+            mov_tczyx=src.data, ref_tczyx=tgt.data, mov_channel_index=source_channel_index,
+            ref_channel_index=target_channel_index, ants_registration_settings=settings.ants_registration_settings,
+            affine_transform_settings=settings.affine_transform_settings, verbose=settings.verbose,
+            output_folder_path=output_dir, cluster="local", sbatch_filepath=sbatch_filepath)
+    if len(transforms) == 1:
+        model = RegistrationSettings(source_channel_names=reg_sources, target_channel_name=reg_target,
+                                     affine_transform_zyx=transforms[0])
+    else:
+        model = StabilizationSettings(stabilization_estimation_channel=target_channel_name, stabilization_type="affine",
+                                      stabilization_method="ants",
+                                      stabilization_channels=[source_channel_name, target_channel_name],
+                                      affine_transform_zyx_list=transforms, time_indices="all",
+                                      output_voxel_size=voxel_size)
+    if parallel.world_info()[0] == 0:
+        model_to_yaml(model, output_filepath)
+    click.echo(f"Registration settings saved to {output_dir.resolve()}")
 
 
 @cli.command("flip")

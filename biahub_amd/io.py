@@ -100,6 +100,10 @@ class ZarrArray:
             os.replace(tmp, f)
 
     def __getitem__(self, key) -> np.ndarray:
+        if not isinstance(key, tuple):
+            key = (key,)
+        if len(key) == 1:  # arr[t] -> (C, Z, Y, X), like the dask / zarr arrays of the reference
+            return np.stack([self.read_volume(int(key[0]), ci) for ci in range(self.shape[1])])
         t, c = key[0], key[1]
         rest = key[2:] if len(key) > 2 else ()
         if isinstance(c, (list, tuple, np.ndarray)):

@@ -90,6 +90,58 @@ class RegistrationSettings(_Strict):
         return _check_4x4(v, "affine_transform_zyx")
 
 
+class AffineTransformSettings(_Strict):
+    """biahub/settings.py:240-257."""
+
+    t_reference: Literal["first", "previous"] = "first"
+    transform_type: Literal["euclidean", "similarity", "affine"] = "euclidean"
+    approx_transform: list = np.eye(4).tolist()
+    use_prev_t_transform: bool = True
+    compute_approx_transform: bool = False
+
+    @field_validator("approx_transform")
+    @classmethod
+    def _approx(cls, v):
+        if v is not None:
+            if not isinstance(v, list):
+                raise ValueError("approx_transform must be a list")
+            if np.array(v).shape != (4, 4):
+                raise ValueError("approx_transform must be a 4x4 array")
+        return v
+
+
+class AntsRegistrationSettings(_Strict):
+    """biahub/settings.py:260-261 plus the preprocessing switches ``estimate_tczyx`` reads from it
+    (registration/ants.py:505-508: crop, ref_mask_radius, clip)."""
+
+    sobel_filter: bool = False
+    crop: bool = False
+    ref_mask_radius: float | None = None
+    clip: bool = False
+
+
+class EstimateRegistrationSettings(_Strict):
+    """biahub/settings.py:270-292; only ``estimation_method: ants`` runs here (manual needs napari, beads is a CPU
+    point-matching flow: SURVEY.md §8f), the other methods' sub-settings are carried through untouched."""
+
+    target_channel_name: str
+    source_channel_name: str
+    estimation_method: Literal["manual", "beads", "ants"] = "manual"
+    beads_match_settings: dict | None = None
+    focus_finding_settings: dict | None = None
+    affine_transform_settings: AffineTransformSettings = AffineTransformSettings()
+    eval_transform_settings: dict | None = None
+    ants_registration_settings: AntsRegistrationSettings | None = None
+    manual_registration_settings: dict | None = None
+    verbose: bool = False
+
+    @model_validator(mode="after")
+    def _defaults(self):
+        if self.estimation_method == "ants" and self.ants_registration_settings is None:
+            self.ants_registration_settings = AntsRegistrationSettings()
+        return self
+
+
 class DeconvolveSettings(_Strict):
     regularization_strength: PositiveFloat = 0.001
     output_ome_zarr_version: OmeZarrVersion | None = None

@@ -12,6 +12,9 @@
  *   bh_tikhonov            <- biahub/deconvolve.py:46-66 deconvolve (waveorder Tikhonov)
  *   bh_richardson_lucy     <- (north-star extension; no reference function)
  *   bh_phase_cross_corr    <- biahub/estimate_stabilization.py:199-256 phase_cross_corr
+ *   bh_image_stats, bh_smooth_shrink, bh_mattes_mi
+ *                          <- biahub/registration/ants.py:55-122 estimate (the data-parallel pieces of the
+ *                             ants.registration call at :104-109: pyramid, Mattes MI value + derivative)
  *   bh_affine              <- biahub/register.py:202-281 apply_affine_transform,
  *                             biahub/stabilize.py:32-90 apply_stabilization_transform,
  *                             biahub/core/transform.py:374-396 Transform._apply_scipy
@@ -136,6 +139,34 @@ int bh_richardson_lucy(bh_ctx* ctx, const float* in, const float* psf, int64_t p
 #define BH_PCC_NORM_CLASSIC 2
 int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t Z, int64_t Y, int64_t X,
                         int normalization, float shift[3], float* corr_shifted);
+
+/* ---- intensity-registration building blocks (biahub/registration/ants.py:55-122 estimate) ---------- */
+/* The reference delegates to ants.registration(type_of_transform="Similarity", aff_shrink_factors (6,3,1),
+ * aff_smoothing_sigmas (2,1,0), aff_iterations (2100,1200,50)) (:93-98,104-109): ITK's multi-resolution gradient descent
+ * on the Mattes mutual-information metric.  These are its data-parallel pieces; the optimiser itself is host code.
+ *
+ * out[6] (host) = min, max, sum, sum*z, sum*y, sum*x of a float32 volume (Parzen intensity range; centre of mass for
+ * the moments initialisation).  Synchronises. */
+int bh_image_stats(bh_ctx* ctx, const float* in, int64_t Z, int64_t Y, int64_t X, double out[6]);
+
+/* One pyramid level: per axis a separable Gaussian of sigma[a] input voxels (edge-clamped, radius ceil(4 sigma), 0 = none)
+ * sampled at input index factor[a]*i + offset[a], i < out_shape[a] = max(1, N/factor), offset centring the kept samples.
+ * out == NULL only fills out_shape / offset (host-only geometry query). */
+int bh_smooth_shrink(bh_ctx* ctx, const float* in, int64_t Z, int64_t Y, int64_t X, const double sigma[3],
+                     const int factor[3], float* out, int64_t out_shape[3], int64_t offset[3]);
+
+/* Mattes mutual information between fixed(p) and moving(P p) over the fixed voxels offset, offset+stride, ... (raster
+ * order), P = 3x4 row-major pull matrix in index space; trilinear moving interpolation, samples mapped outside
+ * [0, N-1]^3 are dropped.  range = {fixed min, fixed max, moving min, moving max}; `bins` Parzen bins incl. 2 padding bins
+ * per end, box window on fixed, cubic B-spline on moving.  value = MI (to be maximised), grad[12] = dMI/dP, nvalid = samples
+ * used.  Bit-reproducible (integer histogram, fixed-order reductions).  Synchronises. */
+int bh_mattes_mi(bh_ctx* ctx, const float* fixed, int64_t Zf, int64_t Yf, int64_t Xf, const float* moving, int64_t Zm,
+                 int64_t Ym, int64_t Xm, const double P[12], const double range[4], int bins, int64_t stride,
+                 int64_t offset, double* value, double grad[12], double* nvalid);
+
+/* skimage.filters.sobel of a 3-D float32 volume (registration/ants.py:272-275 preprocessing option): gradient magnitude
+ * sqrt((gz^2+gy^2+gx^2)/3) of the [1,0,-1] x [1,2,1]/4 x [1,2,1]/4 stencils, edges reflected.  out must not alias in. */
+int bh_sobel(bh_ctx* ctx, const float* in, int64_t Z, int64_t Y, int64_t X, float* out);
 
 /* ---- affine warp ------------------------------------------------------------------- */
 /* out(p) = in(M p), M = 3x4 row-major pull matrix (rows z,y,x; last column translation) in ZYX

@@ -422,3 +422,73 @@ def test_phase_cross_corr_golden_and_oracle(gpu):
         phase_cross_corr(ref, ref[:-1], normalization=None)
     with pytest.raises(ValueError):
         phase_cross_corr(ref, ref, normalization="l2")
+
+
+# ----------------------------------------------------------------------------- registration estimate (N1)
+def test_registration_kernels_vs_oracle(gpu):
+    """bh_image_stats / bh_smooth_shrink / bh_sobel / bh_mattes_mi against their NumPy restatements."""
+    import torch
+    from biahub_amd.registration import metric as R
+
+    vol = O.synthetic_volume((37, 70, 93), seed=11, n_blobs=120)
+    t = torch.from_numpy(vol).to(gpu)
+    st, want = R.image_stats(t), O.image_stats(vol)
+    assert st["min"] == want[0] and st["max"] == want[1]
+    assert abs(st["sum"] - want[2]) <= 1e-9 * want[2]
+    assert np.allclose(st["center_of_mass"], want[3:6] / want[2], rtol=1e-9)
+
+    for sigma, factor in (((2, 2, 2), (6, 6, 6)), ((1, 1, 1), (3, 3, 3)), ((0, 1.5, 0.5), (1, 2, 5)), ((0, 0, 0), (1, 1, 1))):
+        got, off = R.smooth_shrink(t, sigma, factor)
+        w, woff = O.smooth_shrink(vol, sigma, factor)
+        assert tuple(got.shape) == w.shape and off == woff
+        assert R.smooth_shrink_geometry(vol.shape, factor) == (w.shape, woff)
+        assert rel_err(got.cpu().numpy(), w) <= 1e-6
+    assert rel_err(R.sobel(t).cpu().numpy(), O.sobel(vol)) <= 1e-6
+
+    M = _similarity(3.0, 1.03, (0.4, 1.5, -1.2))
+    mov = O.affine_pull(vol, M, vol.shape, 1, O.BOUNDARY_ITK)
+    fx, mv = torch.from_numpy(mov).to(gpu), t
+    rng_ = (float(mov.min()), float(mov.max()), float(vol.min()), float(vol.max()))
+    for P, stride, offset in ((np.eye(4)[:3], 1, 0), (M[:3], 5, 0), (_similarity(-8.0, 0.9, (3, 4, -6))[:3], 3, 2)):
+        v, g, n = R.mattes_mi(fx, mv, P, rng_, bins=32, stride=stride, offset=offset)
+        wv, wg, wn = O.mattes_mi(mov, vol, P, rng_, 32, stride, offset)
+        assert n == wn                                          # same samples inside the moving volume
+        assert abs(v - wv) <= 2e-5 * max(1.0, abs(wv))          # 2^-20 fixed-point histogram, f32 interpolation
+        assert np.abs(g - wg).max() <= 2e-3 * np.abs(wg).max()
+        v2, g2, n2 = R.mattes_mi(fx, mv, P, rng_, bins=32, stride=stride, offset=offset)
+        assert v2 == v and n2 == n and np.array_equal(g2, g)    # bit-reproducible
+    with pytest.raises(ValueError):
+        R.mattes_mi(fx, mv, np.eye(4)[:3], (1.0, 1.0, 0.0, 1.0))  # empty intensity range
+    with pytest.raises(ValueError):
+        R.mattes_mi(fx, mv, np.eye(4)[:3], rng_, bins=5)
+
+
+def test_estimate_registration_recovers_similarity(gpu):
+    """BASELINE config 3 in miniature: arm B = arm A warped by a known similarity; the estimate must find it."""
+    from biahub_amd.register import apply_affine_transform
+    from biahub_amd.registration.ants import estimate, estimate_czyx
+
+    shape = (48, 160, 160)
+    arm_a = O.synthetic_volume(shape, seed=21, n_blobs=400)
+    M = _similarity(2.0, 1.02, (0.9, -3.25, 5.75))
+    arm_b = apply_affine_transform(arm_a, M, shape)          # arm_b(p) = arm_a(M p)
+    arm_b = np.where(arm_b == 0, 110.0, arm_b).astype(np.float32)  # camera offset outside the overlap
+    fwd, inv = estimate(ref=arm_b, mov=arm_a)
+    T = fwd.matrix
+    centre = np.append((np.array(shape) - 1) / 2, 1)
+    assert np.abs(T[:3, :3] - M[:3, :3]).max() < 2e-3
+    assert np.linalg.norm((T @ centre - M @ centre)[:3]) < 0.1
+    assert np.allclose(inv.matrix @ T, np.eye(4), atol=1e-9)
+    # registering with the estimate reproduces arm B (up to interpolation) inside the overlap
+    rereg = apply_affine_transform(arm_a, T, shape)
+    core = (slice(8, 40), slice(20, 140), slice(20, 140))
+    assert np.abs(rereg[core] - arm_b[core]).mean() < 0.02 * arm_b[core].mean()
+    # estimate_czyx: start from a rough initial guess and let the estimate correct it (registration/ants.py:281-366)
+    init = _similarity(1.5, 1.0, (0.0, -2.0, 4.0))
+    composed = estimate_czyx(arm_a[None], arm_b[None], init, crop=True)
+    assert np.abs(composed.matrix[:3, :3] - M[:3, :3]).max() < 3e-3
+    assert np.linalg.norm((composed.matrix @ centre - M @ centre)[:3]) < 0.15
+    with pytest.raises(ValueError, match="Dimension mismatch"):
+        estimate(ref=arm_b, mov=arm_a[0])
+    with pytest.raises(ValueError, match="NaN or zeros"):
+        estimate_czyx(np.zeros((1,) + shape, np.float32), arm_b[None], init)

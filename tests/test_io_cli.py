@@ -84,7 +84,7 @@ def test_cli_help_and_eat_all():
     assert expand_eat_all(["deskew", "-i", "a", "b", "c", "-c", "x.yml", "-o", "o"]) == \
         ["deskew", "-i", "a", "-i", "b", "-i", "c", "-c", "x.yml", "-o", "o"]
     r = CliRunner()
-    for cmd in ("deskew", "deconvolve", "rl-deconvolve", "register", "stabilize", "flip"):
+    for cmd in ("deskew", "deconvolve", "rl-deconvolve", "register", "stabilize", "flip", "estimate-registration"):
         res = r.invoke(cli, [cmd, "--help"])
         assert res.exit_code == 0 and "Usage" in res.output
 
@@ -172,3 +172,66 @@ def test_cli_steps_end_to_end(gpu, tmp_path):
     res = r.invoke(cli, ["flip", "-i", str(src / "A/1/0"), "-x", "-y"])
     assert res.exit_code == 0, res.output
     assert np.array_equal(io.open_ome_zarr(src / "A/1/0").data[1, 0], data[("A", "1", "0", 1, 0)][:, ::-1, ::-1])
+
+
+def test_estimate_registration_settings(tmp_path):
+    from biahub_amd.settings import AffineTransformSettings, EstimateRegistrationSettings
+
+    s = EstimateRegistrationSettings(target_channel_name="Phase3D", source_channel_name="GFP", estimation_method="ants")
+    assert s.ants_registration_settings.sobel_filter is False and s.affine_transform_settings.transform_type == "euclidean"
+    assert np.array_equal(s.affine_transform_settings.approx_transform, np.eye(4))
+    with pytest.raises(ValueError, match="4x4"):
+        AffineTransformSettings(approx_transform=[[1, 0], [0, 1]])
+    with pytest.raises(ValueError):
+        EstimateRegistrationSettings(target_channel_name="a", source_channel_name="b", estimation_method="icp")
+    # methods that need napari / bead matching are refused by the CLI with a pointer to the reference package
+    cfg = tmp_path / "e.yml"
+    cfg.write_text("target_channel_name: ch0\nsource_channel_name: ch0\nestimation_method: manual\n")
+    src = tmp_path / "in.zarr"
+    make_plate(src, positions=(("A", "1", "0"),), shape=(1, 1, 4, 8, 8))
+    res = CliRunner().invoke(cli, ["estimate-registration", "-s", str(src / "A/1/0"), "-t", str(src / "A/1/0"), "-o",
+                                   str(tmp_path / "out.yml"), "-c", str(cfg)])
+    assert res.exit_code != 0 and "not available" in res.output
+
+
+@pytest.mark.gpu
+def test_cli_estimate_registration_then_register(gpu, tmp_path):
+    """BASELINE config 3 in miniature: estimate-registration writes register settings that undo a known warp."""
+    import yaml
+    from biahub_amd.register import apply_affine_transform
+
+    shape = (40, 128, 128)
+    arm_a = O.synthetic_volume(shape, seed=33, n_blobs=300)
+    th = np.deg2rad(2.0)
+    M = np.array([[1.02, 0, 0, 0.6], [0, 1.02 * np.cos(th), -1.02 * np.sin(th), -2.25],
+                  [0, 1.02 * np.sin(th), 1.02 * np.cos(th), 4.75], [0, 0, 0, 1.0]])
+    arm_b = apply_affine_transform(arm_a, M, shape)
+    arm_b = np.where(arm_b == 0, 110.0, arm_b).astype(np.float32)
+    for name, vol, ch in (("a.zarr", arm_a, "GFP"), ("b.zarr", arm_b, "Phase3D")):
+        io.create_empty_plate(tmp_path / name, [("A", "1", "0")], [ch], (1, 1) + shape, scale=(1, 1, 0.2, 0.1, 0.1))
+        io.open_ome_zarr(tmp_path / name / "A/1/0").data[0, 0] = vol
+    cfg = tmp_path / "est.yml"
+    cfg.write_text("target_channel_name: Phase3D\nsource_channel_name: GFP\nestimation_method: ants\n"
+                   "affine_transform_settings:\n  transform_type: similarity\n")
+    out_yml = tmp_path / "est" / "registration.yml"
+    r = CliRunner()
+    res = r.invoke(cli, ["estimate-registration", "-s", str(tmp_path / "a.zarr/A/1/0"), "-t", str(tmp_path / "b.zarr/A/1/0"),
+                         "-o", str(out_yml), "-c", str(cfg), "--local"])
+    assert res.exit_code == 0, res.output
+    est = yaml.safe_load(out_yml.read_text())
+    assert est["source_channel_names"] == ["GFP"] and est["target_channel_name"] == "Phase3D"
+    T = np.array(est["affine_transform_zyx"])
+    assert np.abs(T[:3, :3] - M[:3, :3]).max() < 2e-3
+    centre = np.append((np.array(shape) - 1) / 2, 1)
+    assert np.linalg.norm((T @ centre - M @ centre)[:3]) < 0.1
+    assert np.allclose(np.load(out_yml.parent / "xyz_transforms" / "0.npy"), T)
+    # the written settings feed `register` unchanged
+    est["keep_overhang"] = True
+    out_yml.write_text(yaml.safe_dump(est))
+    reg = tmp_path / "reg.zarr"
+    res = r.invoke(cli, ["register", "-s", str(tmp_path / "a.zarr/A/1/0"), "-t", str(tmp_path / "b.zarr/A/1/0"), "-c",
+                         str(out_yml), "-o", str(reg), "--local"])
+    assert res.exit_code == 0, res.output
+    got = io.open_ome_zarr(reg / "A/1/0").data[0, 0]
+    core = (slice(8, 32), slice(16, 112), slice(16, 112))
+    assert np.abs(got[core] - arm_b[core]).mean() < 0.02 * arm_b[core].mean()

@@ -1,0 +1,82 @@
+"""BASELINE config 3 rehearsal: estimate-registration + register on two-arm (256,1024,1024) synthetic volumes.
+
+Arm B = arm A pulled by a known similarity (2 deg about Z, 1.02x, translation (3.5,-12.25,20.75)); the estimate must
+recover it.  Prints wall times (device-resident inputs) and the matrix error.
+"""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np, torch
+from bench import synthetic_position
+from biahub_amd.register import affine_device, find_lir
+from biahub_amd.registration import metric as R
+from biahub_amd.registration.ants import estimate, postprocess_transform
+
+dev = torch.device("cuda", 0)
+shape = tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 1024, 1024)
+th = np.deg2rad(2.0)
+M = np.array([[1.02, 0, 0, 3.5], [0, 1.02 * np.cos(th), -1.02 * np.sin(th), -12.25],
+              [0, 1.02 * np.sin(th), 1.02 * np.cos(th), 20.75], [0, 0, 0, 1.0]])
+def beads_volume(shape, n_blobs, seed):
+    """Gaussian blobs sigma in [1.5, 4] voxels, amplitude U(200, 4000), offset 110, noise; on device."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    vol = torch.empty(shape, dtype=torch.float32, device=dev).normal_(110.0, 4.0, generator=g)
+    cz = torch.rand(n_blobs, generator=g, device=dev) * shape[0]
+    cy = torch.rand(n_blobs, generator=g, device=dev) * shape[1]
+    cx = torch.rand(n_blobs, generator=g, device=dev) * shape[2]
+    sg = torch.rand(n_blobs, generator=g, device=dev) * 2.5 + 1.5
+    amp = torch.rand(n_blobs, generator=g, device=dev) * 3800 + 200
+    r = 12
+    off = torch.arange(-r, r + 1, device=dev)
+    dz, dy, dx = torch.meshgrid(off, off, off, indexing="ij")
+    for i0 in range(0, n_blobs, 256):  # 256 blobs x 25^3 patch voxels per scatter
+        sl = slice(i0, min(i0 + 256, n_blobs))
+        z0, y0, x0 = cz[sl].floor().long(), cy[sl].floor().long(), cx[sl].floor().long()
+        zz, yy, xx = z0[:, None, None, None] + dz, y0[:, None, None, None] + dy, x0[:, None, None, None] + dx
+        d2 = (zz - cz[sl, None, None, None]) ** 2 + (yy - cy[sl, None, None, None]) ** 2 + (xx - cx[sl, None, None, None]) ** 2
+        val = amp[sl, None, None, None] * torch.exp(-0.5 * d2 / sg[sl, None, None, None] ** 2)
+        ok = (zz >= 0) & (zz < shape[0]) & (yy >= 0) & (yy < shape[1]) & (xx >= 0) & (xx < shape[2])
+        vol.index_put_((zz[ok], yy[ok], xx[ok]), val[ok], accumulate=True)
+    return vol.round_().clamp_(0, 65535)
+
+
+arm_a = beads_volume(shape, max(64, int(np.prod(shape)) // 65536), 0xB1A0)   # 4096 blobs at (256,1024,1024)
+arm_b = affine_device(arm_a, M, shape)
+arm_b = torch.where(arm_b == 0, torch.full_like(arm_b, 110.0), arm_b)
+# estimate_czyx's flow (registration/ants.py:281-366) on device tensors: rough initial guess -> pre-warp -> estimate
+th0 = np.deg2rad(1.5)
+centre = np.append((np.array(shape) - 1) / 2, 1)
+init = np.eye(4)
+init[1:3, 1:3] = [[np.cos(th0), -np.sin(th0)], [np.sin(th0), np.cos(th0)]]        # 1.5 deg, scale 1.0 (truth: 2 deg, 1.02)
+init[:3, 3] = (M @ centre)[:3] - init[:3, :3] @ centre[:3] + np.array([1.0, 3.0, -2.5])  # a few voxels off at the centre
+rng0 = (float(arm_b.min()), float(arm_b.max()), float(arm_a.min()), float(arm_a.max()))
+print("arm A min/max/frac>150:", rng0[2], rng0[3], float((arm_a > 150).float().mean()), " arm B min/max:", rng0[:2])
+print("MI at truth / at the initial guess / at identity (full res, stride 5):",
+      [round(R.mattes_mi(arm_b, arm_a, P[:3], rng0, stride=5)[0], 5) for P in (M, init, np.eye(4))])
+print(f"initial guess: centre error {np.linalg.norm((init @ centre - M @ centre)[:3]):.2f} voxels")
+torch.cuda.synchronize()
+for _ in range(2):
+    t0 = time.perf_counter()
+    pre = affine_device(arm_a, init, shape)
+    zs, ys, xs = find_lir((pre != 0).cpu().numpy().astype(np.uint8))          # crop=True of preprocess_czyx
+    t1 = time.perf_counter()
+    fwd, inv = estimate(ref=arm_b[zs, ys, xs].contiguous(), mov=pre[zs, ys, xs].contiguous(), verbose="-v" in sys.argv)
+    torch.cuda.synchronize()
+    dt, dt_est = time.perf_counter() - t0, time.perf_counter() - t1
+off = np.array([zs.start, ys.start, xs.start], dtype=np.float64)
+fwd = postprocess_transform(type(fwd)(init), fwd, off)
+print(f"crop {zs}, {ys}, {xs}; estimate alone {dt_est:.3f} s")
+T = fwd.matrix
+print(f"estimate {shape}: {dt:.3f} s   |dA|max {np.abs(T[:3,:3]-M[:3,:3]).max():.2e}   "
+      f"centre error {np.linalg.norm((T @ centre - M @ centre)[:3]):.3f} voxels")
+# one full-resolution metric evaluation (the per-iteration unit of the last level)
+rng = (float(arm_b.min()), float(arm_b.max()), float(arm_a.min()), float(arm_a.max()))
+for _ in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    v, g, n = R.mattes_mi(arm_b, arm_a, T[:3], rng, stride=5)
+    dt = time.perf_counter() - t0
+V = np.prod(shape)
+print(f"mattes_mi full res: {dt*1e3:.2f} ms for {n} samples (MI {v:.4f})")
+t0 = time.perf_counter()
+out = affine_device(arm_a, T, shape); torch.cuda.synchronize()
+print(f"register warp: {(time.perf_counter()-t0)*1e3:.2f} ms")
