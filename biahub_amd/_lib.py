@@ -20,7 +20,7 @@ FILL_NONE, FILL_CONSTANT, FILL_MEAN = 0, 1, 2
 INTERP_NEAREST, INTERP_LINEAR = 0, 1
 BOUNDARY_ITK, BOUNDARY_SCIPY_CONSTANT, BOUNDARY_ZEROS = 0, 1, 2
 PCC_NORM = {None: 0, "magnitude": 1, "classic": 2}
-(T_DESKEW, T_FILL, T_RL_TOTAL, T_TIKHONOV, T_AFFINE, T_CROPFLIP, T_RL_ITER, T_TF) = range(8)
+(T_DESKEW, T_FILL, T_RL_TOTAL, T_TIKHONOV, T_AFFINE, T_CROPFLIP, T_RL_ITER, T_TF, T_FLATFIELD) = range(9)
 
 _i64, _f64, _f32, _int, _vp = C.c_int64, C.c_double, C.c_float, C.c_int, C.c_void_p
 
@@ -39,6 +39,8 @@ SIGNATURES = {
     "bh_free": (_int, [_vp]),
     "bh_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_uint64]),
     "bh_memcpy_d2h": (_int, [_vp, _vp, _vp, C.c_uint64]),
+    "bh_median_z": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp]),
+    "bh_flat_field": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, C.POINTER(_f64)]),
     "bh_deskew_shape": (_int, [_i64, _i64, _i64, _f64, _f64, _int, _int, _f64, C.POINTER(_i64), C.POINTER(_f64)]),
     "bh_deskew": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _f64, _f64, _int, _int, _int, _f32, _vp,
                          C.POINTER(_f32)]),

@@ -17,8 +17,8 @@ import numpy as np
 
 from . import parallel
 from .io import create_empty_plate, open_ome_zarr, process_single_position
-from .settings import (DeconvolveSettings, DeskewSettings, EstimateRegistrationSettings, RegistrationSettings,
-                       RichardsonLucySettings, StabilizationSettings)
+from .settings import (DeconvolveSettings, DeskewSettings, EstimateRegistrationSettings, FlatFieldCorrectionSettings,
+                       RegistrationSettings, RichardsonLucySettings, StabilizationSettings)
 from .utils.cluster import echo_resources, estimate_resources, get_submitit_cluster
 from .utils.config import model_to_yaml, settings_fingerprint, yaml_to_model
 from .utils.paths import get_output_paths, sbatch_to_submitit
@@ -141,6 +141,55 @@ def deskew_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor
     _run_positions("deskew", input_position_dirpaths, outs,
                    lambda s, d: process_single_position(_fast_deskew_czyx, s, d, resume=resume,
                                                         resume_token=settings_fingerprint(settings), **kw),
+                   Path(output_dirpath).parent)
+
+
+@cli.command("flat-field")
+@_common
+@_config
+@click.option("--cluster", type=click.Choice(["slurm", "local", "debug"], case_sensitive=False), default="debug",
+              show_default=True)
+@click.option("--init", "init_only", is_flag=True, default=False, help="Only initialize the output store and exit.")
+@click.option("--resume/--no-resume", "resume", default=False, show_default=True)
+def flat_field_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor, config_filepath, cluster, init_only,
+                   resume):
+    """Flat-field correct the selected channels of every (t) volume (reference: ``biahub flat-field``,
+    flat_field.py:213-392); the other channels are copied as float32."""
+    from .flat_field import _flat_field_czyx
+
+    settings = yaml_to_model(config_filepath, FlatFieldCorrectionSettings)
+    with open_ome_zarr(input_position_dirpaths[0]) as ds:
+        names, shape = ds.channel_names, ds.data.shape
+    _same_shape_plate(input_position_dirpaths, output_dirpath, settings.output_ome_zarr_version)
+    minutes, cpus, gb = estimate_resources(shape, ram_multiplier=8, time_multiplier=0.7, max_num_cpus=16)
+    echo_resources(cpus, cpus * gb, minutes)
+    if init_only:
+        click.echo(f"Initialized {output_dirpath} ({len(input_position_dirpaths)} positions)")
+        return
+    if settings.channel_names is None:
+        target = list(names)
+        click.echo(f"Flat fielding ALL channels: {names}")
+    elif settings.channel_names:
+        for n in settings.channel_names:
+            if n not in names:
+                raise click.ClickException(f"Channel '{n}' not found in input dataset. Available channels: {names}")
+        target = list(settings.channel_names)
+        click.echo(f"Input channels: {names}")
+        click.echo(f"Flat field channels: {target}")
+        click.echo("Other channels will be copied as-is")
+    else:
+        raise click.ClickException("Must specify either 'channel_names' or set channel_names to null in config.")
+    if sbatch_filepath:
+        sbatch_to_submitit(sbatch_filepath)
+    _resolve_cluster(cluster)
+    allc = [list(range(shape[1]))]  # _flat_field_czyx sees every channel of a timepoint at once (:144-155)
+    outs = get_output_paths(input_position_dirpaths, output_dirpath)
+    _run_positions("flat-field", input_position_dirpaths, outs,
+                   lambda s, d: process_single_position(_flat_field_czyx, s, d, input_channel_indices=allc,
+                                                        output_channel_indices=allc, resume=resume,
+                                                        resume_token=settings_fingerprint(settings),
+                                                        target_indices=[names.index(n) for n in target],
+                                                        extra_metadata={"biahub-flat_field": settings.model_dump()}),
                    Path(output_dirpath).parent)
 
 

@@ -52,7 +52,7 @@ void set_error(const char* fmt, ...);
         if (_s != BH_OK) return _s;  \
     } while (0)
 
-enum TimerSlot { T_DESKEW = 0, T_FILL, T_RL_TOTAL, T_TIKHONOV, T_AFFINE, T_CROPFLIP, T_RL_ITER, T_TF, T_COUNT };
+enum TimerSlot { T_DESKEW = 0, T_FILL, T_RL_TOTAL, T_TIKHONOV, T_AFFINE, T_CROPFLIP, T_RL_ITER, T_TF, T_FLATFIELD, T_COUNT };
 
 struct FftPlans {
     hipfftHandle r2c = 0;

@@ -1,0 +1,266 @@
+// Flat-field correction on gfx950: exact per-pixel median along Z, then divide the static pattern out.
+//
+//   flat_field_zyx(zyx) = zyx / median(zyx, axis=0) * mean(median(zyx, axis=0))      (biahub/flat_field.py:101-120)
+//
+// The reference's cost is the median: np.median partitions along an axis whose stride is a whole plane, 5-130 CPU-seconds
+// per position depending on the host (flat_field.py:56-99 tiles it to stay in cache).  Here a workgroup stages all Z
+// samples of 64 neighbouring pixels in LDS (one coalesced read of the volume) and every lane finds its own column's order
+// statistic by a most-significant-bit-first search on order-preserving integer keys: 16 counting sweeps over LDS for
+// uint16 camera data, 32 for float32 — no sorting, no data-dependent branches, and the result is the exact element
+// np.median picks (for an even count the mean of the two middle elements, computed in the reference's type).
+// The apply pass re-reads the volume once: out = float32(double(v) / pattern * mean) for integer input (the reference's
+// float64 expression, cast by _flat_field_czyx :154), float32 arithmetic for float32 input.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace bh {
+
+
+template <typename T>
+struct FfKey;
+template <>
+struct FfKey<uint8_t> {
+    using key_t = uint16_t;
+    static constexpr int bits = 8;
+    static __device__ key_t to(uint8_t v) { return v; }
+    static __device__ double from(unsigned k) { return (double)k; }
+};
+template <>
+struct FfKey<uint16_t> {
+    using key_t = uint16_t;
+    static constexpr int bits = 16;
+    static __device__ key_t to(uint16_t v) { return v; }
+    static __device__ double from(unsigned k) { return (double)k; }
+};
+template <>
+struct FfKey<int16_t> {
+    using key_t = uint16_t;
+    static constexpr int bits = 16;
+    static __device__ key_t to(int16_t v) { return (uint16_t)((uint16_t)v ^ 0x8000u); }
+    static __device__ double from(unsigned k) { return (double)(int16_t)(uint16_t)(k ^ 0x8000u); }
+};
+template <>
+struct FfKey<float> {
+    using key_t = uint32_t;
+    static constexpr int bits = 32;
+    static __device__ key_t to(float v) {
+        const uint32_t b = __float_as_uint(v);
+        return (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // total order of finite floats (-0 < +0)
+    }
+    static __device__ double from(unsigned k) {
+        const uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+        return (double)__uint_as_float(b);
+    }
+};
+
+// One workgroup = `cols` neighbouring pixels of one image row, all Z samples in LDS as keys[z][cols]; thread t owns column
+// t % cols and the z-subset {g, g + groups, ...}, g = t / cols; per search step the groups' counts meet in LDS.
+template <typename TIN, int FF_NT>
+__global__ __launch_bounds__(FF_NT) void median_z_kernel(const TIN* __restrict__ in, int Z, int Y, int X, int cols,
+                                                         int tiles_x, double* __restrict__ pattern) {
+    using K = FfKey<TIN>;
+    using key_t = typename K::key_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    key_t* keys = reinterpret_cast<key_t*>(smem);
+    unsigned* part = reinterpret_cast<unsigned*>(smem + (((size_t)Z * cols * sizeof(key_t) + 15) & ~(size_t)15));  // [2][FF_NT]
+    const int groups = FF_NT / cols, col = threadIdx.x % cols, grp = threadIdx.x / cols;
+    const size_t plane = (size_t)Y * X;
+    for (int tile = blockIdx.x; tile < tiles_x * Y; tile += gridDim.x) {
+        const int y = tile / tiles_x, x0 = (tile - y * tiles_x) * cols;
+        __syncthreads();  // the previous tile's readers are done
+        const TIN* src = in + (size_t)y * X + min(x0 + col, X - 1);
+        const int nz = (Z - grp + groups - 1) / groups;  // this thread's samples: z = grp + j * groups
+        const int zs = groups * cols;                    // their distance in the LDS image
+#pragma unroll 8
+        for (int j = 0; j < nz; ++j) keys[(grp + j * groups) * cols + col] = K::to(src[(size_t)(grp + j * groups) * plane]);
+        __syncthreads();
+        const key_t* mine = keys + grp * cols + col;
+        const int k = (Z - 1) >> 1;  // lower middle element (0-based)
+        unsigned res = 0;
+        int buf = 0;
+        auto total = [&](unsigned mine) -> unsigned {  // sum over the groups of this column
+            unsigned* p = part + buf * FF_NT;
+            p[threadIdx.x] = mine;
+            __syncthreads();
+            unsigned s = 0;
+            for (int g = 0; g < groups; ++g) s += p[g * cols + col];
+            buf ^= 1;  // the other buffer is only rewritten after the next barrier
+            return s;
+        };
+        for (int bit = K::bits - 1; bit >= 0; --bit) {
+            const unsigned cand = res | (1u << bit);
+            unsigned c = 0;
+#pragma unroll 8
+            for (int j = 0; j < nz; ++j) c += (unsigned)(mine[j * zs] < cand);
+            if (total(c) <= (unsigned)k) res = cand;  // largest r with #(key < r) <= k is the k-th smallest key
+        }
+        unsigned hi = res;
+        if ((Z & 1) == 0) {  // even count: the upper middle element is res again, or the smallest key above it
+            unsigned cle = 0, mn = 0xffffffffu;
+#pragma unroll 8
+            for (int j = 0; j < nz; ++j) {
+                const unsigned v = mine[j * zs];
+                cle += (unsigned)(v <= res);
+                mn = v > res ? min(mn, v) : mn;
+            }
+            const unsigned tle = total(cle);
+            unsigned* p = part + buf * FF_NT;
+            p[threadIdx.x] = mn;
+            __syncthreads();
+            for (int g = 0; g < groups; ++g) mn = min(mn, p[g * cols + col]);
+            buf ^= 1;
+            hi = tle > (unsigned)(k + 1) ? res : mn;
+        }
+        if (grp == 0 && x0 + col < X) {
+            double m;
+            if (sizeof(TIN) == 4)
+                m = (double)(((float)K::from(res) + (float)K::from(hi)) * 0.5f);  // np.median of float32 stays float32
+            else
+                m = (K::from(res) + K::from(hi)) * 0.5;
+            pattern[(size_t)y * X + x0 + col] = (Z & 1) ? K::from(res) : m;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ff_sum_partial_kernel(const double* __restrict__ v, long long n,
+                                                             double* __restrict__ part) {
+    double a = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) a += v[i];
+    __shared__ double red[256];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void ff_sum_final_kernel(const double* __restrict__ part, int n, double inv_count,
+                                                           double* __restrict__ out) {
+    __shared__ double red[256];
+    double a = 0;
+    for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] * inv_count;
+}
+
+// one thread per pixel, walking Z: the pattern value is read once, every access is coalesced along x
+template <typename TIN>
+__global__ __launch_bounds__(256) void flat_apply_kernel(const TIN* __restrict__ in, const double* __restrict__ pattern,
+                                                         const double* __restrict__ mean, long long plane, int Z, int zchunk,
+                                                         float* __restrict__ out) {
+    const double m = mean[0];
+    const float mf = (float)m;
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= plane) return;
+    const double pat = pattern[p];
+    const float patf = (float)pat;
+    const int z0 = blockIdx.y * zchunk, z1 = min(Z, z0 + zchunk);
+    const TIN* src = in + (size_t)z0 * plane + p;
+    float* dst = out + (size_t)z0 * plane + p;
+#pragma unroll 4
+    for (int z = z0; z < z1; ++z, src += plane, dst += plane) {
+        if (sizeof(TIN) == 4)
+            *dst = ((float)*src / patf) * mf;          // float32 / float32 * float32, as numpy evaluates it
+        else
+            *dst = (float)((double)*src / pat * m);    // integer / float64 * float64, cast by the CZYX adapter
+    }
+}
+
+template <typename TIN, int FF_NT>
+static int run_median(bh_ctx* ctx, const TIN* in, int64_t Z, int64_t Y, int64_t X, double* pattern) {
+    using key_t = typename FfKey<TIN>::key_t;
+    const size_t budget = 144 * 1024;  // of the CU's 160 KiB
+    int cols = 64;
+    while (cols > 4 && (size_t)Z * cols * sizeof(key_t) > budget) cols >>= 1;
+    if ((size_t)Z * cols * sizeof(key_t) > budget) {
+        set_error("flat-field median: Z = %lld does not fit the LDS staging (max %zu samples per pixel)", (long long)Z,
+                  budget / (4 * sizeof(key_t)));
+        return BH_ERR_UNSUPPORTED;
+    }
+    const size_t lds = (((size_t)Z * cols * sizeof(key_t) + 15) & ~(size_t)15) + 2 * FF_NT * sizeof(unsigned);
+    const int tiles_x = (int)ceil_div(X, cols);
+    const int64_t tiles = (int64_t)tiles_x * Y;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 256)));
+    const int grid = (int)std::min<int64_t>(tiles, (int64_t)ctx->num_cus * per_cu);
+    auto kern = median_z_kernel<TIN, FF_NT>;
+    BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(FF_NT), lds, ctx->stream, in, (int)Z, (int)Y, (int)X, cols, tiles_x, pattern);
+    BH_CHECK_HIP(hipGetLastError());
+    return BH_OK;
+}
+
+template <int NT>
+static int dispatch_median_nt(bh_ctx* ctx, const void* in, int dtype, int64_t Z, int64_t Y, int64_t X, double* pattern) {
+    switch (dtype) {
+        case BH_DT_U8: return run_median<uint8_t, NT>(ctx, (const uint8_t*)in, Z, Y, X, pattern);
+        case BH_DT_U16: return run_median<uint16_t, NT>(ctx, (const uint16_t*)in, Z, Y, X, pattern);
+        case BH_DT_I16: return run_median<int16_t, NT>(ctx, (const int16_t*)in, Z, Y, X, pattern);
+        case BH_DT_F32: return run_median<float, NT>(ctx, (const float*)in, Z, Y, X, pattern);
+        default: BH_REQUIRE(false, "unsupported input dtype code %d", dtype);
+    }
+    return BH_OK;
+}
+
+static int dispatch_median(bh_ctx* ctx, const void* in, int dtype, int64_t Z, int64_t Y, int64_t X, double* pattern) {
+    // measured (tools/time_ops.py flatfield): 32-bit keys want 16 waves per workgroup, 16-bit keys 8
+    static const int forced = getenv("BH_FF_NT") ? atoi(getenv("BH_FF_NT")) : 0;
+    const int nt = forced ? forced : (dtype == BH_DT_F32 ? 1024 : 512);
+    if (nt == 1024) return dispatch_median_nt<1024>(ctx, in, dtype, Z, Y, X, pattern);
+    if (nt == 512) return dispatch_median_nt<512>(ctx, in, dtype, Z, Y, X, pattern);
+    return dispatch_median_nt<256>(ctx, in, dtype, Z, Y, X, pattern);
+}
+
+}  // namespace bh
+
+using namespace bh;
+
+extern "C" int bh_median_z(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, int64_t X, double* pattern) {
+    BH_REQUIRE(ctx && in && pattern, "null argument");
+    BH_REQUIRE(Z > 0 && Y > 0 && X > 0 && Z < (1ll << 24) && Y < (1ll << 31) && X < (1ll << 31), "bad shape");
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    return dispatch_median(ctx, in, in_dtype, Z, Y, X, pattern);
+}
+
+extern "C" int bh_flat_field(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, int64_t X, float* out,
+                             double* pattern, double* mean_out) {
+    BH_REQUIRE(ctx && in && out, "null argument");
+    BH_REQUIRE(Z > 0 && Y > 0 && X > 0 && Z < (1ll << 24) && Y < (1ll << 31) && X < (1ll << 31), "bad shape");
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    const int64_t plane = Y * X;
+    double* pat = pattern;
+    if (!pat) BH_TRY(get_scratch(ctx, "ff_pattern", sizeof(double) * (size_t)plane, (void**)&pat));
+    double* red;
+    const int nblk = (int)std::min<int64_t>(ceil_div(plane, 256), 1024);
+    BH_TRY(get_scratch(ctx, "ff_reduce", sizeof(double) * (size_t)(nblk + 2), (void**)&red));
+    ScopedTimer timer(ctx, T_FLATFIELD);
+    BH_TRY(dispatch_median(ctx, in, in_dtype, Z, Y, X, pat));
+    hipLaunchKernelGGL(ff_sum_partial_kernel, dim3(nblk), dim3(256), 0, ctx->stream, pat, (long long)plane, red);
+    hipLaunchKernelGGL(ff_sum_final_kernel, dim3(1), dim3(256), 0, ctx->stream, red, nblk, 1.0 / (double)plane, red + nblk);
+    const int zchunk = 32;
+    const dim3 grid((unsigned)ceil_div(plane, 256), (unsigned)ceil_div(Z, zchunk));
+#define BH_FF_APPLY(T) \
+    hipLaunchKernelGGL(flat_apply_kernel<T>, grid, dim3(256), 0, ctx->stream, (const T*)in, pat, red + nblk, (long long)plane, (int)Z, zchunk, out)
+    switch (in_dtype) {
+        case BH_DT_U8: BH_FF_APPLY(uint8_t); break;
+        case BH_DT_U16: BH_FF_APPLY(uint16_t); break;
+        case BH_DT_I16: BH_FF_APPLY(int16_t); break;
+        case BH_DT_F32: BH_FF_APPLY(float); break;
+        default: BH_REQUIRE(false, "unsupported input dtype code %d", in_dtype);
+    }
+#undef BH_FF_APPLY
+    BH_CHECK_HIP(hipGetLastError());
+    if (mean_out) {
+        BH_CHECK_HIP(hipMemcpyAsync(mean_out, red + nblk, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        BH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return BH_OK;
+}

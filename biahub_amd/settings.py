@@ -25,6 +25,13 @@ class ProcessingSettings(_Strict):
     rot90: int | None = 0
 
 
+class FlatFieldCorrectionSettings(_Strict):
+    """biahub/settings.py:336-339."""
+
+    channel_names: list[str] | None = None
+    output_ome_zarr_version: OmeZarrVersion | None = None
+
+
 class DeskewSettings(_Strict):
     pixel_size_um: PositiveFloat
     ls_angle_deg: PositiveFloat

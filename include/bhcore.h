@@ -7,6 +7,8 @@
  *
  *   bh_deskew_shape        <- biahub/deskew.py:213-274  get_deskewed_data_shape
  *   bh_deskew              <- biahub/deskew.py:456-542  fast_deskew_zyx  (+ :99-154)
+ *   bh_flat_field, bh_median_z
+ *                          <- biahub/flat_field.py:101-120 flat_field_zyx, :56-99 _median_tiled (np.median, axis 0)
  *   bh_overhang_fill       <- biahub/deskew.py:339-368  _fill_overhang_torch
  *   bh_transfer_function   <- biahub/deconvolve.py:30-43 compute_tranfser_function
  *   bh_tikhonov            <- biahub/deconvolve.py:46-66 deconvolve (waveorder Tikhonov)
@@ -93,6 +95,18 @@ int bh_malloc(void** dptr, uint64_t bytes);
 int bh_free(void* dptr);
 int bh_memcpy_h2d(bh_ctx* ctx, void* dst, const void* src, uint64_t bytes); /* synchronous */
 int bh_memcpy_d2h(bh_ctx* ctx, void* dst, const void* src, uint64_t bytes); /* synchronous */
+
+/* ---- flat field (the step before deskew in the mantis pipeline) -------------------------------------------- */
+/* pattern[y*X + x] (device, float64) = np.median(in[:, y, x]) exactly: the middle element, or for an even Z the mean of
+ * the two middle elements (float32 mean for float32 input, like numpy).  BH_ERR_UNSUPPORTED when Z samples of 4 pixels
+ * do not fit the LDS staging (Z > 18432 for 16-bit input, 9216 for float32).  NaN input is not supported. */
+int bh_median_z(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, int64_t X, double* pattern);
+
+/* out = in / pattern * mean(pattern), pattern = median along Z (biahub/flat_field.py:101-120), written as float32 like
+ * _flat_field_czyx (:144-155): float64 arithmetic for integer input, float32 arithmetic for float32 input.
+ * pattern (device, Y*X float64) may be NULL (context scratch is used); mean_out (host) may be NULL (no sync). */
+int bh_flat_field(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, int64_t X, float* out,
+                  double* pattern, double* mean_out);
 
 /* ---- deskew ------------------------------------------------------------------------ */
 /* Host-only geometry. out_shape = (ceil(Y/n), X, Xp); voxel = (n*sin(t)*px, px, px).
@@ -188,7 +202,7 @@ int bh_crop_flip(bh_ctx* ctx, const void* in, int itemsize, int64_t C, int64_t Z
 /* ---- measurement support ----------------------------------------------------------- */
 /* Elapsed milliseconds of the last call of each kind, measured with HIP events on the
  * context's stream (what: 0 deskew kernel, 1 fill passes, 2 RL total, 3 tikhonov, 4 affine,
- * 5 crop_flip, 6 one RL iteration (mean), 7 transfer function). Synchronises. */
+ * 5 crop_flip, 6 one RL iteration (mean), 7 transfer function, 8 flat field). Synchronises. */
 int bh_last_elapsed_ms(bh_ctx* ctx, int what, float* ms);
 /* Enable/disable event timing (off by default: events cost a few us per call). */
 int bh_ctx_set_timing(bh_ctx* ctx, int enabled);

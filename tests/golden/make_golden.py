@@ -37,7 +37,40 @@ sys.path.insert(0, str(HERE.parent.parent))
 from oracle.ref_import import load_reference, reference_available  # noqa: E402
 
 
+def flat_field_vectors():
+    """biahub/flat_field.py:56-155 — np.median pattern, flat_field_zyx, _flat_field_czyx (own generator: can run alone)."""
+    import biahub.flat_field as FF
+
+    rng = np.random.default_rng(20261004)
+    ff = {}
+    cases = [((8, 6, 4), np.uint16), ((9, 6, 4), np.uint16), ((2, 3, 5), np.uint16), ((1, 4, 4), np.uint16),
+             ((8, 6, 4), np.float32), ((9, 7, 5), np.float32), ((16, 12, 9), np.uint16), ((33, 5, 70), np.uint16),
+             ((40, 3, 130), np.float32), ((12, 4, 66), np.int16), ((7, 5, 9), np.uint8)]
+    for j, (shape, dt) in enumerate(cases):
+        lo = -2000 if dt == np.int16 else 1
+        hi = 250 if dt == np.uint8 else 4095
+        data = (rng.random(shape) * (hi - lo) + lo).astype(dt)
+        if j in (6, 7):  # ties: many equal samples per pixel, as a 12-bit camera gives
+            data = (data // 64 * 64 + 1).astype(dt)
+        ff[f"in{j}"] = data
+        ff[f"median{j}"] = FF._median_tiled(data, axis=0, tile_bytes=1)
+        ff[f"flat{j}"] = FF.flat_field_zyx(data)
+    czyx = (rng.random((3, 8, 6, 4)) * 4095 + 1).astype(np.uint16)
+    ff["czyx_in"] = czyx
+    ff["czyx_out"] = FF._flat_field_czyx(czyx, target_indices=[1])
+    ax = (rng.random((7, 8, 9)) * 4095 + 1).astype(np.uint16)
+    ff["axes_in"] = ax
+    for a in range(3):
+        ff[f"axes_median{a}"] = FF._median_tiled(ax, axis=a, tile_bytes=1)
+    np.savez_compressed(HERE / "flat_field.npz", **ff)
+    print("flat_field.npz written")
+
+
 def main():
+    if sys.argv[1:] == ["flat_field"]:
+        load_reference()
+        flat_field_vectors()
+        return 0
     if not reference_available():
         print("reference checkout not present; nothing to do")
         return 0
@@ -230,6 +263,7 @@ def main():
         "rescale_voxel": R.rescale_voxel_size(np.array(M[:3, :3]), np.array([0.2, 0.1, 0.1])).tolist(),
     }
     json.dump(helpers, open(HERE / "helpers.json", "w"), indent=1, default=str)
+    flat_field_vectors()
     total = sum(p.stat().st_size for p in HERE.glob("*.np*")) + sum(p.stat().st_size for p in HERE.glob("*.json"))
     print(f"golden fixtures written to {HERE} ({total/1e6:.2f} MB)")
     return 0

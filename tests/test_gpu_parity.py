@@ -492,3 +492,41 @@ def test_estimate_registration_recovers_similarity(gpu):
         estimate(ref=arm_b, mov=arm_a[0])
     with pytest.raises(ValueError, match="NaN or zeros"):
         estimate_czyx(np.zeros((1,) + shape, np.float32), arm_b[None], init)
+
+
+# ----------------------------------------------------------------------------- flat field (N3)
+def test_flat_field_golden_and_oracle(gpu):
+    """bh_median_z is np.median exactly; bh_flat_field matches the reference expression (float32 output)."""
+    from biahub_amd.flat_field import _flat_field_czyx, _median_tiled, flat_field_zyx, median_z_device
+
+    z = np.load(GOLDEN / "flat_field.npz")
+    for j in range(11):
+        data = z[f"in{j}"]
+        med = _median_tiled(data, axis=0)
+        assert med.dtype == z[f"median{j}"].dtype and np.array_equal(med, z[f"median{j}"]), j
+        got = flat_field_zyx(data)
+        want = z[f"flat{j}"].astype(np.float32)
+        assert got.dtype == np.float32 and got.shape == want.shape
+        # the pattern mean is a device float64 tree, numpy's a pairwise sum: at most the last float32 bit can differ
+        assert np.abs(got - want).max() <= 2e-7 * np.abs(want).max(), j
+    assert np.abs(_flat_field_czyx(z["czyx_in"], [1]) - z["czyx_out"]).max() <= 2e-7 * z["czyx_out"].max()
+    assert np.array_equal(_flat_field_czyx(z["czyx_in"], [1])[0], z["czyx_in"][0].astype(np.float32))
+    for a in range(3):
+        assert np.array_equal(_median_tiled(z["axes_in"], axis=a), z[f"axes_median{a}"])
+    rng = np.random.default_rng(12)
+    # every staging width: 64 columns (uint16, Z = 1068 like a mantis position), 32 (float32, Z = 700), 8 (float32, Z = 4000)
+    for shape, dt in (((1068, 3, 200), np.uint16), ((700, 2, 150), np.float32), ((4000, 1, 40), np.float32),
+                      ((512, 5, 64), np.int16), ((300, 7, 33), np.uint8), ((2, 9, 129), np.uint16)):
+        lo, hi = (-3000, 3000) if dt == np.int16 else ((0, 255) if dt == np.uint8 else (1, 4096))
+        data = (rng.random(shape) * (hi - lo) + lo).astype(dt)
+        if dt == np.float32:
+            data[::3] = -data[::3]                      # negative floats exercise the key transform
+        if dt == np.uint16:
+            data = (data // 16 * 16 + 1).astype(dt)     # ties
+        want = np.median(data, axis=0)
+        got = median_z_device(data).cpu().numpy()
+        assert np.array_equal(got, want.astype(np.float64)), (shape, dt)
+    vol = (rng.random((64, 40, 96)) * 4000 + 100).astype(np.uint16)
+    assert np.abs(flat_field_zyx(vol) - O.flat_field_zyx(vol).astype(np.float32)).max() <= 2e-7 * 65535
+    with pytest.raises(ValueError, match="broadcast"):   # as the reference expression does for axis != 0
+        flat_field_zyx(vol, axis=1)

@@ -84,7 +84,7 @@ def test_cli_help_and_eat_all():
     assert expand_eat_all(["deskew", "-i", "a", "b", "c", "-c", "x.yml", "-o", "o"]) == \
         ["deskew", "-i", "a", "-i", "b", "-i", "c", "-c", "x.yml", "-o", "o"]
     r = CliRunner()
-    for cmd in ("deskew", "deconvolve", "rl-deconvolve", "register", "stabilize", "flip", "estimate-registration"):
+    for cmd in ("deskew", "deconvolve", "rl-deconvolve", "register", "stabilize", "flip", "estimate-registration", "flat-field"):
         res = r.invoke(cli, [cmd, "--help"])
         assert res.exit_code == 0 and "Usage" in res.output
 
@@ -235,3 +235,26 @@ def test_cli_estimate_registration_then_register(gpu, tmp_path):
     got = io.open_ome_zarr(reg / "A/1/0").data[0, 0]
     core = (slice(8, 32), slice(16, 112), slice(16, 112))
     assert np.abs(got[core] - arm_b[core]).mean() < 0.02 * arm_b[core].mean()
+
+
+@pytest.mark.gpu
+def test_cli_flat_field(gpu, tmp_path):
+    """``flat-field --cluster debug``: listed channels corrected, the rest copied as float32 (flat_field.py:144-155)."""
+    src = tmp_path / "in.zarr"
+    shape = (2, 2, 16, 12, 20)
+    data = make_plate(src, positions=(("A", "1", "0"),), shape=shape)
+    cfg = tmp_path / "ff.yml"
+    cfg.write_text("channel_names: [ch1]\n")
+    out = tmp_path / "ff.zarr"
+    res = CliRunner().invoke(cli, ["flat-field", "-i", str(src / "A/1/0"), "-c", str(cfg), "-o", str(out), "--cluster", "debug"])
+    assert res.exit_code == 0, res.output
+    assert "Flat field channels: ['ch1']" in res.output and "RESOURCES:" in res.output
+    got = io.open_ome_zarr(out / "A/1/0")
+    assert got.data.dtype == np.float32 and got.data.shape == shape
+    want = O.flat_field_zyx(data[("A", "1", "0", 1, 1)]).astype(np.float32)
+    assert np.abs(got.data[1, 1] - want).max() <= 2e-7 * want.max()
+    assert np.array_equal(got.data[1, 0], data[("A", "1", "0", 1, 0)].astype(np.float32))
+    assert "biahub-flat_field" in got.zattrs["extra_metadata"]
+    cfg.write_text("channel_names: [nope]\n")
+    res = CliRunner().invoke(cli, ["flat-field", "-i", str(src / "A/1/0"), "-c", str(cfg), "-o", str(tmp_path / "x.zarr")])
+    assert res.exit_code != 0 and "not found" in res.output

@@ -132,3 +132,17 @@ def test_phase_cross_corr_oracle_matches_reference():
             sh, corr = O.phase_cross_corr(z[f"ref{j}"], z[f"mov{j}"], norm)
             assert np.array_equal(sh, z[f"shift{j}_{norm}"]), (j, norm)
             assert rel_err(corr, z[f"corr{j}_{norm}"]) <= 1e-5, (j, norm)
+
+
+def test_flat_field_golden():
+    """biahub/flat_field.py:56-155 through the oracle; values captured from the reference import."""
+    z = np.load(GOLDEN / "flat_field.npz")
+    for j in range(11):
+        data = z[f"in{j}"]
+        med = O.median_axis(data, 0)
+        assert med.dtype == z[f"median{j}"].dtype and np.array_equal(med, z[f"median{j}"])
+        got = O.flat_field_zyx(data)
+        assert got.dtype == z[f"flat{j}"].dtype and np.array_equal(got, z[f"flat{j}"])
+    assert np.array_equal(O.flat_field_czyx(z["czyx_in"], [1]), z["czyx_out"])
+    for a in range(3):
+        assert np.array_equal(O.median_axis(z["axes_in"], a), z[f"axes_median{a}"])

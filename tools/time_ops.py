@@ -45,3 +45,13 @@ if which in ("all", "affine"):
             out = affine_device(vol, M2, shape, "linear"); ms = ctx.elapsed_ms(_lib.T_AFFINE)
         print(f"affine translation {shape}: {ms:.3f} ms -> {8*V/ms/1e6:.0f} GB/s")
         del vol, out
+if which in ("all", "flatfield"):
+    from biahub_amd.flat_field import flat_field_device
+    for shape, dt in (((1068, 256, 1664), torch.uint16), ((512, 2048, 2048), torch.uint16), ((512, 2048, 2048), torch.float32)):
+        V = np.prod(shape)
+        vol = (torch.rand(shape, device=dev) * 4000 + 100).to(dt)
+        for _ in range(3):
+            out = flat_field_device(vol); ms = ctx.elapsed_ms(_lib.T_FLATFIELD)
+        b = (2 * vol.element_size() + 4) * V
+        print(f"flat_field {shape} {dt}: {ms:.2f} ms -> {b/ms/1e6:.0f} GB/s algorithmic (2 reads + 1 f32 write)")
+        del vol, out
