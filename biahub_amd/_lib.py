@@ -55,6 +55,9 @@ SIGNATURES = {
     "bh_mattes_mi": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, C.POINTER(_f64), C.POINTER(_f64), _int,
                             _i64, _i64, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64)]),
     "bh_sobel": (_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
+    "bh_block_peaks": (_int, [_vp, _vp, _i64, _i64, _i64, _int, C.POINTER(_int), _vp, _vp, C.POINTER(_i64)]),
+    "bh_patch_peaks": (_int, [_vp, _vp, _i64, _i64, _i64, C.POINTER(_int), _int, C.POINTER(_int), _f64, C.POINTER(_i64)]),
+    "bh_average_patches": (_int, [_vp, _vp, _i64, _i64, _i64, C.POINTER(_int), _int, C.POINTER(_int), _int, _vp]),
     "bh_affine": (_int, [_vp, _vp, _int, _i64, _i64, _i64, C.POINTER(_f64), _int, _int, _f32, _vp, _i64, _i64,
                          _i64, C.POINTER(_i64)]),
     "bh_crop_flip": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, C.POINTER(_i64), _i64, _i64, _i64, _int,

@@ -18,7 +18,7 @@ import numpy as np
 from . import parallel
 from .io import create_empty_plate, open_ome_zarr, process_single_position
 from .settings import (DeconvolveSettings, DeskewSettings, EstimateRegistrationSettings, FlatFieldCorrectionSettings,
-                       RegistrationSettings, RichardsonLucySettings, StabilizationSettings)
+                       PsfFromBeadsSettings, RegistrationSettings, RichardsonLucySettings, StabilizationSettings)
 from .utils.cluster import echo_resources, estimate_resources, get_submitit_cluster
 from .utils.config import model_to_yaml, settings_fingerprint, yaml_to_model
 from .utils.paths import get_output_paths, sbatch_to_submitit
@@ -379,6 +379,33 @@ def estimate_registration_cli(source_position_dirpaths, target_position_dirpaths
     if parallel.world_info()[0] == 0:
         model_to_yaml(model, output_filepath)
     click.echo(f"Registration settings saved to {output_dir.resolve()}")
+
+
+@cli.command("estimate-psf")
+@click.option("--input-position-dirpaths", "-i", multiple=True, required=True, callback=_positions)
+@_config
+@click.option("--output-dirpath", "-o", required=True, type=click.Path(path_type=Path))
+def estimate_psf_cli(input_position_dirpaths, config_filepath, output_dirpath):
+    """Estimate the PSF from bead volumes and save it as ``<out>/0/0/0`` (reference: ``biahub estimate-psf``,
+    estimate_psf.py:19-121): (t, c) = (0, 0) of every position, beads detected, recentred, averaged on the GPU."""
+    from .estimate_psf import estimate_psf
+
+    settings = yaml_to_model(config_filepath, PsfFromBeadsSettings)
+    click.echo("Loading data...")
+    pzyx, zyx_scale = [], None
+    for p in input_position_dirpaths:
+        with open_ome_zarr(p) as ds:
+            pzyx.append(ds.data[0, 0])
+            zyx_scale = tuple(ds.scale[-3:])
+    if len({v.shape for v in pzyx}) != 1:
+        raise ValueError("Concatenating position arrays failed.")
+    patch = (settings.axis0_patch_size, settings.axis1_patch_size, settings.axis2_patch_size)
+    click.echo("Detecting beads...")
+    psf = estimate_psf(pzyx, zyx_scale, patch_size=patch, verbose=True)
+    create_empty_plate(output_dirpath, [("0", "0", "0")], ["PSF"], (1, 1) + psf.shape, chunks=(1, 1) + psf.shape,
+                       scale=(1, 1) + zyx_scale, dtype=np.float32)
+    open_ome_zarr(Path(output_dirpath) / "0/0/0").data[0, 0] = psf
+    click.echo(f"PSF saved to {Path(output_dirpath).resolve()}")
 
 
 @cli.command("flip")

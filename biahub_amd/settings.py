@@ -149,6 +149,14 @@ class EstimateRegistrationSettings(_Strict):
         return self
 
 
+class PsfFromBeadsSettings(_Strict):
+    """biahub/settings.py:418-421."""
+
+    axis0_patch_size: PositiveInt = 101
+    axis1_patch_size: PositiveInt = 101
+    axis2_patch_size: PositiveInt = 101
+
+
 class DeconvolveSettings(_Strict):
     regularization_strength: PositiveFloat = 0.001
     output_ome_zarr_version: OmeZarrVersion | None = None

@@ -17,6 +17,10 @@
  *   bh_image_stats, bh_smooth_shrink, bh_mattes_mi
  *                          <- biahub/registration/ants.py:55-122 estimate (the data-parallel pieces of the
  *                             ants.registration call at :104-109: pyramid, Mattes MI value + derivative)
+ *   bh_block_peaks         <- biahub/characterize_psf.py:562-711 detect_peaks (its pooling part, :622-650)
+ *   bh_patch_peaks, bh_average_patches
+ *                          <- biahub/estimate_psf.py:84-112 (extract_beads + normalised mean),
+ *                             vendor/napari_psf_analysis/psf_analysis/extract/BeadExtractor.py:36-78
  *   bh_affine              <- biahub/register.py:202-281 apply_affine_transform,
  *                             biahub/stabilize.py:32-90 apply_stabilization_transform,
  *                             biahub/core/transform.py:374-396 Transform._apply_scipy
@@ -181,6 +185,26 @@ int bh_mattes_mi(bh_ctx* ctx, const float* fixed, int64_t Zf, int64_t Yf, int64_
 /* skimage.filters.sobel of a 3-D float32 volume (registration/ants.py:272-275 preprocessing option): gradient magnitude
  * sqrt((gz^2+gy^2+gx^2)/3) of the [1,0,-1] x [1,2,1]/4 x [1,2,1]/4 stencils, edges reflected.  out must not alias in. */
 int bh_sobel(bh_ctx* ctx, const float* in, int64_t Z, int64_t Y, int64_t X, float* out);
+
+/* ---- bead detection / PSF averaging (biahub/characterize_psf.py:562-711, biahub/estimate_psf.py:58-121) ------------- */
+/* One peak candidate per pooling block: values[b] / indices[b] = max and flat input index (first maximum in z, y, x scan
+ * order) of the k x k x k box mean (divisor = in-volume voxels: count_include_pad=False) over block b of
+ * max_pool3d(kernel=block, stride=block, padding=block/2); nblocks[a] = (N + 2*(block/2) - block) / block + 1 and
+ * b = (oz * nblocks[1] + oy) * nblocks[2] + ox.  values == indices == NULL only fills nblocks (host-only).
+ * Bit-identical to torch's avg_pool3d + max_pool3d on CPU. */
+int bh_block_peaks(bh_ctx* ctx, const float* in, int64_t Z, int64_t Y, int64_t X, int blur_kernel_size,
+                   const int block[3], float* values, int64_t* indices, int64_t nblocks[3]);
+
+/* For each of n patches [starts[3b..], starts + patch) (host int array, all fully inside the volume): peaks[b] (host) =
+ * flat index inside the patch of the first maximum of the patch smoothed by a Gaussian of `sigma` voxels (zero outside
+ * the patch, radius int(4 sigma + 0.5)) — BeadExtractor._compute_peak_offset.  Synchronises. */
+int bh_patch_peaks(bh_ctx* ctx, const float* in, int64_t Z, int64_t Y, int64_t X, const int* starts, int n,
+                   const int patch[3], double sigma, int64_t* peaks);
+
+/* out (device, patch voxels) = mean over the n patches of patch / max(patch); with normalise != 0 followed by
+ * out -= min(out); out /= max(out) (estimate_psf.py:104-112).  Synchronises. */
+int bh_average_patches(bh_ctx* ctx, const float* in, int64_t Z, int64_t Y, int64_t X, const int* starts, int n,
+                       const int patch[3], int normalise, float* out);
 
 /* ---- affine warp ------------------------------------------------------------------- */
 /* out(p) = in(M p), M = 3x4 row-major pull matrix (rows z,y,x; last column translation) in ZYX

@@ -53,6 +53,8 @@ _STUBS = [
     "skimage.registration",
     "sklearn",
     "sklearn.neighbors",
+    # only needed by biahub.characterize_psf (detect_peaks)
+    "markdown",
 ]
 
 

@@ -66,7 +66,51 @@ def flat_field_vectors():
     print("flat_field.npz written")
 
 
+def detect_peaks_vectors():
+    """biahub/characterize_psf.py:562-711 detect_peaks on seeded bead volumes (torch CPU), plus the raw pooling outputs."""
+    import torch
+    import torch.nn.functional as F
+
+    import biahub.characterize_psf as CP
+
+    rng = np.random.default_rng(20261005)
+    dp = {}
+
+    def beads(shape, n, seed):
+        r = np.random.default_rng(seed)
+        v = r.normal(110.0, 3.0, shape).astype(np.float32)
+        zz, yy, xx = np.ogrid[: shape[0], : shape[1], : shape[2]]
+        for _ in range(n):
+            c = r.uniform(0, 1, 3) * np.array(shape)
+            v += (r.uniform(400, 3000) * np.exp(-0.5 * (((zz - c[0]) / 1.5) ** 2 + ((yy - c[1]) / 1.2) ** 2
+                                                         + ((xx - c[2]) / 1.2) ** 2))).astype(np.float32)
+        return np.rint(v).astype(np.float32)
+
+    cases = [((24, 40, 36), 12, dict(block_size=(8, 8, 8), nms_distance=3, min_distance=6, threshold_abs=200.0,
+                                      max_num_peaks=50, exclude_border=(2, 3, 3), blur_kernel_size=3)),
+             ((33, 50, 47), 25, dict(block_size=(16, 12, 8), nms_distance=4, min_distance=10, threshold_abs=300.0,
+                                      max_num_peaks=30, exclude_border=None, blur_kernel_size=3)),
+             ((20, 31, 29), 8, dict(block_size=(4, 4, 4), nms_distance=3, min_distance=0, threshold_abs=150.0,
+                                     max_num_peaks=500, exclude_border=(1, 1, 1), blur_kernel_size=5))]
+    for j, (shape, n, kw) in enumerate(cases):
+        vol = beads(shape, n, 100 + j)
+        dp[f"vol{j}"] = vol
+        dp[f"kw{j}"] = np.array(json.dumps(kw))
+        dp[f"peaks{j}"] = CP.detect_peaks(vol, **kw, device="cpu")
+        t = torch.from_numpy(vol)[None, None]
+        k, b = kw["blur_kernel_size"], kw["block_size"]
+        sm = F.avg_pool3d(t, kernel_size=k, stride=1, padding=k // 2, count_include_pad=False)
+        val, idx = F.max_pool3d(sm, kernel_size=b, stride=b, padding=tuple(x // 2 for x in b), return_indices=True)
+        dp[f"pool_val{j}"], dp[f"pool_idx{j}"] = val.flatten().numpy(), idx.flatten().numpy()
+    np.savez_compressed(HERE / "detect_peaks.npz", **dp)
+    print("detect_peaks.npz written")
+
+
 def main():
+    if sys.argv[1:] == ["detect_peaks"]:
+        load_reference()
+        detect_peaks_vectors()
+        return 0
     if sys.argv[1:] == ["flat_field"]:
         load_reference()
         flat_field_vectors()
@@ -264,6 +308,7 @@ def main():
     }
     json.dump(helpers, open(HERE / "helpers.json", "w"), indent=1, default=str)
     flat_field_vectors()
+    detect_peaks_vectors()
     total = sum(p.stat().st_size for p in HERE.glob("*.np*")) + sum(p.stat().st_size for p in HERE.glob("*.json"))
     print(f"golden fixtures written to {HERE} ({total/1e6:.2f} MB)")
     return 0

@@ -530,3 +530,63 @@ def test_flat_field_golden_and_oracle(gpu):
     assert np.abs(flat_field_zyx(vol) - O.flat_field_zyx(vol).astype(np.float32)).max() <= 2e-7 * 65535
     with pytest.raises(ValueError, match="broadcast"):   # as the reference expression does for axis != 0
         flat_field_zyx(vol, axis=1)
+
+
+# ----------------------------------------------------------------------------- bead detection / PSF estimate (N4)
+def _bead_volume(shape, n, seed, sigma=(1.5, 1.2, 1.2)):
+    r = np.random.default_rng(seed)
+    v = r.normal(110.0, 3.0, shape).astype(np.float32)
+    zz, yy, xx = np.ogrid[: shape[0], : shape[1], : shape[2]]
+    centres = []
+    for _ in range(n):
+        c = r.uniform(0.15, 0.85, 3) * np.array(shape)
+        centres.append(c)
+        v += (r.uniform(800, 3000) * np.exp(-0.5 * (((zz - c[0]) / sigma[0]) ** 2 + ((yy - c[1]) / sigma[1]) ** 2
+                                                     + ((xx - c[2]) / sigma[2]) ** 2))).astype(np.float32)
+    return np.rint(v).astype(np.float32), np.array(centres)
+
+
+def test_detect_peaks_golden(gpu):
+    """bh_block_peaks is torch's avg_pool3d + max_pool3d bit for bit; detect_peaks returns the reference's peaks."""
+    import json
+    import torch
+    from biahub_amd.characterize_psf import block_peaks, detect_peaks
+
+    z = np.load(GOLDEN / "detect_peaks.npz")
+    for j in range(3):
+        kw = json.loads(str(z[f"kw{j}"]))
+        kw["block_size"] = tuple(kw["block_size"])
+        kw["exclude_border"] = tuple(kw["exclude_border"]) if kw["exclude_border"] else None
+        val, idx = block_peaks(torch.from_numpy(z[f"vol{j}"]).to(gpu), kw["blur_kernel_size"], kw["block_size"])
+        assert np.array_equal(val, z[f"pool_val{j}"]) and np.array_equal(idx, z[f"pool_idx{j}"]), j
+        assert np.array_equal(detect_peaks(z[f"vol{j}"], **kw), z[f"peaks{j}"]), j
+    with pytest.raises(ValueError, match="odd"):
+        detect_peaks(z["vol0"], blur_kernel_size=4)
+    with pytest.raises(ValueError, match="exclude_border"):
+        detect_peaks(z["vol0"], exclude_border=(1, 2))
+
+
+def test_estimate_psf_vs_oracle(gpu):
+    """detect -> recentre -> average on a synthetic bead volume: same beads and (to float tolerance) the same PSF as the
+    NumPy/SciPy restatement; the estimated PSF has the beads' widths."""
+    from biahub_amd.characterize_psf import detect_peaks, extract_beads
+    from biahub_amd.estimate_psf import estimate_psf
+
+    shape, patch = (48, 120, 110), (15, 21, 21)
+    vol, truth = _bead_volume(shape, 14, 5)
+    kw = dict(block_size=(16, 16, 16), blur_kernel_size=3, nms_distance=6, min_distance=12, threshold_abs=300.0,
+              max_num_peaks=100, exclude_border=(3, 5, 5))
+    peaks = detect_peaks(vol, **kw)
+    assert np.array_equal(peaks, O.detect_peaks(vol, **kw)) and 8 <= len(peaks) <= 14
+    want, centres = O.recentre_and_average(vol, peaks, patch)
+    psf = estimate_psf([vol], (1.0, 1.0, 1.0), patch_size=patch, bead_detection_settings=kw)
+    assert psf.shape == patch and psf.dtype == np.float32 and psf.min() == 0.0 and psf.max() == 1.0
+    assert np.abs(psf - want).max() <= 1e-5
+    assert np.unravel_index(int(psf.argmax()), patch) == tuple(p // 2 for p in patch)   # recentred on the peak
+    beads, offsets = extract_beads(vol, peaks, (1.0, 1.0, 1.0), patch_size=patch)
+    assert len(beads) == len(centres) and all(b.shape == patch for b in beads)
+    assert np.array_equal(np.array(offsets) + np.array(patch) // 2, centres)
+    two = estimate_psf([vol, vol], (1.0, 1.0, 1.0), patch_size=patch, bead_detection_settings=kw)  # positions pooled
+    assert np.abs(two - psf).max() <= 1e-6
+    with pytest.raises(ValueError, match="No beads"):
+        estimate_psf([np.full(shape, 100.0, np.float32)], (1, 1, 1), patch_size=patch, bead_detection_settings=kw)

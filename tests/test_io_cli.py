@@ -84,7 +84,7 @@ def test_cli_help_and_eat_all():
     assert expand_eat_all(["deskew", "-i", "a", "b", "c", "-c", "x.yml", "-o", "o"]) == \
         ["deskew", "-i", "a", "-i", "b", "-i", "c", "-c", "x.yml", "-o", "o"]
     r = CliRunner()
-    for cmd in ("deskew", "deconvolve", "rl-deconvolve", "register", "stabilize", "flip", "estimate-registration", "flat-field"):
+    for cmd in ("deskew", "deconvolve", "rl-deconvolve", "register", "stabilize", "flip", "estimate-registration", "flat-field", "estimate-psf"):
         res = r.invoke(cli, [cmd, "--help"])
         assert res.exit_code == 0 and "Usage" in res.output
 
@@ -258,3 +258,30 @@ def test_cli_flat_field(gpu, tmp_path):
     cfg.write_text("channel_names: [nope]\n")
     res = CliRunner().invoke(cli, ["flat-field", "-i", str(src / "A/1/0"), "-c", str(cfg), "-o", str(tmp_path / "x.zarr")])
     assert res.exit_code != 0 and "not found" in res.output
+
+
+@pytest.mark.gpu
+def test_cli_estimate_psf_feeds_deconvolve(gpu, tmp_path):
+    """``estimate-psf`` writes the psf store that ``deconvolve -p`` reads (estimate_psf.py:114-121, deconvolve.py:131-139)."""
+    rng = np.random.default_rng(3)
+    shape = (40, 200, 200)  # the CLI's fixed detection settings want beads >= 50 voxels apart (estimate_psf.py:58-67)
+    vol = rng.normal(110.0, 3.0, shape).astype(np.float32)
+    zz, yy, xx = np.ogrid[: shape[0], : shape[1], : shape[2]]
+    for c in ((12, 40, 40), (20, 140, 50), (28, 50, 150), (14, 150, 150)):
+        vol += (2000 * np.exp(-0.5 * (((zz - c[0]) / 1.5) ** 2 + ((yy - c[1]) / 1.2) ** 2 + ((xx - c[2]) / 1.2) ** 2))).astype(np.float32)
+    store = tmp_path / "beads.zarr"
+    io.create_empty_plate(store, [("A", "1", "0")], ["beads"], (1, 1) + shape, scale=(1, 1, 0.25, 0.1, 0.1))
+    io.open_ome_zarr(store / "A/1/0").data[0, 0] = vol
+    cfg = tmp_path / "psf.yml"
+    cfg.write_text("axis0_patch_size: 11\naxis1_patch_size: 15\naxis2_patch_size: 15\n")
+    out = tmp_path / "psf.zarr"
+    res = CliRunner().invoke(cli, ["estimate-psf", "-i", str(store / "A/1/0"), "-c", str(cfg), "-o", str(out)])
+    assert res.exit_code == 0, res.output
+    assert "Total beads: 4" in res.output
+    pos = io.open_ome_zarr(out / "0/0/0")
+    psf = pos.data[0, 0]
+    assert pos.channel_names == ["PSF"] and psf.shape == (11, 15, 15) and psf.dtype == np.float32
+    np.testing.assert_allclose(pos.scale, (1, 1, 0.25, 0.1, 0.1))
+    assert psf.max() == 1.0 and psf.min() == 0.0 and np.unravel_index(int(psf.argmax()), psf.shape) == (5, 7, 7)
+    half = psf[5, 7, :]   # sigma 1.2 voxels along x: exp(-0.5 (1/1.2)^2) = 0.707 one voxel off the peak
+    assert abs(half[8] - np.exp(-0.5 / 1.44)) < 0.03

@@ -146,3 +146,17 @@ def test_flat_field_golden():
     assert np.array_equal(O.flat_field_czyx(z["czyx_in"], [1]), z["czyx_out"])
     for a in range(3):
         assert np.array_equal(O.median_axis(z["axes_in"], a), z[f"axes_median{a}"])
+
+
+def test_detect_peaks_golden():
+    """characterize_psf.detect_peaks through the oracle: pooling outputs bit-equal to torch, peaks equal to the reference."""
+    import json
+
+    z = np.load(GOLDEN / "detect_peaks.npz")
+    for j in range(3):
+        kw = json.loads(str(z[f"kw{j}"]))
+        kw["block_size"] = tuple(kw["block_size"])
+        kw["exclude_border"] = tuple(kw["exclude_border"]) if kw["exclude_border"] else None
+        val, idx = O.block_peaks(z[f"vol{j}"], kw["blur_kernel_size"], kw["block_size"])
+        assert np.array_equal(val, z[f"pool_val{j}"]) and np.array_equal(idx, z[f"pool_idx{j}"])
+        assert np.array_equal(O.detect_peaks(z[f"vol{j}"], **kw), z[f"peaks{j}"])
