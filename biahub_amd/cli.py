@@ -17,7 +17,8 @@ import numpy as np
 
 from . import parallel
 from .io import create_empty_plate, open_ome_zarr, process_single_position
-from .settings import (DeconvolveSettings, DeskewSettings, EstimateRegistrationSettings, FlatFieldCorrectionSettings,
+from .settings import (DeconvolveSettings, DeskewSettings, EstimateRegistrationSettings,
+                       EstimateStabilizationSettings, FlatFieldCorrectionSettings, PhaseCrossCorrSettings,
                        PsfFromBeadsSettings, RegistrationSettings, RichardsonLucySettings, StabilizationSettings)
 from .utils.cluster import echo_resources, estimate_resources, get_submitit_cluster
 from .utils.config import model_to_yaml, settings_fingerprint, yaml_to_model
@@ -379,6 +380,47 @@ def estimate_registration_cli(source_position_dirpaths, target_position_dirpaths
     if parallel.world_info()[0] == 0:
         model_to_yaml(model, output_filepath)
     click.echo(f"Registration settings saved to {output_dir.resolve()}")
+
+
+@cli.command("estimate-stabilization")
+@click.option("--input-position-dirpaths", "-i", multiple=True, required=True, callback=_positions)
+@click.option("--output-dirpath", "-o", required=True, type=click.Path(path_type=Path))
+@_config
+@click.option("--sbatch-filepath", "-sb", default=None, type=click.Path(path_type=Path))
+@click.option("--local", "-l", is_flag=True, default=False)
+def estimate_stabilization_cli(input_position_dirpaths, output_dirpath, config_filepath, sbatch_filepath, local):
+    """Estimate per-timepoint stabilization transforms (reference: ``biahub estimate-stabilization``,
+    estimate_stabilization.py:1223-1640).  ``stabilization_type: xyz`` with ``stabilization_method: phase-cross-corr``
+    runs here (GPU phase cross-correlation); one ``xyz_stabilization_settings/<fov>.yml`` per position feeds ``stabilize``."""
+    from .estimate_stabilization import estimate_xyz_stabilization_pcc, save_transforms
+
+    settings = yaml_to_model(config_filepath, EstimateStabilizationSettings)
+    click.echo(f"Settings: {settings}")
+    if not (settings.stabilization_type == "xyz" and settings.stabilization_method == "phase-cross-corr"):
+        raise click.UsageError(f"stabilization_type {settings.stabilization_type!r} with method "
+                               f"{settings.stabilization_method!r} is not available in biahub_amd (only 'xyz' with "
+                               "'phase-cross-corr'); use the reference biahub package for focus finding and beads.")
+    if settings.eval_transform_settings:
+        raise click.UsageError("eval_transform_settings (transform validation / interpolation) is not available in biahub_amd")
+    output_dirpath = Path(output_dirpath)
+    output_dirpath.mkdir(parents=True, exist_ok=True)
+    with open_ome_zarr(input_position_dirpaths[0]) as ds:
+        channel_index = ds.channel_names.index(settings.stabilization_estimation_channel)
+        voxel_size = list(ds.scale)
+    click.echo("Estimating xyz stabilization parameters with phase cross correlation")
+    pcc = settings.phase_cross_corr_settings or PhaseCrossCorrSettings()
+    fov_transforms = estimate_xyz_stabilization_pcc(input_position_dirpaths, output_dirpath, pcc, channel_index=channel_index,
+                                                    sbatch_filepath=sbatch_filepath, cluster="local", verbose=settings.verbose)
+    if parallel.world_info()[0] == 0:
+        for fov, transforms in fov_transforms.items():
+            model = StabilizationSettings(stabilization_type=settings.stabilization_type,
+                                          stabilization_method=settings.stabilization_method,
+                                          stabilization_estimation_channel=settings.stabilization_estimation_channel,
+                                          stabilization_channels=settings.stabilization_channels,
+                                          affine_transform_zyx_list=[np.eye(4).tolist()], time_indices="all",
+                                          output_voxel_size=voxel_size)
+            save_transforms(model, transforms, output_dirpath / "xyz_stabilization_settings" / f"{fov}.yml")
+    click.echo(f"Stabilization settings saved to {output_dirpath.resolve()}")
 
 
 @cli.command("estimate-psf")

@@ -157,6 +157,37 @@ class PsfFromBeadsSettings(_Strict):
     axis2_patch_size: PositiveInt = 101
 
 
+class PhaseCrossCorrSettings(_Strict):
+    """biahub/settings.py:205-214."""
+
+    normalization: Literal["magnitude", "classic"] | None = None
+    maximum_shift: float = 1.2
+    function_type: Literal["custom_padding", "custom"] = "custom"
+    t_reference: Literal["first", "previous"] = "first"
+    skip_beads_fov: str = "0"
+    center_crop_xy: list[int] | None = None
+    X_slice: list | Literal["all"] = "all"
+    Y_slice: list | Literal["all"] = "all"
+    Z_slice: list | Literal["all"] = "all"
+
+
+class EstimateStabilizationSettings(_Strict):
+    """biahub/settings.py:295-310; only ``phase-cross-corr`` runs in this package, the other methods' sub-settings are
+    carried as plain dicts."""
+
+    stabilization_estimation_channel: str
+    stabilization_channels: list
+    stabilization_type: Literal["z", "xy", "xyz"]
+    stabilization_method: Literal["beads", "phase-cross-corr", "focus-finding"] = "focus-finding"
+    beads_match_settings: dict | None = None
+    phase_cross_corr_settings: PhaseCrossCorrSettings | None = None
+    stack_reg_settings: dict | None = None
+    focus_finding_settings: dict | None = None
+    affine_transform_settings: AffineTransformSettings = AffineTransformSettings()
+    eval_transform_settings: dict | None = None
+    verbose: bool = False
+
+
 class DeconvolveSettings(_Strict):
     regularization_strength: PositiveFloat = 0.001
     output_ome_zarr_version: OmeZarrVersion | None = None

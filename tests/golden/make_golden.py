@@ -106,7 +106,35 @@ def detect_peaks_vectors():
     print("detect_peaks.npz written")
 
 
+def pcc_chain_vectors():
+    """estimate_stabilization.py:129-196 (phase_cross_corr_padding) and :259-310 (get_tform_from_pcc)."""
+    import biahub.estimate_stabilization as ES
+
+    rng = np.random.default_rng(20261006)
+    pc = {}
+    for j, (shape, roll) in enumerate([((10, 14, 12), (1, -2, 3)), ((9, 11, 13), (-2, 1, 0)), ((16, 20, 18), (3, 0, -4))]):
+        ref = rng.random(shape, dtype=np.float32)
+        mov = np.roll(ref, roll, axis=(0, 1, 2)) + 0.02 * rng.random(shape, dtype=np.float32)
+        pc[f"ref{j}"], pc[f"mov{j}"] = ref, mov
+        for norm in (None, "magnitude"):
+            peak, corr = ES.phase_cross_corr_padding(ref, mov, normalization=norm)
+            pc[f"peak{j}_{norm}"], pc[f"corr{j}_{norm}"] = np.asarray(peak), np.asarray(corr)
+    stack = np.stack([pc["ref2"], pc["mov2"], np.roll(pc["ref2"], (0, 2, 1), axis=(0, 1, 2))])
+    first = np.broadcast_to(stack[0], stack.shape).copy()
+    pc["stack"] = stack
+    for t in (1, 2):
+        for ft in ("custom", "custom_padding"):
+            tr, sh, _ = ES.get_tform_from_pcc(t, stack, first, function_type=ft, normalization="magnitude")
+            pc[f"tform{t}_{ft}"], pc[f"tshift{t}_{ft}"] = np.asarray(tr), np.asarray(sh, dtype=np.float64)
+    np.savez_compressed(HERE / "pcc_chain.npz", **pc)
+    print("pcc_chain.npz written")
+
+
 def main():
+    if sys.argv[1:] == ["pcc_chain"]:
+        load_reference()
+        pcc_chain_vectors()
+        return 0
     if sys.argv[1:] == ["detect_peaks"]:
         load_reference()
         detect_peaks_vectors()
@@ -309,6 +337,7 @@ def main():
     json.dump(helpers, open(HERE / "helpers.json", "w"), indent=1, default=str)
     flat_field_vectors()
     detect_peaks_vectors()
+    pcc_chain_vectors()
     total = sum(p.stat().st_size for p in HERE.glob("*.np*")) + sum(p.stat().st_size for p in HERE.glob("*.json"))
     print(f"golden fixtures written to {HERE} ({total/1e6:.2f} MB)")
     return 0

@@ -590,3 +590,23 @@ def test_estimate_psf_vs_oracle(gpu):
     assert np.abs(two - psf).max() <= 1e-6
     with pytest.raises(ValueError, match="No beads"):
         estimate_psf([np.full(shape, 100.0, np.float32)], (1, 1, 1), patch_size=patch, bead_detection_settings=kw)
+
+
+def test_pcc_chain_golden(gpu):
+    """The phase-cross-correlation call chain around bh_phase_cross_corr equals the reference's (incl. its sign and
+    index conventions): phase_cross_corr_padding, get_tform_from_pcc."""
+    from biahub_amd.estimate_stabilization import get_tform_from_pcc, phase_cross_corr_padding
+
+    z = np.load(GOLDEN / "pcc_chain.npz")
+    for j in range(3):
+        for norm in (None, "magnitude"):
+            peak, corr = phase_cross_corr_padding(z[f"ref{j}"], z[f"mov{j}"], normalization=norm)
+            assert tuple(peak) == tuple(z[f"peak{j}_{norm}"]), (j, norm, peak)
+            assert corr.shape == z[f"corr{j}_{norm}"].shape and rel_err(corr, z[f"corr{j}_{norm}"]) <= FFT_TOL
+    stack = z["stack"]
+    first = np.broadcast_to(stack[0], stack.shape)
+    for t in (1, 2):
+        for ft in ("custom", "custom_padding"):
+            tr, sh, _ = get_tform_from_pcc(t, stack, first, function_type=ft, normalization="magnitude")
+            assert np.array_equal(tr, z[f"tform{t}_{ft}"]), (t, ft, tr)
+            assert np.array_equal(np.asarray(sh, dtype=np.float64), z[f"tshift{t}_{ft}"])

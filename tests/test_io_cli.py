@@ -84,7 +84,7 @@ def test_cli_help_and_eat_all():
     assert expand_eat_all(["deskew", "-i", "a", "b", "c", "-c", "x.yml", "-o", "o"]) == \
         ["deskew", "-i", "a", "-i", "b", "-i", "c", "-c", "x.yml", "-o", "o"]
     r = CliRunner()
-    for cmd in ("deskew", "deconvolve", "rl-deconvolve", "register", "stabilize", "flip", "estimate-registration", "flat-field", "estimate-psf"):
+    for cmd in ("deskew", "deconvolve", "rl-deconvolve", "register", "stabilize", "flip", "estimate-registration", "flat-field", "estimate-psf", "estimate-stabilization"):
         res = r.invoke(cli, [cmd, "--help"])
         assert res.exit_code == 0 and "Usage" in res.output
 
@@ -285,3 +285,42 @@ def test_cli_estimate_psf_feeds_deconvolve(gpu, tmp_path):
     assert psf.max() == 1.0 and psf.min() == 0.0 and np.unravel_index(int(psf.argmax()), psf.shape) == (5, 7, 7)
     half = psf[5, 7, :]   # sigma 1.2 voxels along x: exp(-0.5 (1/1.2)^2) = 0.707 one voxel off the peak
     assert abs(half[8] - np.exp(-0.5 / 1.44)) < 0.03
+
+
+@pytest.mark.gpu
+def test_cli_estimate_stabilization_then_stabilize(gpu, tmp_path):
+    """``estimate-stabilization`` (xyz, phase-cross-corr) writes per-FOV settings that ``stabilize`` consumes."""
+    import yaml
+
+    rng = np.random.default_rng(5)
+    base = (rng.random((16, 32, 40)) * 1000 + 100).astype(np.float32)
+    rolls = [(0, 0, 0), (1, -2, 3), (2, 1, -1)]
+    src = tmp_path / "in.zarr"
+    io.create_empty_plate(src, [("A", "1", "0")], ["ch0"], (3, 1) + base.shape, scale=(1, 1, 0.2, 0.1, 0.1))
+    pos = io.open_ome_zarr(src / "A/1/0")
+    for t, r in enumerate(rolls):
+        pos.data[t, 0] = np.roll(base, r, axis=(0, 1, 2))
+    cfg = tmp_path / "est.yml"
+    cfg.write_text("stabilization_estimation_channel: ch0\nstabilization_channels: [ch0]\nstabilization_type: xyz\n"
+                   "stabilization_method: phase-cross-corr\nphase_cross_corr_settings:\n  normalization: magnitude\n"
+                   "verbose: true\n")
+    out = tmp_path / "stab_est"
+    r = CliRunner()
+    res = r.invoke(cli, ["estimate-stabilization", "-i", str(src / "A/1/0"), "-o", str(out), "-c", str(cfg), "--local"])
+    assert res.exit_code == 0, res.output
+    yml = out / "xyz_stabilization_settings" / "A_1_0.yml"
+    est = yaml.safe_load(yml.read_text())
+    mats = np.array(est["affine_transform_zyx_list"])
+    assert mats.shape == (3, 4, 4) and np.array_equal(mats[0], np.eye(4))
+    # get_tform_from_pcc correlates frame t against frame 0 and files the shift as (dx, dy, dz) (estimate_stabilization.py:288-305)
+    stack = np.stack([np.roll(base, r_, axis=(0, 1, 2)) for r_ in rolls])
+    for t in (1, 2):
+        want, _, _ = O.get_tform_from_pcc(t, stack, np.broadcast_to(stack[0], stack.shape), "custom", "magnitude")
+        assert np.array_equal(mats[t], want) and np.array_equal(mats[t][:3, 3], np.array(rolls[t], float)[::-1])
+    assert (out / "shifts_per_position" / "A_1_0.csv").exists() and not (out / "transforms_per_position").exists()
+    assert est["stabilization_method"] == "phase-cross-corr" and est["output_voxel_size"] == [1, 1, 0.2, 0.1, 0.1]
+    res = r.invoke(cli, ["stabilize", "-i", str(src / "A/1/0"), "-c", str(yml), "-o", str(tmp_path / "stab.zarr"), "--local"])
+    assert res.exit_code == 0, res.output
+    cfg.write_text("stabilization_estimation_channel: ch0\nstabilization_channels: [ch0]\nstabilization_type: z\n")
+    res = r.invoke(cli, ["estimate-stabilization", "-i", str(src / "A/1/0"), "-o", str(out), "-c", str(cfg)])
+    assert res.exit_code != 0 and "not available" in res.output

@@ -160,3 +160,19 @@ def test_detect_peaks_golden():
         val, idx = O.block_peaks(z[f"vol{j}"], kw["blur_kernel_size"], kw["block_size"])
         assert np.array_equal(val, z[f"pool_val{j}"]) and np.array_equal(idx, z[f"pool_idx{j}"])
         assert np.array_equal(O.detect_peaks(z[f"vol{j}"], **kw), z[f"peaks{j}"])
+
+
+def test_pcc_chain_golden():
+    """phase_cross_corr_padding / get_tform_from_pcc through the oracle (estimate_stabilization.py:129-196, 259-310)."""
+    z = np.load(GOLDEN / "pcc_chain.npz")
+    for j in range(3):
+        for norm in (None, "magnitude"):
+            peak, corr = O.phase_cross_corr_padding(z[f"ref{j}"], z[f"mov{j}"], normalization=norm)
+            assert tuple(peak) == tuple(z[f"peak{j}_{norm}"]) and corr.shape == z[f"corr{j}_{norm}"].shape
+            assert rel_err(corr, z[f"corr{j}_{norm}"]) <= 1e-5
+    stack = z["stack"]
+    first = np.broadcast_to(stack[0], stack.shape)
+    for t in (1, 2):
+        for ft in ("custom", "custom_padding"):
+            tr, sh, _ = O.get_tform_from_pcc(t, stack, first, ft, "magnitude")
+            assert np.array_equal(tr, z[f"tform{t}_{ft}"]) and np.array_equal(np.asarray(sh, float), z[f"tshift{t}_{ft}"])
