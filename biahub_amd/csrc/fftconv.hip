@@ -20,6 +20,8 @@
 // registers prefetch tile t+1 from HBM while the FFT of tile t runs out of LDS.
 #include "common.hpp"
 
+#include <mutex>
+
 #include <cmath>
 #include <vector>
 
@@ -868,7 +870,8 @@ bool fftconv_supported(int64_t Z, int64_t Y, int64_t X) {
     return xlds <= 160 * 1024;
 }
 
-static std::map<std::tuple<int, int64_t, int64_t, int64_t>, ConvPlan> g_plans;
+static std::map<std::tuple<int, int64_t, int64_t, int64_t>, ConvPlan> g_plans;  // twiddle tables per (device, shape): a few KiB, never freed
+static std::mutex g_plans_mu;                                                    // contexts of different threads share the cache
 
 static int upload(const std::vector<cf>& h, cf** dptr) {
     BH_CHECK_HIP(hipMalloc(dptr, h.size() * sizeof(cf) + 16));
@@ -877,6 +880,7 @@ static int upload(const std::vector<cf>& h, cf** dptr) {
 }
 
 int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
+    std::lock_guard<std::mutex> lock(g_plans_mu);
     auto key = std::make_tuple(ctx->device, Z, Y, X);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) {
