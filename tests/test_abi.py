@@ -75,3 +75,34 @@ def test_product_never_imports_oracle():
     pat = re.compile(r"^\s*(from|import)\s+oracle\b|importlib.*oracle|__import__\(.*oracle", re.M)
     for p in (ROOT / "biahub_amd").rglob("*.py"):
         assert not pat.search(p.read_text()), f"{p} imports the oracle"
+
+
+def _build_c_host(tmp_path):
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    exe = tmp_path / "c_host"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / "examples" / "c_host.c"),
+                    f"-L{ROOT / 'biahub_amd'}", "-lbhcore", f"-Wl,-rpath,{ROOT / 'biahub_amd'}", "-lm", "-o", str(exe)],
+                   check=True)
+    return exe
+
+
+def test_plain_c_host_links_and_queries_geometry(tmp_path):
+    """The boundary is a C-ABI: a C99 program with only include/bhcore.h links the library and runs the host-only calls."""
+    import subprocess
+
+    r = subprocess.run([str(_build_c_host(tmp_path))], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "deskewed shape (86, 256, 380)" in r.stdout and "invalid geometry refused" in r.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_host_runs_deskew_on_gpu(tmp_path):
+    import subprocess
+
+    r = subprocess.run([str(_build_c_host(tmp_path)), "gpu"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "fill value 499.9" in r.stdout or "fill value 500.0" in r.stdout
