@@ -124,6 +124,117 @@ __global__ __launch_bounds__(FF_NT) void median_z_kernel(const TIN* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 8 / 16-bit input (camera data): two-pass byte-radix selection with per-pixel histograms instead of 16 bit sweeps.
+// A workgroup owns 128 neighbouring pixels of an image row; lane l of every wave owns pixels 2l and 2l + 1 and counts
+// them in the two 16-bit halves of hist[bin][l] (256 x 64 words = 64 KiB; Z <= 65535 so a half never overflows).  The
+// bank of a counter is its lane, so the LDS atomics are conflict-free whatever the data.  Pass 1 histograms the high
+// byte and finds, per pixel, the bins holding the two middle ranks; pass 2 re-reads the 128 columns (L2 hits) and
+// histograms the low byte of the samples in the first bin (and keeps the smallest low byte of the second bin, for the
+// rare pixel whose two middle samples straddle a bin boundary).
+constexpr int FH_NT = 512, FH_COLS = 128, FH_NW = FH_NT / 64, FH_U = 16;  // 2 workgroups x 8 waves x 16 row loads in flight per CU
+
+template <typename TIN>
+__global__ __launch_bounds__(FH_NT) void median_hist_kernel(const TIN* __restrict__ in, int Z, int Y, int X, int tiles_x,
+                                                            double* __restrict__ pattern) {
+    using K = FfKey<TIN>;
+    __shared__ __attribute__((aligned(16))) unsigned hist[256 * 64];
+    __shared__ unsigned short sb1[FH_COLS], sb2[FH_COLS], sr1[FH_COLS];
+    __shared__ unsigned minlo[FH_COLS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t plane = (size_t)Y * X;
+    const int k = (Z - 1) >> 1, k2 = Z >> 1;  // the two middle ranks (equal for odd Z)
+    const bool paired = (X & 1) == 0;          // pixel pairs are naturally aligned: one load per pair
+    for (int tile = blockIdx.x; tile < tiles_x * Y; tile += gridDim.x) {
+        const int y = tile / tiles_x, x0 = (tile - y * tiles_x) * FH_COLS;
+        const int ca = min(x0 + 2 * lane, paired ? X - 2 : X - 1), cb = min(ca + 1, X - 1);
+        const TIN* src = in + (size_t)y * X;
+        auto load2 = [&](int z, unsigned& ka, unsigned& kb) {
+            const TIN* row = src + (size_t)z * plane;
+            if (paired) {
+                struct alignas(2 * sizeof(TIN)) Pair { TIN a, b; };
+                const Pair v = *reinterpret_cast<const Pair*>(row + ca);
+                ka = K::to(v.a), kb = K::to(v.b);
+            } else {
+                ka = K::to(row[ca]), kb = K::to(row[cb]);
+            }
+        };
+        for (int i = threadIdx.x; i < 256 * 16; i += FH_NT) reinterpret_cast<uint4*>(hist)[i] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x < FH_COLS) minlo[threadIdx.x] = 0xffffffffu;
+        __syncthreads();
+        // pass 1: high byte
+        for (int z0 = wave; z0 < Z; z0 += FH_NW * FH_U) {
+            unsigned ka[FH_U], kb[FH_U];
+#pragma unroll
+            for (int u = 0; u < FH_U; ++u) load2(min(z0 + FH_NW * u, Z - 1), ka[u], kb[u]);
+#pragma unroll
+            for (int u = 0; u < FH_U; ++u)
+                if (z0 + FH_NW * u < Z) {
+                    atomicAdd(&hist[(ka[u] >> 8) * 64 + lane], 1u);
+                    atomicAdd(&hist[(kb[u] >> 8) * 64 + lane], 0x10000u);
+                }
+        }
+        __syncthreads();
+        if (threadIdx.x < FH_COLS) {  // one thread per pixel: the bins of ranks k and k2
+            const int c = threadIdx.x, l = c >> 1, sh = (c & 1) * 16;
+            unsigned cum = 0, b1 = 0, b2 = 0, r1 = 0;
+            bool f1 = false, f2 = false;
+            for (int b0 = 0; b0 < 256; b0 += 8) {  // eight independent LDS reads in flight per step
+                unsigned n[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) n[u] = (hist[(b0 + u) * 64 + l] >> sh) & 0xffffu;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (!f1 && cum + n[u] > (unsigned)k) f1 = true, b1 = b0 + u, r1 = (unsigned)k - cum;
+                    if (!f2 && cum + n[u] > (unsigned)k2) f2 = true, b2 = b0 + u;
+                    cum += n[u];
+                }
+            }
+            sb1[c] = (unsigned short)b1, sb2[c] = (unsigned short)b2, sr1[c] = (unsigned short)r1;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 256 * 16; i += FH_NT) reinterpret_cast<uint4*>(hist)[i] = make_uint4(0, 0, 0, 0);
+        const unsigned a1 = sb1[2 * lane], a2 = sb2[2 * lane], c1 = sb1[2 * lane + 1], c2 = sb2[2 * lane + 1];
+        __syncthreads();
+        // pass 2: low byte of the samples in bin b1; smallest low byte of bin b2 when it is another bin
+        for (int z0 = wave; z0 < Z; z0 += FH_NW * FH_U) {
+            unsigned ka[FH_U], kb[FH_U];
+#pragma unroll
+            for (int u = 0; u < FH_U; ++u) load2(min(z0 + FH_NW * u, Z - 1), ka[u], kb[u]);
+#pragma unroll
+            for (int u = 0; u < FH_U; ++u)
+                if (z0 + FH_NW * u < Z) {
+                    if ((ka[u] >> 8) == a1) atomicAdd(&hist[(ka[u] & 255u) * 64 + lane], 1u);
+                    else if ((ka[u] >> 8) == a2) atomicMin(&minlo[2 * lane], ka[u] & 255u);
+                    if ((kb[u] >> 8) == c1) atomicAdd(&hist[(kb[u] & 255u) * 64 + lane], 0x10000u);
+                    else if ((kb[u] >> 8) == c2) atomicMin(&minlo[2 * lane + 1], kb[u] & 255u);
+                }
+        }
+        __syncthreads();
+        if (threadIdx.x < FH_COLS && x0 + (int)threadIdx.x < X) {
+            const int c = threadIdx.x, l = c >> 1, sh = (c & 1) * 16;
+            const unsigned b1 = sb1[c], b2 = sb2[c], r1 = sr1[c];
+            unsigned cum = 0, lo1 = 0, lo2 = 0;
+            bool f1 = false, f2 = false;
+            for (int b0 = 0; b0 < 256; b0 += 8) {
+                unsigned n[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) n[u] = (hist[(b0 + u) * 64 + l] >> sh) & 0xffffu;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (!f1 && cum + n[u] > r1) f1 = true, lo1 = b0 + u;
+                    if (!f2 && cum + n[u] > r1 + 1) f2 = true, lo2 = b0 + u;  // the next rank, if in the same high-byte bin
+                    cum += n[u];
+                }
+            }
+            const unsigned v1 = (b1 << 8) | lo1;
+            const unsigned v2 = (Z & 1) ? v1 : (b2 == b1 ? ((b1 << 8) | lo2) : ((b2 << 8) | minlo[c]));
+            pattern[(size_t)y * X + x0 + c] = (Z & 1) ? K::from(v1) : (K::from(v1) + K::from(v2)) * 0.5;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void ff_sum_partial_kernel(const double* __restrict__ v, long long n,
                                                              double* __restrict__ part) {
     double a = 0;
@@ -210,7 +321,26 @@ static int dispatch_median_nt(bh_ctx* ctx, const void* in, int dtype, int64_t Z,
     return BH_OK;
 }
 
+template <typename TIN>
+static int run_median_hist(bh_ctx* ctx, const TIN* in, int64_t Z, int64_t Y, int64_t X, double* pattern) {
+    const int tiles_x = (int)ceil_div(X, FH_COLS);
+    const int grid = (int)std::min<int64_t>((int64_t)tiles_x * Y, (int64_t)ctx->num_cus * 2);
+    hipLaunchKernelGGL(median_hist_kernel<TIN>, dim3(grid), dim3(FH_NT), 0, ctx->stream, in, (int)Z, (int)Y, (int)X, tiles_x,
+                       pattern);
+    BH_CHECK_HIP(hipGetLastError());
+    return BH_OK;
+}
+
 static int dispatch_median(bh_ctx* ctx, const void* in, int dtype, int64_t Z, int64_t Y, int64_t X, double* pattern) {
+    static const bool bitsearch = getenv("BH_FF_BITSEARCH") != nullptr;  // force the bit-search kernel (tests, comparison)
+    if (!bitsearch && dtype != BH_DT_F32 && Z <= 65535 && X >= 2) {
+        switch (dtype) {
+            case BH_DT_U8: return run_median_hist(ctx, (const uint8_t*)in, Z, Y, X, pattern);
+            case BH_DT_U16: return run_median_hist(ctx, (const uint16_t*)in, Z, Y, X, pattern);
+            case BH_DT_I16: return run_median_hist(ctx, (const int16_t*)in, Z, Y, X, pattern);
+            default: BH_REQUIRE(false, "unsupported input dtype code %d", dtype);
+        }
+    }
     // measured (tools/time_ops.py flatfield): 32-bit keys want 16 waves per workgroup, 16-bit keys 8
     static const int forced = getenv("BH_FF_NT") ? atoi(getenv("BH_FF_NT")) : 0;
     const int nt = forced ? forced : (dtype == BH_DT_F32 ? 1024 : 512);
