@@ -332,7 +332,7 @@ static int run_median_hist(bh_ctx* ctx, const TIN* in, int64_t Z, int64_t Y, int
 }
 
 static int dispatch_median(bh_ctx* ctx, const void* in, int dtype, int64_t Z, int64_t Y, int64_t X, double* pattern) {
-    static const bool bitsearch = getenv("BH_FF_BITSEARCH") != nullptr;  // force the bit-search kernel (tests, comparison)
+    const bool bitsearch = getenv("BH_FF_BITSEARCH") != nullptr;  // force the bit-search kernel (tests, comparison)
     if (!bitsearch && dtype != BH_DT_F32 && Z <= 65535 && X >= 2) {
         switch (dtype) {
             case BH_DT_U8: return run_median_hist(ctx, (const uint8_t*)in, Z, Y, X, pattern);

@@ -495,8 +495,11 @@ def test_estimate_registration_recovers_similarity(gpu):
 
 
 # ----------------------------------------------------------------------------- flat field (N3)
-def test_flat_field_golden_and_oracle(gpu):
-    """bh_median_z is np.median exactly; bh_flat_field matches the reference expression (float32 output)."""
+@pytest.mark.parametrize("bitsearch", [False, True])
+def test_flat_field_golden_and_oracle(gpu, monkeypatch, bitsearch):
+    """bh_median_z is np.median exactly (both selection kernels); bh_flat_field matches the reference expression."""
+    if bitsearch:
+        monkeypatch.setenv("BH_FF_BITSEARCH", "1")  # 8/16-bit input through the bit-search kernel too
     from biahub_amd.flat_field import _flat_field_czyx, _median_tiled, flat_field_zyx, median_z_device
 
     z = np.load(GOLDEN / "flat_field.npz")
