@@ -290,6 +290,8 @@ int fftconv_apply(bh_ctx* ctx, const ConvPlan& pl, const float* in, const cf* ot
                   int epilogue, const float* aux, float eps, float* out);
 int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, const cf* otf, cf* spec, int iterations,
                             float eps, float* est);
+int fftconv_forward(bh_ctx* ctx, const ConvPlan& pl, const float* in, cf* spec);
+int fftconv_inverse(bh_ctx* ctx, const ConvPlan& pl, cf* spec, float* out);
 int fftconv_tikhonov(bh_ctx* ctx, const ConvPlan& pl, const float* in, const float* tf_full, float reg, cf* spec,
                      float* filt, float* out);
 
@@ -446,25 +448,41 @@ int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t
     // volume comes back with X - 1 columns; the same half spectrum is inverted by a (Z, Y, Xc) plan here.
     const int64_t Xc = (X & 1) ? X - 1 : X;
     BH_REQUIRE(Xc >= 2, "X must be at least 2");
-    FftPlans *pl, *plc;
-    BH_TRY(get_plans(ctx, Z, Y, X, &pl));
-    BH_TRY(get_plans(ctx, Z, Y, Xc, &plc));
-    const int64_t V = Z * Y * Xc, Xh = X / 2 + 1, NS = Z * Y * Xh;
+    const int64_t V = Z * Y * Xc;
     cf *s1, *s2;
     float* corr;
     ArgMax *partial, *result;
     const int nblk = ctx->num_cus * 8;
-    BH_TRY(get_scratch(ctx, "fft_spec", NS * sizeof(cf), (void**)&s1));
-    BH_TRY(get_scratch(ctx, "pcc_spec2", NS * sizeof(cf), (void**)&s2));
     BH_TRY(get_scratch(ctx, "fft_real", Z * Y * X * sizeof(float), (void**)&corr));
     BH_TRY(get_scratch(ctx, "pcc_partial", (nblk + 1) * sizeof(ArgMax), (void**)&partial));
     result = partial + nblk;
     hipStream_t s = ctx->stream;
-    BH_CHECK_FFT(hipfftExecR2C(pl->r2c, const_cast<float*>(ref), (hipfftComplex*)s1));
-    BH_CHECK_FFT(hipfftExecR2C(pl->r2c, const_cast<float*>(mov), (hipfftComplex*)s2));
-    hipLaunchKernelGGL(pcc_product_kernel, grid_for(ctx, NS), dim3(256), 0, s, s1, s2, NS, normalization,
-                       (float)(1.0 / (double)V));
-    BH_CHECK_FFT(hipfftExecC2R(plc->c2r, (hipfftComplex*)s1, corr));
+    if (use_fused_engine(Z, Y, X)) {
+        // power-of-two volume: six in-place passes each way on the fused engine instead of hipFFT's transposing pipeline
+        ConvPlan* cp;
+        BH_TRY(fftconv_plan(ctx, Z, Y, X, &cp));
+        const size_t NSf = fftconv_spectrum_elems(*cp);
+        BH_TRY(get_scratch(ctx, "fc_spec", NSf * sizeof(cf), (void**)&s1));
+        BH_TRY(get_scratch(ctx, "pcc_spec2", NSf * sizeof(cf), (void**)&s2));
+        BH_TRY(fftconv_forward(ctx, *cp, ref, s1));
+        BH_TRY(fftconv_forward(ctx, *cp, mov, s2));
+        const int64_t nprod = (int64_t)NSf - 64;  // Z * Y * XP stored coefficients (pad columns are zero), not the tail slack
+        hipLaunchKernelGGL(pcc_product_kernel, grid_for(ctx, nprod), dim3(256), 0, s, s1, s2, nprod, normalization,
+                           (float)(2.0 / (double)V));
+        BH_TRY(fftconv_inverse(ctx, *cp, s1, corr));
+    } else {
+        FftPlans *pl, *plc;
+        BH_TRY(get_plans(ctx, Z, Y, X, &pl));
+        BH_TRY(get_plans(ctx, Z, Y, Xc, &plc));
+        const int64_t Xh = X / 2 + 1, NS = Z * Y * Xh;
+        BH_TRY(get_scratch(ctx, "fft_spec", NS * sizeof(cf), (void**)&s1));
+        BH_TRY(get_scratch(ctx, "pcc_spec2", NS * sizeof(cf), (void**)&s2));
+        BH_CHECK_FFT(hipfftExecR2C(pl->r2c, const_cast<float*>(ref), (hipfftComplex*)s1));
+        BH_CHECK_FFT(hipfftExecR2C(pl->r2c, const_cast<float*>(mov), (hipfftComplex*)s2));
+        hipLaunchKernelGGL(pcc_product_kernel, grid_for(ctx, NS), dim3(256), 0, s, s1, s2, NS, normalization,
+                           (float)(1.0 / (double)V));
+        BH_CHECK_FFT(hipfftExecC2R(plc->c2r, (hipfftComplex*)s1, corr));
+    }
     hipLaunchKernelGGL(pcc_argmax_kernel, dim3(nblk), dim3(256), 0, s, corr, corr_shifted, Z, Y, Xc, partial);
     hipLaunchKernelGGL(pcc_argmax_final_kernel, dim3(1), dim3(256), 0, s, partial, nblk, result);
     BH_CHECK_HIP(hipGetLastError());

@@ -1111,6 +1111,23 @@ int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, con
     return BH_OK;
 }
 
+// Bare transform pair for callers that do their own spectral arithmetic (phase cross-correlation): forward leaves the
+// true DFT coefficients in the engine's scrambled half-spectrum layout, inverse returns real space scaled by V/2
+// (multiply the spectrum by 2/V first for a normalised irfftn).  Any element-wise operation that treats both spectra
+// alike is layout-agnostic.
+int fftconv_forward(bh_ctx* ctx, const ConvPlan& pl, const float* in, cf* spec) {
+    BH_TRY(launch_x(ctx, pl, false, 0, in, spec, nullptr, nullptr, 0.f));
+    BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));
+    BH_TRY(launch_col(ctx, pl, COL_FWD, true, spec, nullptr, 1.f));
+    return BH_OK;
+}
+int fftconv_inverse(bh_ctx* ctx, const ConvPlan& pl, cf* spec, float* out) {
+    BH_TRY(launch_col(ctx, pl, COL_INV, true, spec, nullptr, 1.f));
+    BH_TRY(launch_col(ctx, pl, COL_INV, false, spec, nullptr, 1.f));
+    BH_TRY(launch_x(ctx, pl, true, XE_STORE, nullptr, spec, out, nullptr, 0.f));
+    return BH_OK;
+}
+
 // out = irfft( rfft(in) * H/(H^2+reg) ), H = tf_full (natural order, real, even)
 int fftconv_tikhonov(bh_ctx* ctx, const ConvPlan& pl, const float* in, const float* tf_full, float reg, cf* spec,
                      float* filt, float* out) {

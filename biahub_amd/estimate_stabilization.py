@@ -19,12 +19,9 @@ from . import _lib
 from .device import as_device_volume, get_context, ptr, resolve_device
 
 
-def phase_cross_corr(ref_img, mov_img, normalization=None, output_path=None, verbose: bool = False, device="cuda"):
-    """Translation between two equally shaped 3-D images: ``(shift, corr_shifted)`` like the reference.
-
-    ``shift`` is a float32 array (the signed location of max |corr|), ``corr_shifted = fftshift(|corr|)``.
-    ``normalization`` is ``None``, ``"magnitude"`` or ``"classic"`` (estimate_stabilization.py:233-238).
-    """
+def phase_cross_corr_device(ref_img, mov_img, normalization=None, device="cuda", want_corr: bool = True):
+    """Device-level correlation: ``(shift float32[3], corr tensor or None)``.  With ``want_corr=False`` the correlation
+    volume is neither written nor copied (a 1-GB volume costs ~80 ms to bring to the host; the shift costs nothing)."""
     if normalization not in _lib.PCC_NORM:
         raise ValueError(f"unknown normalization {normalization!r}")
     dev = resolve_device(device if not isinstance(ref_img, torch.Tensor) else ref_img.device)
@@ -38,10 +35,20 @@ def phase_cross_corr(ref_img, mov_img, normalization=None, output_path=None, ver
     shift = (C.c_float * 3)()
     with torch.cuda.device(dev):
         # irfftn without a shape: an odd last axis comes back one shorter (the reference's behaviour, kept)
-        corr = torch.empty((Z, Y, X - (X & 1)), dtype=torch.float32, device=dev)
+        corr = torch.empty((Z, Y, X - (X & 1)), dtype=torch.float32, device=dev) if want_corr else None
         _lib.check(ctx.lib.bh_phase_cross_corr(ctx.handle, ptr(a), ptr(b), Z, Y, X, _lib.PCC_NORM[normalization],
-                                               shift, ptr(corr)))
-    return np.array(list(shift), dtype=np.float32), corr.cpu().numpy()
+                                               shift, ptr(corr) if want_corr else None))
+    return np.array(list(shift), dtype=np.float32), corr
+
+
+def phase_cross_corr(ref_img, mov_img, normalization=None, output_path=None, verbose: bool = False, device="cuda"):
+    """Translation between two equally shaped 3-D images: ``(shift, corr_shifted)`` like the reference.
+
+    ``shift`` is a float32 array (the signed location of max |corr|), ``corr_shifted = fftshift(|corr|)``.
+    ``normalization`` is ``None``, ``"magnitude"`` or ``"classic"`` (estimate_stabilization.py:233-238).
+    """
+    shift, corr = phase_cross_corr_device(ref_img, mov_img, normalization, device, want_corr=True)
+    return shift, corr.cpu().numpy()
 
 
 # ----------------------------------------------------------------------------- padding variant and the per-position chain
@@ -93,7 +100,7 @@ def phase_cross_corr_padding(ref_img, mov_img, maximum_shift: float = 1.2, norma
 
 
 def get_tform_from_pcc(t: int, source_channel_tzyx, target_channel_tzyx, function_type: str = "custom", normalization=None,
-                       output_path=None, verbose: bool = False, device="cuda"):
+                       output_path=None, verbose: bool = False, device="cuda", want_corr: bool = True):
     """``estimate_stabilization.py:259-310``, kept as written: the image named ``target`` is read from the *source* stack
     and vice versa, and the shift lands as ``transform[0, 3] = dx, [1, 3] = dy, [2, 3] = dz``."""
     target = np.asarray(source_channel_tzyx[t]).astype(np.float32)
@@ -101,7 +108,10 @@ def get_tform_from_pcc(t: int, source_channel_tzyx, target_channel_tzyx, functio
     if function_type == "custom_padding":
         shift, corr = phase_cross_corr_padding(target, source, normalization=normalization, device=device)
     elif function_type == "custom":
-        shift, corr = phase_cross_corr(target, source, normalization=normalization, device=device)
+        if want_corr:
+            shift, corr = phase_cross_corr(target, source, normalization=normalization, device=device)
+        else:  # the per-position loop only reads the correlation volume for its verbose statistics
+            shift, corr = phase_cross_corr_device(target, source, normalization, device, want_corr=False)
     else:
         raise ValueError(f"unknown function_type {function_type!r}")
     if verbose:
@@ -154,7 +164,8 @@ def estimate_xyz_stabilization_pcc_per_position(input_position_dirpath, output_f
             shifts.append((t, 0, 0, 0))
             continue
         transform, shift, _corr = get_tform_from_pcc(t, source, target, function_type=s.function_type,
-                                                     normalization=s.normalization, verbose=verbose, device=device)
+                                                     normalization=s.normalization, verbose=verbose, device=device,
+                                                     want_corr=False)
         transforms.append(transform)
         shifts.append((t, *[float(v) for v in shift]))
     output_folder_path = Path(output_folder_path)

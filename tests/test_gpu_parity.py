@@ -418,6 +418,15 @@ def test_phase_cross_corr_golden_and_oracle(gpu):
         want, _ = O.phase_cross_corr(ref, mov, "magnitude")
         got, corr = phase_cross_corr(ref, mov, normalization="magnitude")
         assert np.array_equal(got, want) and corr.shape == ref.shape
+    # power-of-two volumes run on the fused FFT engine (scrambled half-spectrum), everything else on hipFFT: same answers
+    big = rng.random((32, 64, 128), dtype=np.float32)
+    for roll in ((0, 0, 0), (5, -20, 33), (-16, 32, -64)):
+        mov = np.roll(big, roll, axis=(0, 1, 2)) + 0.05 * rng.random(big.shape, dtype=np.float32)
+        for norm in (None, "magnitude", "classic"):
+            want, wcorr = O.phase_cross_corr(big, mov, norm)
+            got, corr = phase_cross_corr(big, mov, normalization=norm)
+            assert np.array_equal(got, want), (roll, norm, got, want)
+            assert rel_err(corr, wcorr) <= FFT_TOL, (roll, norm)
     with pytest.raises(ValueError):
         phase_cross_corr(ref, ref[:-1], normalization=None)
     with pytest.raises(ValueError):

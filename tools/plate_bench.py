@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 4 rehearsal: positions of a synthetic plate (T=4, C=2, 1024x1024x256) sharded by position,
-each (t, c) volume run through deskew -> Richardson-Lucy/Tikhonov deconvolve -> stabilize on the GPU.
+each (t, c) uint16 volume run through flat-field -> Richardson-Lucy/Tikhonov deconvolve -> deskew -> phase-cross-correlation
+drift estimate against t = 0 -> stabilize on the GPU (per-stage seconds are reported for rank 0).
 
     python tools/plate_bench.py --positions 8                     # one GPU
     torchrun --nproc-per-node 8 tools/plate_bench.py --positions 64
@@ -15,6 +16,8 @@ import numpy as np, torch
 from biahub_amd import parallel
 from biahub_amd.deconvolve import richardson_lucy, tikhonov_zyx, transfer_function_device
 from biahub_amd.deskew import fast_deskew_zyx, _fast_deskew_czyx
+from biahub_amd.estimate_stabilization import phase_cross_corr_device
+from biahub_amd.flat_field import flat_field_device
 from biahub_amd.register import affine_device
 
 ap = argparse.ArgumentParser()
@@ -42,21 +45,47 @@ shifts = [np.eye(4)] * args.T
 for t in range(args.T):
     m = np.eye(4); m[:3, 3] = (0.25 * t, -1.5 * t, 2.25 * t); shifts[t] = m
 
+stage = {"flat_field": 0.0, "deconvolve": 0.0, "deskew": 0.0, "estimate_shift": 0.0, "stabilize": 0.0}
+
+
+def timed(name, fn):
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize(dev)
+    stage[name] += time.perf_counter() - t0
+    return out
+
+
 def one_position(pos):
     gen = torch.Generator(device=dev).manual_seed(0xB1A0 + pos)
     n = 0
+    base = (torch.rand(shape, generator=gen, device=dev) * 400 + 100)
+    ref = {}
     for t in range(args.T):
         for c in range(args.C):
-            vol = (torch.rand(shape, generator=gen, device=dev) * 400 + 100).round_()
-            dec = richardson_lucy(vol, psf, 10, 1e-6) if args.deconv == "rl" else tikhonov_zyx(vol, tf, 1e-3)
-            dsk = fast_deskew_zyx(dec, **DK)
-            stab = affine_device(dsk, shifts[t], tuple(dsk.shape), "linear")
+            # the same scene drifting by (0, -2t, 3t) voxels, camera counts as uint16
+            raw = (torch.roll(base, (0, -2 * t, 3 * t), (0, 1, 2)) + 20 * c).round_().to(torch.uint16)
+            flat = timed("flat_field", lambda: flat_field_device(raw))
+            dec = timed("deconvolve", lambda: richardson_lucy(flat, psf, 10, 1e-6) if args.deconv == "rl"
+                        else tikhonov_zyx(flat, tf, 1e-3))
+            dsk = timed("deskew", lambda: fast_deskew_zyx(dec, **DK))
+            if t == 0:
+                ref[c] = flat
+                m = np.eye(4)
+            else:  # drift of the raw volume against t = 0 (estimate_stabilization.py:259-310), applied in deskewed space
+                sh, _ = timed("estimate_shift", lambda: phase_cross_corr_device(ref[c], flat, "magnitude", want_corr=False))
+                m = shifts[t]
+                assert tuple(sh) == (0.0, 2.0 * t, -3.0 * t), sh
+            stab = timed("stabilize", lambda: affine_device(dsk, m, tuple(dsk.shape), "linear"))
             n += V
-            del vol, dec, dsk, stab
+            del raw, dec, dsk, stab
     torch.cuda.synchronize(dev)
     return n
 
 one_position(10_000 + rank)  # warm-up: plans, OTF, allocator
+for k in stage:
+    stage[k] = 0.0
 parallel.barrier(); torch.cuda.synchronize(dev)
 t0 = time.perf_counter()
 st = parallel.process_positions(range(args.positions), one_position, rank, world)
@@ -64,9 +93,10 @@ torch.cuda.synchronize(dev); parallel.barrier()
 dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
 rows = parallel.gather_stats(st, dev)
 if rank == 0:
-    out = {"workload": f"{args.positions} positions x T={args.T} x C={args.C} x {shape}: {args.deconv} deconvolve -> deskew -> stabilize",
+    out = {"workload": f"{args.positions} positions x T={args.T} x C={args.C} x {shape}: flat-field -> {args.deconv} deconvolve -> deskew -> PCC drift -> stabilize",
            "n_gpus": world, "seconds": dt, "voxels_per_s_resident": sum(r.voxels for r in rows) / dt,
-           "positions_done": sum(r.n_done for r in rows), "positions_failed": sum(r.n_failed for r in rows)}
+           "positions_done": sum(r.n_done for r in rows), "positions_failed": sum(r.n_failed for r in rows),
+           "stage_seconds_rank0": {k: round(v, 4) for k, v in stage.items()}}
     # host boundary: numpy uint16 CZYX in -> numpy float32 CZYX out through the operator adapter (PCIe both ways)
     czyx = (np.random.default_rng(0).random((1,) + shape) * 400 + 100).astype(np.uint16)
     _fast_deskew_czyx(czyx, device=str(dev), **DK)
