@@ -106,3 +106,41 @@ def test_plain_c_host_runs_deskew_on_gpu(tmp_path):
     r = subprocess.run([str(_build_c_host(tmp_path)), "gpu"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "fill value 499.9" in r.stdout or "fill value 500.0" in r.stdout
+
+
+def test_invalid_arguments_return_status_not_crash(lib_built):
+    """Every entry point validates its arguments before touching the device: BH_ERR_INVALID + a message, on any host."""
+    from biahub_amd import _lib
+
+    lib = _lib.load()
+    I64x3, F64x3, Ix3 = C.c_int64 * 3, C.c_double * 3, C.c_int * 3
+    bad = [
+        lib.bh_deskew(None, None, _lib.DT_F32, 4, 4, 4, 30.0, 0.5, 1, 1, 0, 0.0, None, None),
+        lib.bh_overhang_fill(None, None, 4, 4, 4, 1, 0.0, 3, None),
+        lib.bh_richardson_lucy(None, None, None, 3, 3, 3, 8, 8, 8, 10, 1e-6, None),
+        lib.bh_tikhonov(None, None, None, 8, 8, 8, 1e-3, None),
+        lib.bh_transfer_function(None, None, 3, 3, 3, 8, 8, 8, None),
+        lib.bh_phase_cross_corr(None, None, None, 8, 8, 8, 0, None, None),
+        lib.bh_affine(None, None, _lib.DT_F32, 4, 4, 4, None, 1, 0, 0.0, None, 4, 4, 4, None),
+        lib.bh_crop_flip(None, None, 4, 1, 4, 4, 4, None, 2, 2, 2, 0, 0, 0, None),
+        lib.bh_flat_field(None, None, _lib.DT_U16, 4, 4, 4, None, None, None),
+        lib.bh_median_z(None, None, _lib.DT_U16, 4, 4, 4, None),
+        lib.bh_image_stats(None, None, 4, 4, 4, None),
+        lib.bh_mattes_mi(None, None, 4, 4, 4, None, 4, 4, 4, None, None, 32, 1, 0, None, None, None),
+        lib.bh_sobel(None, None, 4, 4, 4, None),
+        lib.bh_patch_peaks(None, None, 4, 4, 4, None, 0, None, 2.0, None),
+        lib.bh_average_patches(None, None, 4, 4, 4, None, 1, None, 1, None),
+        lib.bh_smooth_shrink(None, None, 0, 4, 4, F64x3(0, 0, 0), Ix3(1, 1, 1), None, I64x3(), I64x3()),
+        lib.bh_smooth_shrink(None, None, 4, 4, 4, F64x3(0, 0, 0), Ix3(0, 1, 1), None, I64x3(), I64x3()),
+        lib.bh_block_peaks(None, None, 4, 4, 4, 2, Ix3(2, 2, 2), None, None, I64x3()),
+        lib.bh_ctx_destroy(None) if False else _lib.BH_ERR_INVALID,
+    ]
+    assert all(s == _lib.BH_ERR_INVALID for s in bad), bad
+    assert _lib.last_error()  # the thread-local message is set
+    # host-only geometry queries succeed without a context
+    shape, off = I64x3(), I64x3()
+    assert lib.bh_smooth_shrink(None, None, 13, 20, 31, F64x3(2, 1, 0), Ix3(3, 2, 1), None, shape, off) == _lib.BH_OK
+    assert tuple(shape) == (4, 10, 31) and tuple(off) == (1, 0, 0)
+    nb = I64x3()
+    assert lib.bh_block_peaks(None, None, 24, 40, 36, 3, Ix3(8, 8, 8), None, None, nb) == _lib.BH_OK
+    assert tuple(nb) == (4, 6, 5)  # torch: floor((N + 2*(b//2) - b) / b) + 1
