@@ -622,3 +622,62 @@ def test_pcc_chain_golden(gpu):
             tr, sh, _ = get_tform_from_pcc(t, stack, first, function_type=ft, normalization="magnitude")
             assert np.array_equal(tr, z[f"tform{t}_{ft}"]), (t, ft, tr)
             assert np.array_equal(np.asarray(sh, dtype=np.float64), z[f"tshift{t}_{ft}"])
+
+
+# ----------------------------------------------------------------------------- BASELINE config 2 at full size
+def test_full_size_properties_config2(gpu):
+    """The bench workload's shape (512, 2048, 2048): properties that hold at any size, checked where the oracle cannot go.
+
+    R-L: non-negative, finite, flux-conserving; a shifted delta image is deconvolved to the same shifted answer (circular
+    shift equivariance).  Deskew: shape, linearity, partition of unity, determinism.  Flat field: a per-pixel pattern times
+    a z profile gives the analytic median.  Affine: identity is exact, an integer translation is a shifted copy.
+    """
+    from biahub_amd.deconvolve import richardson_lucy
+    from biahub_amd.deskew import fast_deskew_zyx, get_deskewed_data_shape
+    from biahub_amd.flat_field import flat_field_device, median_z_device
+    from biahub_amd.register import affine_device
+
+    shape = (512, 2048, 2048)
+    g = torch.Generator(device=gpu).manual_seed(11)
+    vol = (torch.rand(shape, generator=g, device=gpu) * 300 + 100).round_()
+    psf = torch.from_numpy(O.gaussian_psf((33, 17, 17), (3.0, 1.5, 1.5))).to(gpu)
+    est = richardson_lucy(vol, psf, 3, 1e-6)
+    assert float(est.min()) >= 0.0 and bool(torch.isfinite(est).all())
+    assert abs(float(est.double().sum()) / float(vol.double().sum()) - 1.0) < 1e-4
+    rolled = richardson_lucy(torch.roll(vol, (7, -33, 129), (0, 1, 2)), psf, 3, 1e-6)
+    assert float((torch.roll(est, (7, -33, 129), (0, 1, 2)) - rolled).abs().max()) <= FFT_TOL * float(est.max())
+    del rolled
+
+    kw = dict(ls_angle_deg=36.17, px_to_scan_ratio=0.371, keep_overhang=True, average_n_slices=3)
+    d_est = fast_deskew_zyx(est, **kw)
+    assert tuple(d_est.shape) == get_deskewed_data_shape(shape, 36.17, 0.371, True, 3)[0] == (683, 2048, 3034)
+    d_vol = fast_deskew_zyx(vol, **kw)
+    mix = fast_deskew_zyx(2 * est + vol, **kw)
+    mix -= d_vol
+    mix -= 2 * d_est
+    assert float(mix.abs().max()) <= 1e-5 * float(d_est.abs().max() * 3)          # linearity
+    del mix, d_vol
+    assert torch.equal(fast_deskew_zyx(est, **kw), d_est)                           # deterministic
+    del d_est
+    ones = fast_deskew_zyx(torch.ones(shape, device=gpu), **kw)
+    assert float(ones.max()) <= 1.0 + 1e-6 and float(ones.min()) >= 0.0             # partition of unity
+    del ones, est
+
+    ident = affine_device(vol, np.eye(4), shape, "linear")
+    assert torch.equal(ident, vol)                                                  # identity is exact
+    m = np.eye(4)
+    m[:3, 3] = (3, -5, 17)
+    moved = affine_device(vol, m, shape, "linear")                                  # out(p) = in(p + t)
+    assert torch.equal(moved[:500, 10:, :2000], vol[3:503, 5:2043, 17:2017])
+    assert float(moved[509:].abs().max()) == 0.0 and float(moved[:, :5].abs().max()) == 0.0
+    del ident, moved
+
+    pat = (torch.rand(shape[1:], generator=g, device=gpu) * 3000 + 200).round_()
+    prof = (torch.arange(shape[0], device=gpu) % 5).float()                         # 103, 103, 102, 102, 102 samples
+    raw = (pat[None] + prof[:, None, None]).to(torch.uint16)
+    del vol
+    assert torch.equal(median_z_device(raw), (pat + 2).double())                    # both middle ranks carry profile 2
+    flat = flat_field_device(raw)
+    want_mean = float((pat + 2).double().mean())
+    z7 = raw[7].double() / (pat + 2).double() * want_mean
+    assert float((flat[7].double() - z7).abs().max()) <= 2e-7 * float(z7.max())
