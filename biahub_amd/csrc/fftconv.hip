@@ -280,7 +280,9 @@ __device__ __forceinline__ void radix16_step(cf* buf, int N, int logW, int P, in
 
 // R16: pair consecutive radix-4 steps into radix-16 steps (one column per thread); a leftover radix-4 step and
 // the radix-2 step of an odd log2(N) use <BPT, CPT>.
-template <bool INV, int BPT, int CPT, bool R16 = false>
+// SKIP2: leave out the h = 2 radix-4 step (last forward / first inverse; its twiddles are all 1) — the convolution
+// passes run it fused with the spectral multiply in registers (conv_mid_step).
+template <bool INV, int BPT, int CPT, bool R16 = false, bool SKIP2 = false>
 __device__ __forceinline__ void fft_lds(cf* buf, int N, int logN, int logW, int P, const cf* tw, int tid) {
     const bool odd = logN & 1;
     const int H0 = odd ? (N >> 2) : (N >> 1);
@@ -297,13 +299,13 @@ __device__ __forceinline__ void fft_lds(cf* buf, int N, int logN, int logW, int 
             radix16_step<false>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), t4 + (2 * H0 - 2 * (h >> 2)), tid);
             __syncthreads();
         }
-        for (; h >= 2; h >>= 2) {
+        for (; h >= (SKIP2 ? 8 : 2); h >>= 2) {
             radix4_step<false, BPT, CPT>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
             __syncthreads();
         }
     } else {
         const int hr = H0 >> (4 * n16);  // largest half-size left to plain radix-4 steps
-        for (int h = 2; h <= hr; h <<= 2) {
+        for (int h = SKIP2 ? 8 : 2; h <= hr; h <<= 2) {
             radix4_step<true, BPT, CPT>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
             __syncthreads();
         }
@@ -381,6 +383,7 @@ struct ColParams {
     int nouter;         // number of o values
     int ncoltiles;
     float scale;
+    int midfuse;        // fuse the unit-twiddle steps around the spectral product (BH_FC_NOZMID=1 turns it off)
 };
 
 // The prefetch registers are eight named float4 (not an array: hipcc keeps a loop-carried float4[8]
@@ -482,7 +485,71 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
         const bool col_ok = (ct * W_ + 2 * lane) < XP;  // pad columns of a ragged last tile are never stored
         __syncthreads();
         const long tn = t + gridDim.x;
-        if (HAS_OTF) {
+        if (HAS_OTF && !FC_R16 && p.midfuse) {
+            // This tile's OTF arrives behind the forward FFT, fetched in the order the fused middle step wants it:
+            // butterfly b = tid / LPS + s * RPR (s = 0, 1) covers rows 4b .. 4b + 3 of this lane's two columns.
+            // The h = 2 radix-4 steps at the end of the forward and the start of the inverse transform have unit
+            // twiddles and touch the same four rows, so forward step, spectral multiply and inverse step happen in
+            // registers: one LDS round trip and one barrier instead of three.
+            const int nbf = N_ >> 2;  // butterflies per column
+            {
+                const long tb_ = tile_base(t);
+#define BH_LDM(u)                                                                                                  \
+    {                                                                                                              \
+        const int row_ = min(4 * (r0 + (u >> 2) * RPR) + (u & 3), N_ - 1);                                         \
+        if (MODE == COL_FILTER) {                                                                                  \
+            const float2 f_ = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(otf) + tb_ + (long)row_ * row_stride); \
+            v##u = make_float4(f_.x, f_.x, f_.y, f_.y);                                                            \
+        } else {                                                                                                   \
+            v##u = *reinterpret_cast<const float4*>(otf + tb_ + (long)row_ * row_stride);                          \
+        }                                                                                                          \
+    }
+                BH_LDM(0) BH_LDM(1) BH_LDM(2) BH_LDM(3) BH_LDM(4) BH_LDM(5) BH_LDM(6) BH_LDM(7)
+#undef BH_LDM
+            }
+            fft_lds<false, 1, 2, false, true>(buf, N_, logN, logW, W_, tw, tid);
+#define BH_SPEC_MUL(a, b)                                                                                          \
+    (MODE == COL_FILTER ? make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w)                                  \
+     : MODE == COL_CONV ? make_float4(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x, a.z * b.z - a.w * b.w,         \
+                                      a.z * b.w + a.w * b.z)                                                       \
+                        : make_float4(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y, a.z * b.z + a.w * b.w,         \
+                                      a.w * b.z - a.z * b.w))
+#define BH_MID(S_, O0, O1, O2, O3)                                                                                 \
+    if (r0 + S_ * RPR < nbf) {                                                                                     \
+        float4* q_ = reinterpret_cast<float4*>(buf + (size_t)(4 * (r0 + S_ * RPR)) * W_ + 2 * lane);              \
+        const int st_ = W_ >> 1; /* float4 units per row */                                                        \
+        const float4 x0 = q_[0], x1 = q_[st_], x2 = q_[2 * st_], x3 = q_[3 * st_];                                 \
+        /* forward h = 2 step, unit twiddles: rows 4b .. 4b + 3 <- s02+s13, s02-s13, d02+d13, d02-d13 */         \
+        const float4 s02 = make_float4(x0.x + x2.x, x0.y + x2.y, x0.z + x2.z, x0.w + x2.w);                       \
+        const float4 d02 = make_float4(x0.x - x2.x, x0.y - x2.y, x0.z - x2.z, x0.w - x2.w);                       \
+        const float4 s13 = make_float4(x1.x + x3.x, x1.y + x3.y, x1.z + x3.z, x1.w + x3.w);                       \
+        const float4 e13 = make_float4(x1.x - x3.x, x1.y - x3.y, x1.z - x3.z, x1.w - x3.w);                       \
+        const float4 d13 = make_float4(e13.y, -e13.x, e13.w, -e13.z); /* * (-i) */                                 \
+        const float4 f0 = make_float4(s02.x + s13.x, s02.y + s13.y, s02.z + s13.z, s02.w + s13.w);                 \
+        const float4 f1 = make_float4(s02.x - s13.x, s02.y - s13.y, s02.z - s13.z, s02.w - s13.w);                 \
+        const float4 f2 = make_float4(d02.x + d13.x, d02.y + d13.y, d02.z + d13.z, d02.w + d13.w);                 \
+        const float4 f3 = make_float4(d02.x - d13.x, d02.y - d13.y, d02.z - d13.z, d02.w - d13.w);                 \
+        const float4 y0 = BH_SPEC_MUL(f0, O0), y1 = BH_SPEC_MUL(f1, O1), y2 = BH_SPEC_MUL(f2, O2),                 \
+                     y3 = BH_SPEC_MUL(f3, O3);                                                                     \
+        /* inverse h = 2 step, unit twiddles: rows <- A+C, B+D, A-C, B-D */                                        \
+        const float4 A = make_float4(y0.x + y1.x, y0.y + y1.y, y0.z + y1.z, y0.w + y1.w);                          \
+        const float4 B = make_float4(y0.x - y1.x, y0.y - y1.y, y0.z - y1.z, y0.w - y1.w);                          \
+        const float4 Cc = make_float4(y2.x + y3.x, y2.y + y3.y, y2.z + y3.z, y2.w + y3.w);                         \
+        const float4 e23 = make_float4(y2.x - y3.x, y2.y - y3.y, y2.z - y3.z, y2.w - y3.w);                       \
+        const float4 D = make_float4(-e23.y, e23.x, -e23.w, e23.z); /* * (+i) */                                   \
+        q_[0] = make_float4(A.x + Cc.x, A.y + Cc.y, A.z + Cc.z, A.w + Cc.w);                                       \
+        q_[st_] = make_float4(B.x + D.x, B.y + D.y, B.z + D.z, B.w + D.w);                                         \
+        q_[2 * st_] = make_float4(A.x - Cc.x, A.y - Cc.y, A.z - Cc.z, A.w - Cc.w);                                 \
+        q_[3 * st_] = make_float4(B.x - D.x, B.y - D.y, B.z - D.z, B.w - D.w);                                     \
+    }
+            BH_MID(0, v0, v1, v2, v3)
+            BH_MID(1, v4, v5, v6, v7)
+#undef BH_MID
+#undef BH_SPEC_MUL
+            __syncthreads();
+            if (tn < ntiles) BH_LOAD_TILE(S, tn)
+            fft_lds<true, 1, 2, false, true>(buf, N_, logN, logW, W_, tw, tid);
+        } else if (HAS_OTF) {
             // this tile's OTF arrives behind the forward FFT; the next tile's data behind the inverse FFT
             if (MODE == COL_FILTER) BH_LOAD_FILTER(t) else BH_LOAD_TILE(otf, t)
             fft_lds<false, 1, 2, FC_R16>(buf, N_, logN, logW, W_, tw, tid);
@@ -793,6 +860,10 @@ __global__ __launch_bounds__(FC_NT) void x_inv_kernel(XParams p) {
                 aux[u] = *reinterpret_cast<const float4*>(p.aux + trow0 * d.X + x_row_off(d, c, d.X, 4 * q));
             }
         };
+        // (Running the last inverse radix-4 step, the epilogue and the first forward radix-4 step on their common four legs
+        // in registers — two LDS round trips and two barriers fewer — was built and measured 0.7 ms per iteration SLOWER:
+        // the leg-ordered aux / est accesses are 8-B instead of 16-B per lane.  The same fusion does pay in the Z pass,
+        // where the unit-twiddle steps around the OTF product need no extra global traffic: BH_MID in col_pass_kernel.)
         if (FUSE) {
             if (EPI != XE_STORE) load_aux();
         } else if (FAST && tn < ntiles) {
@@ -968,6 +1039,7 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
         p.nouter = pl.d.Y;
     }
     p.logW = ilog2(p.W);
+    p.midfuse = getenv("BH_FC_NOZMID") == nullptr;
     p.ncoltiles = (int)ceil_div(pl.d.XP, p.W);
     BH_REQUIRE((long)p.N * p.W <= FC_TILE && (long)p.N * (p.W / 2) <= 16l * FC_NT && (FC_NT % (p.W / 2)) == 0,
                "internal: column tile %dx%d unsupported", p.N, p.W);
