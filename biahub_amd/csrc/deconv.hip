@@ -206,6 +206,65 @@ __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ est, co
     }
 }
 
+// ---- pad / fold: exact circular convolution at an awkward size N through FFTs of a friendly size P >= N + K - 1 ----
+// The zero-padded estimate convolved at size P is the LINEAR convolution; its samples that stick out of [0, N) by up to
+// elo voxels below and ehi above are folded back (n + N and n - N) to give the circular result at size N.
+struct FoldDims {
+    int64_t N[3], P[3];
+    int elo[3], ehi[3];  // reach of the kernel below index 0 / above index N-1
+};
+
+// dst (P-volume) <- zero-padded src (N-volume)
+__global__ __launch_bounds__(256) void pad_volume_kernel(const float* __restrict__ src, float* __restrict__ dst, FoldDims f) {
+    const int64_t total = f.P[0] * f.P[1] * f.P[2];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t x = i % f.P[2], y = (i / f.P[2]) % f.P[1], z = i / (f.P[2] * f.P[1]);
+        dst[i] = (z < f.N[0] && y < f.N[1] && x < f.N[2]) ? src[(z * f.N[1] + y) * f.N[2] + x] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ float fold_at(const float* __restrict__ lin, const FoldDims& f, int64_t z, int64_t y, int64_t x) {
+    // up to three source indices per axis: n, n + N (the part above N-1), P + n - N (the part below 0)
+    int64_t iz[3], iy[3], ix[3];
+    int nz = 0, ny = 0, nx = 0;
+    iz[nz++] = z;
+    if (z < f.ehi[0]) iz[nz++] = z + f.N[0];
+    if (z >= f.N[0] - f.elo[0]) iz[nz++] = f.P[0] + z - f.N[0];
+    iy[ny++] = y;
+    if (y < f.ehi[1]) iy[ny++] = y + f.N[1];
+    if (y >= f.N[1] - f.elo[1]) iy[ny++] = f.P[1] + y - f.N[1];
+    ix[nx++] = x;
+    if (x < f.ehi[2]) ix[nx++] = x + f.N[2];
+    if (x >= f.N[2] - f.elo[2]) ix[nx++] = f.P[2] + x - f.N[2];
+    float acc = 0.0f;
+    for (int a = 0; a < nz; ++a)
+        for (int b = 0; b < ny; ++b)
+            for (int c = 0; c < nx; ++c) acc += lin[(iz[a] * f.P[1] + iy[b]) * f.P[2] + ix[c]];
+    return acc;
+}
+
+// next (P-volume, zero outside the N box) <- d / max(fold(lin), eps)
+__global__ __launch_bounds__(256) void fold_ratio_kernel(const float* __restrict__ lin, const float* __restrict__ d,
+                                                         float* __restrict__ next, FoldDims f, float eps) {
+    const int64_t total = f.P[0] * f.P[1] * f.P[2];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t x = i % f.P[2], y = (i / f.P[2]) % f.P[1], z = i / (f.P[2] * f.P[1]);
+        float r = 0.0f;
+        if (z < f.N[0] && y < f.N[1] && x < f.N[2])
+            r = d[(z * f.N[1] + y) * f.N[2] + x] / fmaxf(fold_at(lin, f, z, y, x), eps);
+        next[i] = r;
+    }
+}
+
+// est (N-volume) <- max(est * fold(lin), 0)
+__global__ __launch_bounds__(256) void fold_update_kernel(const float* __restrict__ lin, float* __restrict__ est, FoldDims f) {
+    const int64_t total = f.N[0] * f.N[1] * f.N[2];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t x = i % f.N[2], y = (i / f.N[2]) % f.N[1], z = i / (f.N[2] * f.N[1]);
+        est[i] = fmaxf(est[i] * fold_at(lin, f, z, y, x), 0.0f);
+    }
+}
+
 // out <- max(in, 0)
 __global__ void clip_copy_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -530,6 +589,87 @@ int bh_tikhonov(bh_ctx* ctx, const float* in, const float* tf_full, int64_t Z, i
     return BH_OK;
 }
 
+static bool is_smooth(int64_t n) {  // only the radices hipFFT has native kernels for
+    for (int p : {2, 3, 5, 7})
+        while (n % p == 0) n /= p;
+    return n == 1;
+}
+static int64_t next_smooth(int64_t n) {
+    while (!is_smooth(n)) ++n;
+    return n;
+}
+
+// Richardson-Lucy for a volume with an awkward axis (a large prime factor makes hipFFT fall back to Bluestein: the
+// deskewed (342, 1024, 1517) runs 10x slower per voxel than a power of two).  Awkward axes are zero-padded to the next
+// 7-smooth P >= N + K - 1 and the wrapped-around part of the linear convolution is folded back, which is exactly the
+// circular convolution at size N the definition asks for; smooth axes keep P = N and wrap by themselves.
+static int richardson_lucy_padfold(bh_ctx* ctx, const float* d, const float* psf, int64_t pz, int64_t py, int64_t px,
+                                   int64_t Z, int64_t Y, int64_t X, const int64_t P[3], int iterations, float eps,
+                                   float* out) {
+    const int64_t N[3] = {Z, Y, X}, K[3] = {pz, py, px};
+    FoldDims conv, corr;
+    for (int a = 0; a < 3; ++a) {
+        conv.N[a] = corr.N[a] = N[a];
+        conv.P[a] = corr.P[a] = P[a];
+        const bool padded = P[a] != N[a];
+        conv.elo[a] = padded ? (int)(K[a] / 2) : 0;             // kernel taps sit at -K/2 .. K-1-K/2
+        conv.ehi[a] = padded ? (int)(K[a] - 1 - K[a] / 2) : 0;
+        corr.elo[a] = conv.ehi[a];                               // the correlation kernel is the mirror image
+        corr.ehi[a] = conv.elo[a];
+    }
+    const int64_t V = Z * Y * X, VP = P[0] * P[1] * P[2], NS = P[0] * P[1] * (P[2] / 2 + 1);
+    FftPlans* pl;
+    BH_TRY(get_plans(ctx, P[0], P[1], P[2], &pl));
+    float *ra, *rb;
+    cf *spec, *otf;
+    double* psum;
+    BH_TRY(get_scratch(ctx, "fft_real", VP * sizeof(float), (void**)&ra));
+    BH_TRY(get_scratch(ctx, "rl_real2", VP * sizeof(float), (void**)&rb));
+    BH_TRY(get_scratch(ctx, "fft_spec", NS * sizeof(cf), (void**)&spec));
+    BH_TRY(get_scratch(ctx, "rl_otf", NS * sizeof(cf), (void**)&otf));
+    BH_TRY(get_scratch(ctx, "rl_psum", 64, (void**)&psum));
+    hipStream_t s = ctx->stream;
+    ScopedTimer timer(ctx, T_RL_TOTAL);
+    BH_CHECK_HIP(hipMemsetAsync(ra, 0, VP * sizeof(float), s));
+    hipLaunchKernelGGL(psf_sum_kernel, dim3(1), dim3(256), 0, s, psf, pz * py * px, psum);
+    hipLaunchKernelGGL(place_psf_kernel, grid_for(ctx, pz * py * px), dim3(256), 0, s, psf, ra, (int)pz, (int)py, (int)px,
+                       P[0], P[1], P[2], 0, 0, 0, (int)(pz / 2), (int)(py / 2), (int)(px / 2), (const double*)psum);
+    BH_CHECK_FFT(hipfftExecR2C(pl->r2c, ra, (hipfftComplex*)otf));
+    hipLaunchKernelGGL(scale_spectrum_kernel, grid_for(ctx, NS), dim3(256), 0, s, otf, NS, (float)(1.0 / (double)VP));
+    hipLaunchKernelGGL(clip_copy_kernel, grid_for(ctx, V), dim3(256), 0, s, d, out, V);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing && iterations > 0) {
+        BH_CHECK_HIP(hipEventCreate(&e0));
+        BH_CHECK_HIP(hipEventCreate(&e1));
+        BH_CHECK_HIP(hipEventRecord(e0, s));
+    }
+    const int64_t n2 = NS / 2;
+    for (int it = 0; it < iterations; ++it) {
+        hipLaunchKernelGGL(pad_volume_kernel, grid_for(ctx, VP), dim3(256), 0, s, (const float*)out, ra, conv);
+        BH_CHECK_FFT(hipfftExecR2C(pl->r2c, ra, (hipfftComplex*)spec));
+        hipLaunchKernelGGL(cmul_kernel<false>, grid_for(ctx, n2), dim3(256), 0, s, spec, otf, n2);
+        if (NS & 1) hipLaunchKernelGGL(cmul_tail_kernel<false>, dim3(1), dim3(1), 0, s, spec, otf, NS - 1);
+        BH_CHECK_FFT(hipfftExecC2R(pl->c2r, (hipfftComplex*)spec, ra));
+        hipLaunchKernelGGL(fold_ratio_kernel, grid_for(ctx, VP), dim3(256), 0, s, (const float*)ra, d, rb, conv, eps);
+        BH_CHECK_FFT(hipfftExecR2C(pl->r2c, rb, (hipfftComplex*)spec));
+        hipLaunchKernelGGL(cmul_kernel<true>, grid_for(ctx, n2), dim3(256), 0, s, spec, otf, n2);
+        if (NS & 1) hipLaunchKernelGGL(cmul_tail_kernel<true>, dim3(1), dim3(1), 0, s, spec, otf, NS - 1);
+        BH_CHECK_FFT(hipfftExecC2R(pl->c2r, (hipfftComplex*)spec, ra));
+        hipLaunchKernelGGL(fold_update_kernel, grid_for(ctx, V), dim3(256), 0, s, (const float*)ra, out, corr);
+    }
+    BH_CHECK_HIP(hipGetLastError());
+    if (e0) {
+        BH_CHECK_HIP(hipEventRecord(e1, s));
+        BH_CHECK_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        BH_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ctx->ms_override[T_RL_ITER] = ms / iterations;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    return BH_OK;
+}
+
 int bh_richardson_lucy(bh_ctx* ctx, const float* in, const float* psf, int64_t pz, int64_t py, int64_t px, int64_t Z,
                        int64_t Y, int64_t X, int iterations, float eps, float* out) {
     BH_REQUIRE(ctx && in && psf && out, "NULL argument");
@@ -546,6 +686,17 @@ int bh_richardson_lucy(bh_ctx* ctx, const float* in, const float* psf, int64_t p
         d = dcopy;
     }
     if (use_fused_engine(Z, Y, X)) return richardson_lucy_fused(ctx, d, psf, pz, py, px, Z, Y, X, iterations, eps, out);
+    {
+        const int64_t N[3] = {Z, Y, X}, K[3] = {pz, py, px};
+        int64_t P[3];
+        bool padded = false;
+        for (int a = 0; a < 3; ++a) {
+            P[a] = is_smooth(N[a]) ? N[a] : next_smooth(N[a] + K[a] - 1);
+            padded = padded || P[a] != N[a];
+        }
+        if (padded && getenv("BH_RL_NOPAD") == nullptr)
+            return richardson_lucy_padfold(ctx, d, psf, pz, py, px, Z, Y, X, P, iterations, eps, out);
+    }
     FftPlans* pl;
     BH_TRY(get_plans(ctx, Z, Y, X, &pl));
     cf *spec, *otf;

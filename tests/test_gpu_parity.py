@@ -181,6 +181,32 @@ def test_richardson_lucy_vs_oracle(gpu, shape, pshape):
     assert c.shape == (2,) + shape and np.array_equal(c[0], c[1])
 
 
+@pytest.mark.parametrize("shape,pshape", [
+    ((37, 53, 71), (7, 5, 9)),      # every axis has a large prime factor: all three padded and folded
+    ((37, 53, 71), (4, 6, 8)),      # even PSF extents: the kernel reaches further below 0 than above N-1
+    ((32, 53, 64), (9, 7, 5)),      # only Y is awkward; Z and X wrap on their own
+    ((19, 40, 134), (5, 3, 11)),    # 134 = 2 * 67
+])
+def test_richardson_lucy_awkward_sizes_pad_fold(gpu, shape, pshape, monkeypatch):
+    """Axes with a large prime factor are zero-padded to a 7-smooth FFT size and the wrapped part of the linear
+    convolution folded back: the result is still the circular R-L at the true size (oracle), and equals the plain
+    hipFFT path at the awkward size (BH_RL_NOPAD=1)."""
+    from biahub_amd.deconvolve import richardson_lucy
+
+    vol = O.synthetic_volume(shape, seed=9, n_blobs=8)
+    vol[0, 0, :] += 500.0   # structure on the faces: a wrong fold shows up as a wrap-around error
+    vol[-1, :, -1] += 300.0
+    psf = O.gaussian_psf(pshape, tuple(max(p / 4.0, 0.8) for p in pshape))
+    psf[0, 0, 0] += 0.02    # asymmetric: convolution and correlation differ
+    want = O.richardson_lucy_zyx(vol, psf, iterations=6, eps=1e-6)
+    v, pt = torch.from_numpy(vol).to(gpu), torch.from_numpy(psf).to(gpu)
+    got = richardson_lucy(v, pt, 6, 1e-6).cpu().numpy()
+    assert rel_err(got, want) <= FFT_TOL, rel_err(got, want)
+    monkeypatch.setenv("BH_RL_NOPAD", "1")
+    plain = richardson_lucy(v, pt, 6, 1e-6).cpu().numpy()
+    assert rel_err(plain, want) <= FFT_TOL and rel_err(got, plain) <= FFT_TOL
+
+
 # ----------------------------------------------------------------------------- affine
 def test_affine_reference_tests(gpu):
     """tests/test_affine.py:26-59 of the reference, verbatim expectations."""
