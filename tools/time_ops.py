@@ -55,3 +55,27 @@ if which in ("all", "flatfield"):
         b = (2 * vol.element_size() + 4) * V
         print(f"flat_field {shape} {dt}: {ms:.2f} ms -> {b/ms/1e6:.0f} GB/s algorithmic (2 reads + 1 f32 write)")
         del vol, out
+if which in ("all", "psf"):
+    import time
+    from biahub_amd.characterize_psf import block_peaks, detect_peaks, recentre_beads, _patch_margins
+    from biahub_amd.estimate_psf import average_beads_device, BEAD_DETECTION_SETTINGS
+    shape = (256, 1024, 1024)
+    g = torch.Generator(device=dev).manual_seed(3)
+    vol = torch.empty(shape, device=dev).normal_(110.0, 3.0, generator=g)
+    n = 400
+    cz, cy, cx = (torch.randint(30, s - 30, (n,), generator=g, device=dev) for s in shape)
+    off = torch.arange(-6, 7, device=dev)
+    dz, dy, dx = torch.meshgrid(off, off, off, indexing="ij")
+    val = 2000 * torch.exp(-0.5 * ((dz / 1.5) ** 2 + (dy / 1.2) ** 2 + (dx / 1.2) ** 2))
+    vol.index_put_((cz[:, None, None, None] + dz, cy[:, None, None, None] + dy, cx[:, None, None, None] + dx),
+                   val.expand(n, -1, -1, -1), accumulate=True)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        t0 = time.perf_counter(); block_peaks(vol, 3, (64, 64, 32)); torch.cuda.synchronize(); t1 = time.perf_counter()
+    print(f"block_peaks {shape} blur 3 block (64,64,32): {(t1-t0)*1e3:.2f} ms")
+    t0 = time.perf_counter(); peaks = detect_peaks(vol, **BEAD_DETECTION_SETTINGS, device=dev); t1 = time.perf_counter()
+    margins = _patch_margins((1, 1, 1), (31, 41, 41))
+    centres = recentre_beads(vol, peaks, margins); torch.cuda.synchronize(); t2 = time.perf_counter()
+    psf, nb = average_beads_device(vol, centres, margins); torch.cuda.synchronize(); t3 = time.perf_counter()
+    print(f"detect_peaks: {len(peaks)} peaks in {(t1-t0)*1e3:.1f} ms; recentre {len(centres)} beads {(t2-t1)*1e3:.1f} ms; "
+          f"average {nb} patches of (31,41,41): {(t3-t2)*1e3:.1f} ms")
