@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .device import get_context, ptr, resolve_device
+from .device import get_context, ptr, resolve_device, to_host
 
 
 def _bounds(sl, n):
@@ -56,7 +56,7 @@ def _crop_numpy(a4: np.ndarray, slicing, nan_to_zero, device, flip_y=False, flip
         out = _crop_raw(t, lo, shape, flip_y, flip_x, True)
     else:
         out = _crop_raw(t, lo, shape, flip_y, flip_x, False)
-    res = out.cpu().numpy().view(a4.dtype)
+    res = to_host(out).view(a4.dtype)
     return res.astype(np.float16) if narrow else res
 
 

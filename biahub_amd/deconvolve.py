@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .device import as_device_volume, get_context, ptr, resolve_device
+from .device import as_device_volume, get_context, ptr, resolve_device, to_host
 
 
 def _f32_device(x, device=None):
@@ -41,7 +41,7 @@ def transfer_function_device(psf_zyx, output_zyx_shape, device="cuda") -> torch.
 
 def compute_tranfser_function(psf_zyx_data: np.ndarray, output_zyx_shape: tuple, device="cuda") -> np.ndarray:
     """numpy in / numpy out transfer function (biahub/deconvolve.py:30-43)."""
-    return transfer_function_device(psf_zyx_data, output_zyx_shape, device).cpu().numpy()
+    return to_host(transfer_function_device(psf_zyx_data, output_zyx_shape, device))
 
 
 def tikhonov_zyx(zyx, transfer_function, regularization_strength: float = 1e-3) -> torch.Tensor:
@@ -87,7 +87,7 @@ def deconvolve(
     H, _ = _f32_device(transfer_function, dev)
     out = []
     for zyx in np.asarray(czyx_raw_data):
-        out.append(tikhonov_zyx(_f32_device(zyx, dev)[0], H, regularization_strength).cpu().numpy())
+        out.append(to_host(tikhonov_zyx(_f32_device(zyx, dev)[0], H, regularization_strength)))
     return np.stack(out)
 
 
@@ -117,6 +117,6 @@ def richardson_lucy_czyx(czyx_raw_data: np.ndarray, psf_zyx: np.ndarray, iterati
     dev = resolve_device(device)
     psf, _ = _f32_device(psf_zyx, dev)
     return np.stack([
-        richardson_lucy(_f32_device(zyx, dev)[0], psf, iterations, eps).cpu().numpy()
+        to_host(richardson_lucy(_f32_device(zyx, dev)[0], psf, iterations, eps))
         for zyx in np.asarray(czyx_raw_data)
     ])

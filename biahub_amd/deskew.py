@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .device import as_device_volume, get_context, ptr, resolve_device
+from .device import as_device_volume, get_context, ptr, resolve_device, to_host
 
 
 def _get_averaged_shape(deskewed_data_shape: tuple, average_window_width: int) -> tuple:
@@ -120,12 +120,12 @@ def _fast_deskew_czyx(data, device="cuda", num_splits=1, **kwargs):
     if num_splits > 1:
         chunks = np.array_split(zyx, num_splits, axis=2)
         results = [
-            fast_deskew_zyx(as_device_volume(np.ascontiguousarray(c), dev)[0], **kwargs).cpu().numpy()
+            to_host(fast_deskew_zyx(as_device_volume(np.ascontiguousarray(c), dev)[0], **kwargs))
             for c in reversed(chunks)
         ]
         return np.concatenate(results, axis=1)[None]
     t, _, _ = as_device_volume(zyx, dev)
-    return fast_deskew_zyx(t, **kwargs).cpu().numpy()[None]
+    return to_host(fast_deskew_zyx(t, **kwargs))[None]
 
 
 def deskew_zyx(

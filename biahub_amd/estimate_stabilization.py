@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .device import as_device_volume, get_context, ptr, resolve_device
+from .device import as_device_volume, get_context, ptr, resolve_device, to_host
 
 
 def phase_cross_corr_device(ref_img, mov_img, normalization=None, device="cuda", want_corr: bool = True):
@@ -48,7 +48,7 @@ def phase_cross_corr(ref_img, mov_img, normalization=None, output_path=None, ver
     ``normalization`` is ``None``, ``"magnitude"`` or ``"classic"`` (estimate_stabilization.py:233-238).
     """
     shift, corr = phase_cross_corr_device(ref_img, mov_img, normalization, device, want_corr=True)
-    return shift, corr.cpu().numpy()
+    return shift, to_host(corr)
 
 
 # ----------------------------------------------------------------------------- padding variant and the per-position chain

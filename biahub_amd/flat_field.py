@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .device import as_device_volume, get_context, ptr
+from .device import as_device_volume, get_context, ptr, to_host
 
 
 def median_z_device(vol, device=None) -> torch.Tensor:
@@ -71,7 +71,7 @@ def flat_field_zyx(zyx_data: np.ndarray, axis: int = 0, device="cuda") -> np.nda
     if axis % 3 != 0:  # the reference expression only broadcasts for axis 0 (zyx / pattern, flat_field.py:119-120)
         raise ValueError(f"operands could not be broadcast together: the median pattern along axis {axis} does not "
                          f"divide a {a.shape} volume; flat_field_zyx supports axis=0")
-    return flat_field_device(a, device).cpu().numpy()
+    return to_host(flat_field_device(a, device))
 
 
 def flat_field_correction(zyx_data: np.ndarray, axis: int = 0, device="cuda") -> np.ndarray:

@@ -13,6 +13,7 @@ from __future__ import annotations
 import inspect
 import json
 import os
+import threading
 import zlib
 from pathlib import Path
 
@@ -33,6 +34,54 @@ def _write_json(path: Path, obj) -> None:
     tmp = path.with_suffix(path.suffix + ".tmp")
     tmp.write_text(json.dumps(obj, indent=1))
     os.replace(tmp, path)
+
+
+_IO_POOL = None
+
+
+def _io_pool():
+    """Shared pool for chunk I/O (file reads/writes and zlib release the GIL); size via BH_IO_THREADS (default 8)."""
+    global _IO_POOL
+    if _IO_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _IO_POOL = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("BH_IO_THREADS", "8"))),
+                                      thread_name_prefix="bh-io")
+    return _IO_POOL
+
+
+def _io_map(fn, items):
+    items = list(items)
+    if len(items) <= 1 or threading.current_thread().name.startswith("bh-io"):
+        for it in items:  # already on a pool thread (read-ahead / write-behind): do not nest
+            fn(it)
+        return
+    for r in _io_pool().map(fn, items):
+        pass
+
+
+_TORCH_DT = None
+
+
+def _host_volume(shape, dtype) -> np.ndarray:
+    """Destination of a volume read: pinned host memory from torch's caching host allocator when a GPU is present (the
+    upload that follows is then a direct DMA, and a plate's equally shaped volumes reuse the blocks), plain numpy else."""
+    global _TORCH_DT
+    dtype = np.dtype(dtype)
+    if int(np.prod(shape)) * dtype.itemsize >= (8 << 20):
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                if _TORCH_DT is None:
+                    _TORCH_DT = {np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.uint16,
+                                 np.dtype(np.int16): torch.int16, np.dtype(np.float32): torch.float32,
+                                 np.dtype(np.float64): torch.float64, np.dtype(np.int32): torch.int32}
+                if dtype in _TORCH_DT:
+                    return torch.empty(tuple(int(v) for v in shape), dtype=_TORCH_DT[dtype], pin_memory=True).numpy()
+        except Exception:  # no torch / no pinned memory: pageable is always correct
+            pass
+    return np.empty(shape, dtype=dtype)
 
 
 class ZarrArray:
@@ -63,19 +112,31 @@ class ZarrArray:
         return self.path / self.sep.join(str(v) for v in (t, c, zi, 0, 0))
 
     def read_volume(self, t: int, c: int) -> np.ndarray:
+        """One (t, c) volume; its z-chunks are read (and inflated) concurrently, straight into the result."""
         T, C, Z, Y, X = self.shape
         zc = self.chunks[2]
-        out = np.empty((Z, Y, X), dtype=self.dtype)
-        for zi in range(-(-Z // zc)):
+        out = _host_volume((Z, Y, X), self.dtype)
+
+        def one(zi):
             f = self._chunk_path(t, c, zi)
             z0, z1 = zi * zc, min(Z, (zi + 1) * zc)
-            if not f.exists():
+            try:
+                fh = open(f, "rb")
+            except FileNotFoundError:
                 out[z0:z1] = self.fill_value
-                continue
-            raw = f.read_bytes()
+                return
+            with fh:
+                if self.compressor is None and z1 - z0 == zc:
+                    view = memoryview(out[z0:z1]).cast("B")
+                    if fh.readinto(view) != len(view):
+                        raise OSError(f"{f}: truncated chunk")
+                    return
+                raw = fh.read()
             if self.compressor is not None:
-                raw = zlib.decompress(raw)
+                raw = zlib.decompress(raw)  # releases the GIL
             out[z0:z1] = np.frombuffer(raw, dtype=self.dtype).reshape(zc, Y, X)[: z1 - z0]
+
+        _io_map(one, range(-(-Z // zc)))
         return out
 
     def write_volume(self, t: int, c: int, vol: np.ndarray) -> None:
@@ -84,20 +145,24 @@ class ZarrArray:
             raise ValueError(f"volume shape {vol.shape} does not match array {(Z, Y, X)}")
         zc = self.chunks[2]
         vol = np.ascontiguousarray(vol, dtype=self.dtype)
-        for zi in range(-(-Z // zc)):
+
+        def one(zi):
             z0, z1 = zi * zc, min(Z, (zi + 1) * zc)
             chunk = vol[z0:z1]
             if z1 - z0 < zc:  # zarr stores full chunks
                 pad = np.full((zc - (z1 - z0), Y, X), self.fill_value, dtype=self.dtype)
                 chunk = np.concatenate([chunk, pad])
-            raw = chunk.tobytes()
+            raw = memoryview(chunk).cast("B")
             if self.compressor is not None:
                 raw = zlib.compress(raw, self.compressor.get("level", 1))
             f = self._chunk_path(t, c, zi)
             f.parent.mkdir(parents=True, exist_ok=True)
             tmp = f.with_name(f.name + ".tmp")
-            tmp.write_bytes(raw)
+            with open(tmp, "wb") as fh:
+                fh.write(raw)
             os.replace(tmp, f)
+
+        _io_map(one, range(-(-Z // zc)))
 
     def __getitem__(self, key) -> np.ndarray:
         if not isinstance(key, tuple):
@@ -253,8 +318,9 @@ def process_single_position(func, input_position_path, output_position_path, inp
     Mirrors how the reference drives its operators (call sites biahub/deskew.py:738-749,
     register.py:556-574, stabilize.py:287-300): one channel per call by default, all-zero/NaN inputs skipped,
     ``input_time_index`` injected when ``func`` declares it, ``extra_metadata`` moved into the output zattrs,
-    finished units recorded for ``resume`` under the ``resume_token``.  Units run serially in this process:
-    the GPU is the parallel resource here, not a pool of CPU workers (``num_workers`` is accepted and ignored).
+    finished units recorded for ``resume`` under the ``resume_token``.  The operator runs serially in this process
+    (the GPU is the parallel resource, ``num_workers`` is accepted and ignored); reading the next unit and writing
+    the previous result overlap it on I/O threads.
     """
     extra_metadata = kwargs.pop("extra_metadata", None)
     src, dst = Position(input_position_path), Position(output_position_path)
@@ -272,25 +338,50 @@ def process_single_position(func, input_position_path, output_position_path, inp
         rec = json.loads(done_file.read_text())
         if rec.get("token") == resume_token:
             done = rec.get("units", {})
-    n_run = 0
+    units = []
     for ti, to in zip(in_t, out_t):
         for gi, go in zip(in_c, out_c):
             key = f"{to}:{','.join(map(str, go))}"
-            if resume and done.get(key):
-                continue
-            czyx = np.stack([src.data.read_volume(ti, c) for c in gi])
+            if not (resume and done.get(key)):
+                units.append((ti, to, gi, go, key))
+
+    # Three-stage pipeline: the next unit is read (chunks in parallel) while this one is on the GPU and the previous
+    # result is being written; the operator itself runs on this thread only (a bh_ctx is not thread-safe).
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+
+    def load(u):
+        return np.stack([src.data.read_volume(u[0], c) for c in u[2]])
+
+    def store(u, res):
+        if res is not None:
+            for c, vol in zip(u[3], res):
+                dst.data.write_volume(u[1], c, vol)
+        done[u[4]] = True
+        _write_json(done_file, {"token": resume_token, "units": done})
+
+    n_run = 0
+    with ThreadPoolExecutor(1, thread_name_prefix="bh-pipe-r") as reader, \
+            ThreadPoolExecutor(1, thread_name_prefix="bh-pipe-w") as writer:
+        nxt = reader.submit(load, units[0]) if units else None
+        pending = deque()
+        for i, u in enumerate(units):
+            czyx = nxt.result()
+            nxt = reader.submit(load, units[i + 1]) if i + 1 < len(units) else None
+            res = None
             if not _check_nan_n_zeros(czyx):
                 call_kw = dict(kwargs)
                 if wants_t:
-                    call_kw["input_time_index"] = ti
+                    call_kw["input_time_index"] = u[0]
                 res = np.asarray(func(czyx, **call_kw))
-                if res.shape[0] != len(go):
-                    raise ValueError(f"operator returned {res.shape[0]} channels for {len(go)} output channels")
-                for c, vol in zip(go, res):
-                    dst.data.write_volume(to, c, vol)
+                if res.shape[0] != len(u[3]):
+                    raise ValueError(f"operator returned {res.shape[0]} channels for {len(u[3])} output channels")
                 n_run += 1
-            done[key] = True
-            _write_json(done_file, {"token": resume_token, "units": done})
+            pending.append(writer.submit(store, u, res))
+            while len(pending) > 2:  # bound the results held in host memory
+                pending.popleft().result()
+        while pending:
+            pending.popleft().result()
     if extra_metadata:
         merged = dict(dst.zattrs.get("extra_metadata", {}))
         merged.update(extra_metadata)

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .device import as_device_volume, get_context, ptr, resolve_device
+from .device import as_device_volume, get_context, ptr, resolve_device, to_host
 
 _INTERP = {"linear": _lib.INTERP_LINEAR, "nearestneighbor": _lib.INTERP_NEAREST}
 
@@ -193,5 +193,4 @@ def apply_affine_transform(
                                             device=device)
         return out
     dev = resolve_device(device)
-    return affine_device(zyx_data, matrix, (Z, Y, X), interpolation, _lib.BOUNDARY_ITK, 0.0, lo, shape,
-                         dev).cpu().numpy()
+    return to_host(affine_device(zyx_data, matrix, (Z, Y, X), interpolation, _lib.BOUNDARY_ITK, 0.0, lo, shape, dev))

@@ -5,7 +5,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _lib
-from .device import resolve_device
+from .device import resolve_device, to_host
 from .register import affine_device
 
 
@@ -33,4 +33,4 @@ def apply_stabilization_transform(
                                                    device=device)
         return out
     dev = resolve_device(device)
-    return affine_device(zyx_data, matrix, output_shape, "linear", _lib.BOUNDARY_ITK, 0.0, device=dev).cpu().numpy()
+    return to_host(affine_device(zyx_data, matrix, output_shape, "linear", _lib.BOUNDARY_ITK, 0.0, device=dev))

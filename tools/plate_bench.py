@@ -103,7 +103,7 @@ if rank == 0:
     t1 = time.perf_counter(); o = _fast_deskew_czyx(czyx, device=str(dev), **DK); t2 = time.perf_counter()
     out["deskew_adapter_host_boundary"] = {"seconds": t2 - t1, "voxels_per_s": V / (t2 - t1),
                                            "h2d_bytes": czyx.nbytes, "d2h_bytes": o.nbytes,
-                                           "note": "pageable numpy memory, torch copies; uint16 in (2 B/voxel), float32 out"}
+                                           "note": "pageable numpy in (uint16, 2 B/voxel), float32 out through pinned host blocks (biahub_amd.device.to_host)"}
     print(json.dumps(out))
 if world > 1:
     torch.distributed.destroy_process_group()
