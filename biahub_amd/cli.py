@@ -19,7 +19,8 @@ from . import parallel
 from .io import create_empty_plate, open_ome_zarr, process_single_position
 from .settings import (DeconvolveSettings, DeskewSettings, EstimateRegistrationSettings,
                        EstimateStabilizationSettings, FlatFieldCorrectionSettings, PhaseCrossCorrSettings,
-                       PsfFromBeadsSettings, RegistrationSettings, RichardsonLucySettings, StabilizationSettings)
+                       ProcessingImportFuncSettings, PsfFromBeadsSettings, RegistrationSettings, RichardsonLucySettings,
+                       StabilizationSettings)
 from .utils.cluster import echo_resources, estimate_resources, get_submitit_cluster
 from .utils.config import model_to_yaml, settings_fingerprint, yaml_to_model
 from .utils.paths import get_output_paths, sbatch_to_submitit
@@ -142,6 +143,50 @@ def deskew_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor
     _run_positions("deskew", input_position_dirpaths, outs,
                    lambda s, d: process_single_position(_fast_deskew_czyx, s, d, resume=resume,
                                                         resume_token=settings_fingerprint(settings), **kw),
+                   Path(output_dirpath).parent)
+
+
+@cli.command("process-with-config")
+@_common
+@_config
+@click.option("--local", "-l", is_flag=True, default=False)
+def process_with_config_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor, config_filepath, local):
+    """Process data with the functions named in the config (reference: ``biahub process-with-config``,
+    process_data.py:148-349); every channel of a timepoint reaches the functions at once."""
+    from .process_data import process_czyx, resolve_function
+
+    settings = yaml_to_model(config_filepath, ProcessingImportFuncSettings)
+    if not settings.processing_functions:
+        raise ValueError("Processing functions must be specified")
+    with open_ome_zarr(input_position_dirpaths[0]) as ds:
+        names, (T, Cn, Z, Y, X), scale, version = ds.channel_names, ds.data.shape, list(ds.scale), ds.version
+    for proc in settings.processing_functions:
+        if proc.input_channels is not None and len(proc.input_channels) == 1:
+            proc.input_channels[0] = names.index(proc.input_channels[0])
+        else:
+            raise ValueError("Channel must be specified for preprocessing functions")
+        try:
+            resolve_function(proc.function)
+        except ValueError as e:
+            raise ValueError(f"Function {proc.function} could not be resolved: {e}") from e
+    out_shape, new_scale = (T, Cn, Z, Y, X), scale
+    for proc in settings.processing_functions:  # the reference sizes the output from the first binning function (:211-236)
+        if proc.function.endswith("process_data.binning_czyx"):
+            f = proc.kwargs.get("binning_factor_zyx", (1, 4, 4))
+            click.echo(f"Binning factor: {f}")
+            out_shape = (T, Cn, Z // f[0], Y // f[1], X // f[2])
+            new_scale = scale[:2] + [scale[2] * f[0], scale[3] * f[1], scale[4] * f[2]]
+            break
+    create_empty_plate(output_dirpath, [p.parts[-3:] for p in input_position_dirpaths], names, out_shape, scale=new_scale,
+                       dtype=np.float32, version=settings.output_ome_zarr_version or version)
+    if sbatch_filepath:
+        sbatch_to_submitit(sbatch_filepath)
+    allc = [list(range(Cn))]
+    outs = get_output_paths(input_position_dirpaths, output_dirpath)
+    _run_positions("process-with-config", input_position_dirpaths, outs,
+                   lambda s, d: process_single_position(process_czyx, s, d, input_time_indices=list(range(T)),
+                                                        input_channel_indices=allc, output_channel_indices=allc,
+                                                        processing_functions=settings.processing_functions),
                    Path(output_dirpath).parent)
 
 

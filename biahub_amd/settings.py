@@ -25,6 +25,22 @@ class ProcessingSettings(_Strict):
     rot90: int | None = 0
 
 
+class ProcessingFunctions(_Strict):
+    """biahub/settings.py:33-37."""
+
+    function: str
+    input_channels: list | None = None
+    kwargs: dict = {}
+    per_timepoint: bool | None = True
+
+
+class ProcessingImportFuncSettings(_Strict):
+    """biahub/settings.py:40-43."""
+
+    processing_functions: list[ProcessingFunctions] = []
+    output_ome_zarr_version: OmeZarrVersion | None = None
+
+
 class FlatFieldCorrectionSettings(_Strict):
     """biahub/settings.py:336-339."""
 

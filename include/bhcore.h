@@ -9,6 +9,8 @@
  *   bh_deskew              <- biahub/deskew.py:456-542  fast_deskew_zyx  (+ :99-154)
  *   bh_flat_field, bh_median_z
  *                          <- biahub/flat_field.py:101-120 flat_field_zyx, :56-99 _median_tiled (np.median, axis 0)
+ *   bh_bin_reduce, bh_bin_finish
+ *                          <- biahub/process_data.py:29-105 binning_czyx
  *   bh_overhang_fill       <- biahub/deskew.py:339-368  _fill_overhang_torch
  *   bh_transfer_function   <- biahub/deconvolve.py:30-43 compute_tranfser_function
  *   bh_tikhonov            <- biahub/deconvolve.py:46-66 deconvolve (waveorder Tikhonov)
@@ -111,6 +113,16 @@ int bh_median_z(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y,
  * pattern (device, Y*X float64) may be NULL (context scratch is used); mean_out (host) may be NULL (no sync). */
 int bh_flat_field(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, int64_t X, float* out,
                   double* pattern, double* mean_out);
+
+/* ---- binning (biahub/process_data.py:29-105 binning_czyx) ---------------------------------------------------------- */
+/* out (device float32, (Z/fz, Y/fy, X/fx)) = window sums (mean == 0) or sums / count (mean != 0) of a volume whose shape is
+ * divisible by the factors (BH_ERR_INVALID otherwise, like numpy's reshape); minmax (host) = min and max of out. Sync. */
+int bh_bin_reduce(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, int64_t X, const int factor[3], int mean,
+                  float* out, float minmax[2]);
+/* out[i] = cast(apply ? ((v[i] - sub) * mul) / div : v[i]) in float32 in that operation order, truncating like
+ * ndarray.astype; out_dtype is one of the BH_DT_* codes. */
+int bh_bin_finish(bh_ctx* ctx, const float* v, int64_t n, int apply, float sub, float mul, float div, int out_dtype,
+                  void* out);
 
 /* ---- deskew ------------------------------------------------------------------------ */
 /* Host-only geometry. out_shape = (ceil(Y/n), X, Xp); voxel = (n*sin(t)*px, px, px).

@@ -130,7 +130,37 @@ def pcc_chain_vectors():
     print("pcc_chain.npz written")
 
 
+def binning_vectors():
+    """biahub/process_data.py:29-105 binning_czyx."""
+    import biahub.process_data as PD
+
+    rng = np.random.default_rng(20261007)
+    bn = {}
+    cases = [((2, 4, 12, 16), np.uint16, (1, 2, 2), "sum"), ((2, 4, 12, 16), np.uint16, (2, 3, 4), "mean"),
+             ((1, 6, 8, 10), np.uint8, (3, 2, 5), "sum"), ((3, 4, 6, 8), np.int16, (1, 2, 2), "mean"),
+             ((2, 4, 8, 12), np.float32, (2, 2, 3), "sum"), ((2, 4, 8, 12), np.float32, (1, 4, 4), "mean"),
+             ((1, 2, 4, 4), np.uint16, (1, 2, 2), "sum")]
+    for j, (shape, dt, f, mode) in enumerate(cases):
+        if dt == np.int16:
+            data = (rng.random(shape) * 3000 + 5).astype(dt)
+        elif dt == np.float32:
+            data = (rng.random(shape) * 1000).astype(dt)
+        else:
+            data = (rng.random(shape) * (250 if dt == np.uint8 else 60000)).astype(dt)
+        if j == 6:
+            data[:] = 0  # all-zero channel: the stretch is skipped
+        bn[f"in{j}"] = data
+        bn[f"kw{j}"] = np.array(json.dumps({"binning_factor_zyx": list(f), "mode": mode}))
+        bn[f"out{j}"] = PD.binning_czyx(data, binning_factor_zyx=f, mode=mode)
+    np.savez_compressed(HERE / "binning.npz", **bn)
+    print("binning.npz written")
+
+
 def main():
+    if sys.argv[1:] == ["binning"]:
+        load_reference()
+        binning_vectors()
+        return 0
     if sys.argv[1:] == ["pcc_chain"]:
         load_reference()
         pcc_chain_vectors()
@@ -338,6 +368,7 @@ def main():
     flat_field_vectors()
     detect_peaks_vectors()
     pcc_chain_vectors()
+    binning_vectors()
     total = sum(p.stat().st_size for p in HERE.glob("*.np*")) + sum(p.stat().st_size for p in HERE.glob("*.json"))
     print(f"golden fixtures written to {HERE} ({total/1e6:.2f} MB)")
     return 0

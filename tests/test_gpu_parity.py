@@ -707,3 +707,34 @@ def test_full_size_properties_config2(gpu):
     want_mean = float((pat + 2).double().mean())
     z7 = raw[7].double() / (pat + 2).double() * want_mean
     assert float((flat[7].double() - z7).abs().max()) <= 2e-7 * float(z7.max())
+
+
+# ----------------------------------------------------------------------------- binning (process-with-config)
+def test_binning_golden_and_oracle(gpu):
+    """process_data.binning_czyx: integer inputs bit-exact (window sums are exact in float32, the stretch is evaluated
+    in the reference's operation order), float32 inputs to summation-order tolerance."""
+    import json
+    from biahub_amd.process_data import binning_czyx, process_czyx
+    from biahub_amd.settings import ProcessingFunctions
+
+    z = np.load(GOLDEN / "binning.npz")
+    for j in range(7):
+        kw = json.loads(str(z[f"kw{j}"]))
+        got = binning_czyx(z[f"in{j}"], **kw)
+        want = z[f"out{j}"]
+        assert got.dtype == want.dtype and got.shape == want.shape
+        if np.issubdtype(want.dtype, np.integer):
+            assert np.array_equal(got, want), j
+        else:
+            assert rel_err(got, want) <= 1e-6, j
+    rng = np.random.default_rng(4)
+    big = (rng.random((2, 32, 96, 160)) * 60000).astype(np.uint16)
+    for f, mode in (((1, 2, 2), "sum"), ((2, 4, 4), "mean"), ((4, 3, 5), "sum")):
+        assert np.array_equal(binning_czyx(big, f, mode), O.binning_czyx(big, f, mode)), (f, mode)
+    proc = ProcessingFunctions(function="biahub.process_data.binning_czyx", input_channels=[0],
+                               kwargs={"binning_factor_zyx": [1, 2, 2], "mode": "sum"})
+    assert np.array_equal(process_czyx(big, [proc]), O.binning_czyx(big, (1, 2, 2), "sum"))
+    with pytest.raises(ValueError, match="cannot reshape"):
+        binning_czyx(big, (1, 5, 2))
+    with pytest.raises(ValueError, match="Invalid mode"):
+        binning_czyx(big, (1, 2, 2), "median")

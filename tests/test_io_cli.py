@@ -84,7 +84,7 @@ def test_cli_help_and_eat_all():
     assert expand_eat_all(["deskew", "-i", "a", "b", "c", "-c", "x.yml", "-o", "o"]) == \
         ["deskew", "-i", "a", "-i", "b", "-i", "c", "-c", "x.yml", "-o", "o"]
     r = CliRunner()
-    for cmd in ("deskew", "deconvolve", "rl-deconvolve", "register", "stabilize", "flip", "estimate-registration", "flat-field", "estimate-psf", "estimate-stabilization"):
+    for cmd in ("deskew", "deconvolve", "rl-deconvolve", "register", "stabilize", "flip", "estimate-registration", "flat-field", "estimate-psf", "estimate-stabilization", "process-with-config"):
         res = r.invoke(cli, [cmd, "--help"])
         assert res.exit_code == 0 and "Usage" in res.output
 
@@ -324,3 +324,25 @@ def test_cli_estimate_stabilization_then_stabilize(gpu, tmp_path):
     cfg.write_text("stabilization_estimation_channel: ch0\nstabilization_channels: [ch0]\nstabilization_type: z\n")
     res = r.invoke(cli, ["estimate-stabilization", "-i", str(src / "A/1/0"), "-o", str(out), "-c", str(cfg)])
     assert res.exit_code != 0 and "not available" in res.output
+
+
+@pytest.mark.gpu
+def test_cli_process_with_config_binning(gpu, tmp_path):
+    """``process-with-config`` with the binning function: output shape and scale follow the factor (process_data.py:211-236)."""
+    src = tmp_path / "in.zarr"
+    shape = (2, 2, 8, 12, 16)
+    data = make_plate(src, positions=(("A", "1", "0"),), shape=shape)
+    cfg = tmp_path / "p.yml"
+    cfg.write_text("processing_functions:\n- function: biahub.process_data.binning_czyx\n  input_channels: [ch0]\n"
+                   "  kwargs:\n    binning_factor_zyx: [1, 2, 2]\n    mode: sum\n")
+    out = tmp_path / "binned.zarr"
+    res = CliRunner().invoke(cli, ["process-with-config", "-i", str(src / "A/1/0"), "-c", str(cfg), "-o", str(out), "--local"])
+    assert res.exit_code == 0, res.output
+    pos = io.open_ome_zarr(out / "A/1/0")
+    assert pos.data.shape == (2, 2, 8, 6, 8) and pos.data.dtype == np.float32
+    np.testing.assert_allclose(pos.scale, (1, 1, 1, 0.232, 0.232))
+    czyx = np.stack([data[("A", "1", "0", 1, c)] for c in range(2)])
+    assert np.array_equal(np.stack([pos.data[1, 0], pos.data[1, 1]]), O.binning_czyx(czyx, (1, 2, 2), "sum").astype(np.float32))
+    cfg.write_text("processing_functions:\n- function: np.mean\n  input_channels: [ch0]\n")
+    res = CliRunner().invoke(cli, ["process-with-config", "-i", str(src / "A/1/0"), "-c", str(cfg), "-o", str(out), "--local"])
+    assert res.exit_code != 0

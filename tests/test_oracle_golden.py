@@ -176,3 +176,14 @@ def test_pcc_chain_golden():
         for ft in ("custom", "custom_padding"):
             tr, sh, _ = O.get_tform_from_pcc(t, stack, first, ft, "magnitude")
             assert np.array_equal(tr, z[f"tform{t}_{ft}"]) and np.array_equal(np.asarray(sh, float), z[f"tshift{t}_{ft}"])
+
+
+def test_binning_golden():
+    """process_data.binning_czyx through the oracle (values captured from the reference import)."""
+    import json
+
+    z = np.load(GOLDEN / "binning.npz")
+    for j in range(7):
+        kw = json.loads(str(z[f"kw{j}"]))
+        got = O.binning_czyx(z[f"in{j}"], tuple(kw["binning_factor_zyx"]), kw["mode"])
+        assert got.dtype == z[f"out{j}"].dtype and np.array_equal(got, z[f"out{j}"]), j
