@@ -126,7 +126,10 @@ def to_host(t: torch.Tensor) -> np.ndarray:
     t = t.contiguous()
     if t.numel() * t.element_size() < _PIN_MIN_BYTES:
         return t.cpu().numpy()
-    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    try:
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    except RuntimeError:  # pinned memory exhausted / locked-memory limit: pageable is slower but always works
+        return t.cpu().numpy()
     host.copy_(t)  # synchronous for a pinned destination copied with non_blocking=False
     return host.numpy()
 
