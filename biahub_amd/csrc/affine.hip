@@ -23,7 +23,8 @@
 namespace bh {
 
 constexpr int ATX = 64, ATY = 8, ATZ = 8;
-constexpr int A_LDS_FLOATS = 9984;   // 39 KiB cap -> at least four workgroups per CU; gentler warps get less (host bound)
+constexpr int A_LDS_FLOATS = 9984;      // 39 KiB cap -> at least four workgroups per CU; gentler warps get less (host bound)
+constexpr int A_LDS_FLOATS_X8 = 13056;  // 16-bit input staged in groups of 8: wider boxes, 51 KiB cap -> three per CU
 
 struct AffineParams {
     double m[12];
@@ -33,8 +34,9 @@ struct AffineParams {
     int cz, cy, cx;
     int interp, boundary;
     float cval;
-    int lds_floats;  // staging capacity of this launch (dynamic LDS), <= A_LDS_FLOATS
+    int lds_floats;  // staging capacity of this launch (dynamic LDS), <= A_LDS_FLOATS[_X8]
     int x4;          // float32 rows are 16-B aligned: stage with 16-B LDS-DMA, box x range rounded out to 4 floats
+    int x8;          // 16-bit rows are 16-B aligned: stage 8 samples per lane (one 16-B load), x range rounded out to 8
 };
 
 template <typename T>
@@ -127,6 +129,12 @@ __device__ __forceinline__ void compute_box(const AffineParams& p, int tile, int
             ext = end - org;
             b->rcp_l = (unsigned)(0xffffffffu / (unsigned)(ext >> 2)) + 1u;  // wraps to 0 for 1: handled by the user
         }
+        if (a == 2 && p.x8 && ext > 0) {  // 16-bit input: whole 16-B groups of 8 samples; Xi % 8 == 0
+            const int end = (org + ext + 7) & ~7;
+            org &= ~7;
+            ext = end - org;
+            b->rcp_l = (unsigned)(0xffffffffu / (unsigned)(ext >> 3)) + 1u;
+        }
         if (a == 1 && ext > 0) b->rcp_dy = (unsigned)(0xffffffffu / (unsigned)ext) + 1u;
         b->org[a] = org;
         b->ext[a] = ext;
@@ -198,6 +206,37 @@ __device__ __forceinline__ void stage_box(const TIN* __restrict__ in, const Affi
             if (y >= dy) {
                 y -= dy;
                 ++z;
+            }
+        }
+    } else if (sizeof(TIN) == 2 && p.x8) {
+        // 16-bit input: the box as a flat list of 8-sample groups, one 16-B load per lane, widened in registers
+        const unsigned L = (unsigned)dx >> 3, S = (unsigned)nrows * L;
+        const TIN* base = in + (size_t)bz * sZ + (size_t)by * sY + bx;
+        for (unsigned i0 = 0; i0 < S; i0 += A_NT * 2) {
+            uint4 raw[2];
+            unsigned qq[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned q = min(i0 + u * A_NT + threadIdx.x, S - 1);
+                const unsigned r = L == 1 ? q : __umulhi(q, b.rcp_l), xq = q - r * L;
+                const unsigned z = dy == 1 ? r : __umulhi(r, b.rcp_dy), y = r - z * (unsigned)dy;
+                raw[u] = *reinterpret_cast<const uint4*>(base + ((size_t)z * sZ + (size_t)y * sY + 8 * xq));
+                qq[u] = q;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (i0 + u * A_NT + threadIdx.x < S) {
+                    const unsigned w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+                    float f[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        f[2 * k] = (float)(TIN)(w[k] & 0xffffu);
+                        f[2 * k + 1] = (float)(TIN)(w[k] >> 16);
+                    }
+                    float4* dst = reinterpret_cast<float4*>(tile + 8 * qq[u]);
+                    dst[0] = make_float4(f[0], f[1], f[2], f[3]);
+                    dst[1] = make_float4(f[4], f[5], f[6], f[7]);
+                }
             }
         }
     } else {
@@ -420,7 +459,7 @@ __device__ __forceinline__ void sample_tile(const TIN* __restrict__ in, float* _
 template <typename TIN, int INTERP, int BOUNDARY>
 __global__ __launch_bounds__(A_NT) void affine_kernel(const TIN* __restrict__ in, float* __restrict__ out,
                                                      AffineParams p, int ntx, int nty, int ntiles, int per_xcd) {
-    extern __shared__ float tile[];
+    extern __shared__ __attribute__((aligned(16))) float tile[];
     __shared__ TileBox box;
     const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= per_xcd || t >= ntiles) return;
@@ -491,6 +530,7 @@ extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, 
     p.boundary = boundary;
     p.cval = cval;
     p.x4 = (in_dtype == BH_DT_F32 && Xi % 4 == 0 && ((uintptr_t)in & 15) == 0) ? 1 : 0;
+    p.x8 = ((in_dtype == BH_DT_U16 || in_dtype == BH_DT_I16) && Xi % 8 == 0 && ((uintptr_t)in & 15) == 0) ? 1 : 0;
     // Upper bound of any tile's source box (compute_box: hi - lo <= sum |m| * (T - 1), then floor / floor + 1 and the
     // slack add at most 3): the launch asks for exactly that much LDS, so a gentle warp (a stabilisation shift needs
     // 10 x 10 x 66 floats) runs six workgroups per CU instead of four.  Tiles that exceed it gather from global memory.
@@ -502,9 +542,11 @@ extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, 
             for (int j = 0; j < 3; ++j) span += std::fabs(matrix[4 * a + j]) * (double)(T[j] - 1);
             double e = std::floor(span * (1.0 + 1e-6)) + 4.0;
             if (a == 2 && p.x4) e = std::floor((e + 6.0) / 4.0) * 4.0;
+            if (a == 2 && p.x8) e = std::floor((e + 14.0) / 8.0) * 8.0;
             nb *= e;
         }
-        p.lds_floats = nb < (double)A_LDS_FLOATS ? (int)nb : A_LDS_FLOATS;
+        const int cap = p.x8 ? A_LDS_FLOATS_X8 : A_LDS_FLOATS;
+        p.lds_floats = nb < (double)cap ? (int)nb : cap;
     }
     ScopedTimer timer(ctx, T_AFFINE);
     switch (in_dtype) {

@@ -281,8 +281,11 @@ def test_affine_interior_tiles_nonfinite(gpu, X):
             assert np.allclose(got, want, rtol=2e-5, atol=2e-3)
         else:
             assert np.array_equal(got, want)
-    u16 = rng.integers(0, 60000, vol.shape).astype(np.uint16)
+    u16 = rng.integers(0, 60000, vol.shape).astype(np.uint16)   # X = 200: 16-B group staging; X = 198: per-sample loads
     assert rel_err(apply_affine_transform(u16, M, u16.shape), O.apply_affine_transform(u16, M, u16.shape, "linear")) <= 1e-5
+    i16 = (rng.integers(0, 60000, vol.shape) - 30000).astype(np.int16)
+    assert rel_err(apply_affine_transform(i16, M, i16.shape), O.apply_affine_transform(i16, M, i16.shape, "linear")) <= 1e-5
+    assert np.array_equal(apply_affine_transform(u16, np.eye(4), u16.shape), u16.astype(np.float32))
 
 
 def test_affine_scipy_mode_golden(gpu):

@@ -40,6 +40,11 @@ if which in ("all", "affine"):
             for _ in range(3):
                 out = affine_device(vol, M, shape, interp); ms = ctx.elapsed_ms(_lib.T_AFFINE)
             print(f"affine {interp} {shape}: {ms:.3f} ms -> 8V/t = {8*V/ms/1e6:.0f} GB/s ({8*V/ms/1e6/8000:.1%})")
+        vol16 = vol.to(torch.uint16)
+        for _ in range(3):
+            out = affine_device(vol16, M, shape, "linear"); ms = ctx.elapsed_ms(_lib.T_AFFINE)
+        print(f"affine linear uint16 in {shape}: {ms:.3f} ms -> 6V/t = {6*V/ms/1e6:.0f} GB/s ({6*V/ms/1e6/8000:.1%})")
+        del vol16
         M2 = np.eye(4); M2[:3, 3] = (0.5, -2.25, 3.0)
         for _ in range(3):
             out = affine_device(vol, M2, shape, "linear"); ms = ctx.elapsed_ms(_lib.T_AFFINE)
