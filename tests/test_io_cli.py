@@ -84,7 +84,7 @@ def test_cli_help_and_eat_all():
     assert expand_eat_all(["deskew", "-i", "a", "b", "c", "-c", "x.yml", "-o", "o"]) == \
         ["deskew", "-i", "a", "-i", "b", "-i", "c", "-c", "x.yml", "-o", "o"]
     r = CliRunner()
-    for cmd in ("deskew", "deconvolve", "rl-deconvolve", "register", "stabilize", "flip", "estimate-registration", "flat-field", "estimate-psf", "estimate-stabilization", "process-with-config"):
+    for cmd in ("deskew", "deconvolve", "rl-deconvolve", "register", "stabilize", "flip", "estimate-registration", "flat-field", "estimate-psf", "estimate-stabilization", "process-with-config", "optimize-registration"):
         res = r.invoke(cli, [cmd, "--help"])
         assert res.exit_code == 0 and "Usage" in res.output
 
@@ -225,6 +225,19 @@ def test_cli_estimate_registration_then_register(gpu, tmp_path):
     centre = np.append((np.array(shape) - 1) / 2, 1)
     assert np.linalg.norm((T @ centre - M @ centre)[:3]) < 0.1
     assert np.allclose(np.load(out_yml.parent / "xyz_transforms" / "0.npy"), T)
+    # optimize-registration: a rough manual transform in RegistrationSettings form is refined on the overlap (crop=True)
+    th0 = np.deg2rad(1.5)
+    rough = [[1, 0, 0, 0.0], [0, float(np.cos(th0)), float(-np.sin(th0)), -1.5], [0, float(np.sin(th0)), float(np.cos(th0)), 4.0],
+             [0, 0, 0, 1]]
+    rough_yml = tmp_path / "rough.yml"
+    rough_yml.write_text(yaml.safe_dump({"source_channel_names": ["GFP"], "target_channel_name": "Phase3D",
+                                         "affine_transform_zyx": rough, "time_indices": 0}))
+    opt_yml = tmp_path / "opt" / "optimized.yml"
+    res = r.invoke(cli, ["optimize-registration", "-s", str(tmp_path / "a.zarr/A/1/0"), "-t", str(tmp_path / "b.zarr/A/1/0"),
+                         "-c", str(rough_yml), "-o", str(opt_yml)])
+    assert res.exit_code == 0, res.output
+    To = np.array(yaml.safe_load(opt_yml.read_text())["affine_transform_zyx"])
+    assert np.abs(To[:3, :3] - M[:3, :3]).max() < 3e-3 and np.linalg.norm((To @ centre - M @ centre)[:3]) < 0.15
     # the written settings feed `register` unchanged
     est["keep_overhang"] = True
     out_yml.write_text(yaml.safe_dump(est))

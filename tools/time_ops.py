@@ -84,3 +84,19 @@ if which in ("all", "psf"):
     psf, nb = average_beads_device(vol, centres, margins); torch.cuda.synchronize(); t3 = time.perf_counter()
     print(f"detect_peaks: {len(peaks)} peaks in {(t1-t0)*1e3:.1f} ms; recentre {len(centres)} beads {(t2-t1)*1e3:.1f} ms; "
           f"average {nb} patches of (31,41,41): {(t3-t2)*1e3:.1f} ms")
+if which in ("all", "deskew"):
+    from biahub_amd.deskew import fast_deskew_zyx
+    kw = dict(ls_angle_deg=36.17, px_to_scan_ratio=0.371, keep_overhang=True, average_n_slices=3)
+    for shape in ((256, 1024, 1024), (512, 2048, 2048)):
+        V = np.prod(shape)
+        base = (torch.rand(shape, device=dev) * 400 + 100).round_()
+        for dt in (torch.float32, torch.uint16):
+            vol = base.to(dt)
+            for fill in ("mean", 0):
+                for _ in range(3):
+                    out = fast_deskew_zyx(vol, overhang_fill=fill, **kw); ms = ctx.elapsed_ms(_lib.T_DESKEW)
+                fl = ctx.elapsed_ms(_lib.T_FILL) if fill == "mean" else 0.0
+                b = vol.element_size() * V + 4 * out.numel()
+                print(f"deskew {shape} {dt} fill={fill}: kernel {ms:.2f} ms ({b/ms/1e6:.0f} GB/s algorithmic), fill passes {fl:.2f} ms")
+            del vol
+        del base, out
