@@ -18,8 +18,6 @@ __global__ __launch_bounds__(256) void bin_reduce_kernel(const TIN* __restrict__
                                                          float* __restrict__ part) {
     const long long total = (long long)Zb * Yb * Xb;
     float mn = INFINITY, mx = -INFINITY;
-    const float inv = 1.0f;  // the mean divides by the count (float32 division, like numpy), not by a reciprocal
-    (void)inv;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int x = (int)(i % Xb), y = (int)((i / Xb) % Yb), z = (int)(i / ((long long)Xb * Yb));
         float s = 0.0f;
@@ -28,7 +26,7 @@ __global__ __launch_bounds__(256) void bin_reduce_kernel(const TIN* __restrict__
                 const TIN* row = in + ((size_t)(z * fz + a) * Y + (size_t)(y * fy + b)) * X + (size_t)x * fx;
                 for (int c = 0; c < fx; ++c) s += (float)row[c];
             }
-        if (mean) s = s / (float)(fz * fy * fx);
+        if (mean) s = s / (float)(fz * fy * fx);  // float32 division by the count, like numpy's mean (not a reciprocal)
         out[i] = s;
         mn = fminf(mn, s);
         mx = fmaxf(mx, s);

@@ -386,8 +386,8 @@ struct ColParams {
     int midfuse;        // fuse the unit-twiddle steps around the spectral product (BH_FC_NOZMID=1 turns it off)
 };
 
-// The prefetch registers are eight named float4 (not an array: hipcc keeps a loop-carried float4[8]
-// in scratch memory here even with every index constant).
+// The prefetch registers are sixteen named float4, of which ROUNDS are used (not an array: hipcc keeps a loop-carried
+// float4[] in scratch memory here even with every index constant).  BH_FOR8 applies a macro to all of them.
 #define BH_FOR8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
 template <int MODE, int ROUNDS>
