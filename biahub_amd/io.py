@@ -351,7 +351,8 @@ def process_single_position(func, input_position_path, output_position_path, inp
     from concurrent.futures import ThreadPoolExecutor
 
     def load(u):
-        return np.stack([src.data.read_volume(u[0], c) for c in u[2]])
+        vols = [src.data.read_volume(u[0], c) for c in u[2]]
+        return vols[0][None] if len(vols) == 1 else np.stack(vols)  # the common one-channel unit stays in its pinned block
 
     def store(u, res):
         if res is not None:
