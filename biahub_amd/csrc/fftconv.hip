@@ -34,8 +34,20 @@ typedef float2 cf;
 #endif
 constexpr int FC_NT = BH_FC_NT;    // threads per workgroup
 constexpr int FC_TILE = 16384;     // complex elements per column tile (128 KiB)
-constexpr int FC_XR = 16;          // rows per X-pass tile (8 row pairs)
+#ifndef BH_FC_XR
+#define BH_FC_XR 16
+#endif
+#ifndef BH_FC_XNT
+#define BH_FC_XNT BH_FC_NT
+#endif
+constexpr int FC_XR = BH_FC_XR;    // rows per X-pass tile (FC_XH row pairs y, y + Y/2); a power of two
+constexpr int FC_XH = FC_XR / 2;
+constexpr int FC_LOGXR = FC_XR == 16 ? 4 : (FC_XR == 8 ? 3 : (FC_XR == 4 ? 2 : 1));
+constexpr int FC_LOGXH = FC_LOGXR - 1;
 constexpr int FC_XPITCH = FC_XR + 1;
+constexpr int FC_XNT = BH_FC_XNT;  // threads per workgroup of the X passes
+static_assert(FC_XNT >= 512 && FC_XNT <= 1024, "an X-pass thread owns one complex pair of a row: X/4 <= 512 threads per row");
+static_assert(FC_XR == 2 || FC_XR == 4 || FC_XR == 8 || FC_XR == 16, "FC_XR must be a power of two");
 #ifndef BH_FC_R16
 #define BH_FC_R16 0
 #endif
@@ -114,21 +126,21 @@ BH_CV_OPT(vmulc, cmulc)
 #undef BH_CV_OP2
 #undef BH_CV_OPT
 
-template <bool INV, int BPT, int CPT>
+template <bool INV, int BPT, int CPT, int NT = FC_NT>
 __device__ __forceinline__ void radix4_step(cf* buf, int N, int logW, int P, int h, const cf* t, int tid) {
     const int q = h >> 1;
     const int lw = logW - (CPT == 2 ? 1 : 0);       // log2 of column groups per row
     const int total = (N >> 2) << lw;
     const size_t qP = (size_t)q * P;
     // all threads run the same number of groups; ragged tails clamp the index and skip the store
-    const bool ragged = (total % (BPT * FC_NT)) != 0;
-    for (int g0 = 0; g0 < total; g0 += BPT * FC_NT) {
+    const bool ragged = (total % (BPT * NT)) != 0;
+    for (int g0 = 0; g0 < total; g0 += BPT * NT) {
     CV<CPT> x0[BPT], x1[BPT], x2[BPT], x3[BPT];
     cf t1[BPT], t2[BPT], t3[BPT];
     cf* p0[BPT];
 #pragma unroll
     for (int k = 0; k < BPT; ++k) {
-        const int idx = min(g0 + tid + k * FC_NT, total - 1);
+        const int idx = min(g0 + tid + k * NT, total - 1);
         const int c = (idx & ((1 << lw) - 1)) * CPT;
         const int b = idx >> lw;
         const int j = b & (q - 1);
@@ -145,7 +157,7 @@ __device__ __forceinline__ void radix4_step(cf* buf, int N, int logW, int P, int
     if (ragged) __syncthreads();  // clamped duplicates must all read before anyone writes
 #pragma unroll
     for (int k = 0; k < BPT; ++k) {
-        if (g0 + tid + k * FC_NT < total) {
+        if (g0 + tid + k * NT < total) {
             if (!INV) {
                 const CV<CPT> s02 = vadd<CPT>(x0[k], x2[k]), d02 = vsub<CPT>(x0[k], x2[k]);
                 const CV<CPT> s13 = vadd<CPT>(x1[k], x3[k]), d13 = vmul_mi<CPT>(vsub<CPT>(x1[k], x3[k]));
@@ -168,21 +180,21 @@ __device__ __forceinline__ void radix4_step(cf* buf, int N, int logW, int P, int
     }
 }
 
-template <bool INV, int BPT, int CPT>
+template <bool INV, int BPT, int CPT, int NT = FC_NT>
 __device__ __forceinline__ void radix2_step(cf* buf, int N, int logW, int P, const cf* t, int tid) {
     const int h = N >> 1;
     const int lw = logW - (CPT == 2 ? 1 : 0);
     const int total = h << lw;
     const size_t hP = (size_t)h * P;
     constexpr int B2 = 2 * BPT;  // a radix-2 step has twice the butterflies of a radix-4 step
-    const bool ragged = (total % (B2 * FC_NT)) != 0;
-    for (int g0 = 0; g0 < total; g0 += B2 * FC_NT) {
+    const bool ragged = (total % (B2 * NT)) != 0;
+    for (int g0 = 0; g0 < total; g0 += B2 * NT) {
     CV<CPT> a[B2], b[B2];
     cf w[B2];
     cf* pa[B2];
 #pragma unroll
     for (int k = 0; k < B2; ++k) {
-        const int idx = min(g0 + tid + k * FC_NT, total - 1);
+        const int idx = min(g0 + tid + k * NT, total - 1);
         const int c = (idx & ((1 << lw) - 1)) * CPT;
         const int j = idx >> lw;
         pa[k] = buf + (size_t)j * P + c;
@@ -193,7 +205,7 @@ __device__ __forceinline__ void radix2_step(cf* buf, int N, int logW, int P, con
     if (ragged) __syncthreads();
 #pragma unroll
     for (int k = 0; k < B2; ++k) {
-        if (g0 + tid + k * FC_NT < total) {
+        if (g0 + tid + k * NT < total) {
             if (!INV) {
                 vadd<CPT>(a[k], b[k]).st(pa[k]);
                 vmul<CPT>(vsub<CPT>(a[k], b[k]), w[k]).st(pa[k] + hP);
@@ -232,14 +244,14 @@ __device__ __forceinline__ void bfly4(cf& x0, cf& x1, cf& x2, cf& x3, cf t1, cf 
 // Radix-16 step = the two radix-4 steps of half-sizes h and h/4 fused in registers: 16 legs spaced h/8, one
 // LDS round trip and one barrier instead of two.  Forward runs step h then h/4, inverse the mirror image.
 // tA / tB are the twiddle tables of the radix-4 steps h and h/4.
-template <bool INV>
+template <bool INV, int NT = FC_NT>
 __device__ __forceinline__ void radix16_step(cf* buf, int N, int logW, int P, int h, const cf* tA, const cf* tB, int tid) {
     const int qB = h >> 3;
     const int W = 1 << logW;
     const int total = (N >> 4) << logW;
-    const bool ragged = (total % FC_NT) != 0;
+    const bool ragged = (total % NT) != 0;
 #pragma unroll 1
-    for (int g0 = 0; g0 < total; g0 += FC_NT) {
+    for (int g0 = 0; g0 < total; g0 += NT) {
         const int idx = min(g0 + tid, total - 1);
         const int c = idx & (W - 1);
         const int b = idx >> logW;
@@ -282,7 +294,7 @@ __device__ __forceinline__ void radix16_step(cf* buf, int N, int logW, int P, in
 // the radix-2 step of an odd log2(N) use <BPT, CPT>.
 // SKIP2: leave out the h = 2 radix-4 step (last forward / first inverse; its twiddles are all 1) — the convolution
 // passes run it fused with the spectral multiply in registers (conv_mid_step).
-template <bool INV, int BPT, int CPT, bool R16 = false, bool SKIP2 = false>
+template <bool INV, int BPT, int CPT, bool R16 = false, bool SKIP2 = false, int NT = FC_NT>
 __device__ __forceinline__ void fft_lds(cf* buf, int N, int logN, int logW, int P, const cf* tw, int tid) {
     const bool odd = logN & 1;
     const int H0 = odd ? (N >> 2) : (N >> 1);
@@ -291,31 +303,31 @@ __device__ __forceinline__ void fft_lds(cf* buf, int N, int logN, int logW, int 
     const int n16 = R16 ? (L4 >> 1) : 0;          // of which fused pairwise
     if (!INV) {
         if (odd) {
-            radix2_step<false, BPT, CPT>(buf, N, logW, P, tw, tid);
+            radix2_step<false, BPT, CPT, NT>(buf, N, logW, P, tw, tid);
             __syncthreads();
         }
         int h = H0;
         for (int s = 0; s < n16; ++s, h >>= 4) {
-            radix16_step<false>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), t4 + (2 * H0 - 2 * (h >> 2)), tid);
+            radix16_step<false, NT>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), t4 + (2 * H0 - 2 * (h >> 2)), tid);
             __syncthreads();
         }
         for (; h >= (SKIP2 ? 8 : 2); h >>= 2) {
-            radix4_step<false, BPT, CPT>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
+            radix4_step<false, BPT, CPT, NT>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
             __syncthreads();
         }
     } else {
         const int hr = H0 >> (4 * n16);  // largest half-size left to plain radix-4 steps
         for (int h = SKIP2 ? 8 : 2; h <= hr; h <<= 2) {
-            radix4_step<true, BPT, CPT>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
+            radix4_step<true, BPT, CPT, NT>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
             __syncthreads();
         }
         for (int s = n16 - 1; s >= 0; --s) {
             const int h = H0 >> (4 * s);
-            radix16_step<true>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), t4 + (2 * H0 - 2 * (h >> 2)), tid);
+            radix16_step<true, NT>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), t4 + (2 * H0 - 2 * (h >> 2)), tid);
             __syncthreads();
         }
         if (odd) {
-            radix2_step<true, BPT, CPT>(buf, N, logW, P, tw, tid);
+            radix2_step<true, BPT, CPT, NT>(buf, N, logW, P, tw, tid);
             __syncthreads();
         }
     }
@@ -595,22 +607,22 @@ struct XParams {
     float eps;
 };
 
-// tile = (z, group g): rows c < 8 -> y = 8g + c ; rows c >= 8 -> y = 8g + (c - 8) + Y/2.
-// row0 = z * Y + 8 g is computed ONCE per tile (a 64-bit division per row load costs more than the FFT's index math).
+// tile = (z, group g): rows c < XH -> y = XH g + c ; rows c >= XH -> y = XH g + (c - XH) + Y/2   (XH = FC_XH).
+// row0 = z * Y + XH g is computed ONCE per tile (a 64-bit division per row load costs more than the FFT's index math).
 __device__ __forceinline__ long x_tile_row0(const ConvDims& d, long tile) {
     const int gpz = d.Y / FC_XR;  // groups per z
     const int ti = (int)tile;     // host guarantees < 2^31 tiles
     const int z = ti / gpz;
     const int g = ti - z * gpz;
-    return (long)z * d.Y + 8 * g;
+    return (long)z * d.Y + FC_XH * g;
 }
 __device__ __forceinline__ long x_row_index(const ConvDims& d, long row0, int c) {
-    return row0 + (c & 7) + ((c >> 3) ? d.Y / 2 : 0);
+    return row0 + (c & (FC_XH - 1)) + ((c >> FC_LOGXH) ? d.Y / 2 : 0);
 }
 // 32-bit element offset of (tile row c, column col) from the tile's first row, for a row pitch `pitch`
 // ((Y/2 + 8) * pitch < 2^31 for every supported shape)
 __device__ __forceinline__ unsigned x_row_off(const ConvDims& d, int c, int pitch, int col) {
-    return (unsigned)(((c & 7) + ((c >> 3) ? d.Y / 2 : 0)) * pitch + col);
+    return (unsigned)(((c & (FC_XH - 1)) + ((c >> FC_LOGXH) ? d.Y / 2 : 0)) * pitch + col);
 }
 // opaque copy of a per-thread value: address math built on it stays inside the tile loop instead of being
 // hoisted into (scarce) registers for the whole kernel
@@ -622,7 +634,7 @@ __device__ __forceinline__ int opaque(int v) {
 // untangle in place after the packed length-M FFT: pairs (p, mirror(p)); u = 0 handles DC + Nyquist and p = 1
 template <bool INV>
 __device__ __forceinline__ void untangle_lds(cf* buf, const cf* ut, int M, int tid) {
-    for (int idx = tid; idx < (M >> 1) * FC_XR; idx += FC_NT) {
+    for (int idx = tid; idx < (M >> 1) * FC_XR; idx += FC_XNT) {
         const int c = idx % FC_XR;
         const int u = idx / FC_XR;
         if (u == 0) {
@@ -664,7 +676,7 @@ __device__ __forceinline__ void x_forward_from_lds(cf* buf, const cf* tw, const 
                                                    const ConvDims& d, long t, int tid, int q, int rr, int RPR) {
     const int M = d.M;
     constexpr int HALF = ROUNDS / 2;
-    fft_lds<false, 2, 1, FC_R16>(buf, M, d.logM, 4, FC_XPITCH, tw, tid);
+    fft_lds<false, 2, 1, FC_R16, false, FC_XNT>(buf, M, d.logM, FC_LOGXR, FC_XPITCH, tw, tid);
     untangle_lds<false>(buf, ut, M, tid);
     __syncthreads();
 
@@ -676,11 +688,11 @@ __device__ __forceinline__ void x_forward_from_lds(cf* buf, const cf* tw, const 
         // this thread's rounds u and u + HALF are exactly a pair (y, y + Y/2): two columns per lane, 16-B stores
 #pragma unroll
         for (int u = 0; u < (HALF > 0 ? HALF : 1); ++u) {
-            const int c = rr + u * RPR;  // < 8
-            const int y = 8 * g + c;
+            const int c = rr + u * RPR;  // < FC_XH
+            const int y = FC_XH * g + c;
             const cf w = p.twy[y];
-            const cf xa0 = buf[(size_t)(2 * q) * FC_XPITCH + c], xb0 = buf[(size_t)(2 * q) * FC_XPITCH + c + 8];
-            const cf xa1 = buf[(size_t)(2 * q + 1) * FC_XPITCH + c], xb1 = buf[(size_t)(2 * q + 1) * FC_XPITCH + c + 8];
+            const cf xa0 = buf[(size_t)(2 * q) * FC_XPITCH + c], xb0 = buf[(size_t)(2 * q) * FC_XPITCH + c + FC_XH];
+            const cf xa1 = buf[(size_t)(2 * q + 1) * FC_XPITCH + c], xb1 = buf[(size_t)(2 * q + 1) * FC_XPITCH + c + FC_XH];
             const cf A0 = cadd(xa0, xb0), A1 = cadd(xa1, xb1);
             const cf B0 = cmul(csub(xa0, xb0), w), B1 = cmul(csub(xa1, xb1), w);
             cf* rowA = p.S + ((long)z * d.Y + y) * d.XP + 2 * q;
@@ -688,12 +700,12 @@ __device__ __forceinline__ void x_forward_from_lds(cf* buf, const cf* tw, const 
             *reinterpret_cast<float4*>(rowA) = make_float4(A0.x, A0.y, A1.x, A1.y);
             *reinterpret_cast<float4*>(rowB) = make_float4(B0.x, B0.y, B1.x, B1.y);
         }
-        if (tid < 8 * 16) {  // Nyquist column + zero pad columns
+        if (tid < FC_XH * 16) {  // Nyquist column + zero pad columns
             const int rp = tid >> 4, col = M + (tid & 15);
-            const int y = 8 * g + rp;
+            const int y = FC_XH * g + rp;
             cf A = make_float2(0.f, 0.f), B = A;
             if (col == M) {
-                const cf xa = buf[(size_t)M * FC_XPITCH + rp], xb = buf[(size_t)M * FC_XPITCH + rp + 8];
+                const cf xa = buf[(size_t)M * FC_XPITCH + rp], xb = buf[(size_t)M * FC_XPITCH + rp + FC_XH];
                 A = cadd(xa, xb);
                 B = cmul(csub(xa, xb), p.twy[y]);
             }
@@ -701,13 +713,13 @@ __device__ __forceinline__ void x_forward_from_lds(cf* buf, const cf* tw, const 
             p.S[((long)z * d.Y + y + d.Y / 2) * d.XP + col] = B;
         }
     } else {
-        for (int idx = tid; idx < 8 * d.XP; idx += FC_NT) {
+        for (int idx = tid; idx < FC_XH * d.XP; idx += FC_XNT) {
             const int pcol = idx % d.XP;
             const int rp = idx / d.XP;
-            const int y = 8 * g + rp;
+            const int y = FC_XH * g + rp;
             cf A = make_float2(0.f, 0.f), B = A;
             if (pcol <= M) {
-                const cf xa = buf[(size_t)pcol * FC_XPITCH + rp], xb = buf[(size_t)pcol * FC_XPITCH + rp + 8];
+                const cf xa = buf[(size_t)pcol * FC_XPITCH + rp], xb = buf[(size_t)pcol * FC_XPITCH + rp + FC_XH];
                 A = cadd(xa, xb);
                 B = cmul(csub(xa, xb), p.twy[y]);
             }
@@ -718,7 +730,7 @@ __device__ __forceinline__ void x_forward_from_lds(cf* buf, const cf* tw, const 
 }
 
 template <int ROUNDS>
-__global__ __launch_bounds__(FC_NT) void x_fwd_kernel(XParams p) {
+__global__ __launch_bounds__(FC_XNT) void x_fwd_kernel(XParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ConvDims d = p.d;
     const int M = d.M;
@@ -726,11 +738,11 @@ __global__ __launch_bounds__(FC_NT) void x_fwd_kernel(XParams p) {
     cf* tw = buf + (size_t)(M + 1) * FC_XPITCH;
     cf* ut = tw + p.ntw;                                                    // [M]
     const int tid = threadIdx.x;
-    for (int i = tid; i < p.ntw; i += FC_NT) tw[i] = p.tw[i];
-    for (int i = tid; i < M; i += FC_NT) ut[i] = p.untangle[i];
+    for (int i = tid; i < p.ntw; i += FC_XNT) tw[i] = p.tw[i];
+    for (int i = tid; i < M; i += FC_XNT) ut[i] = p.untangle[i];
 
     const int QPR = M >> 1;                 // float4 per real row
-    const int RPR = FC_NT / QPR;            // rows per round (QPR <= 512)
+    const int RPR = FC_XNT / QPR;            // rows per round (QPR <= 512)
     const int q = tid % QPR;
     const int rr = tid / QPR;
     const int gpz = d.Y / FC_XR;
@@ -775,7 +787,7 @@ __global__ __launch_bounds__(FC_NT) void x_fwd_kernel(XParams p) {
 }
 
 template <int EPI, int ROUNDS, bool FUSE>
-__global__ __launch_bounds__(FC_NT) void x_inv_kernel(XParams p) {
+__global__ __launch_bounds__(FC_XNT) void x_inv_kernel(XParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ConvDims d = p.d;
     const int M = d.M;
@@ -783,11 +795,11 @@ __global__ __launch_bounds__(FC_NT) void x_inv_kernel(XParams p) {
     cf* tw = buf + (size_t)(M + 1) * FC_XPITCH;
     cf* ut = tw + p.ntw;
     const int tid = threadIdx.x;
-    for (int i = tid; i < p.ntw; i += FC_NT) tw[i] = p.tw[i];
-    for (int i = tid; i < M; i += FC_NT) ut[i] = p.untangle[i];
+    for (int i = tid; i < p.ntw; i += FC_XNT) tw[i] = p.tw[i];
+    for (int i = tid; i < M; i += FC_XNT) ut[i] = p.untangle[i];
 
     const int QPR = M >> 1;
-    const int RPR = FC_NT / QPR;
+    const int RPR = FC_XNT / QPR;
     const int q = tid % QPR;
     const int rr = tid / QPR;
     const int gpz = d.Y / FC_XR;
@@ -806,45 +818,45 @@ __global__ __launch_bounds__(FC_NT) void x_inv_kernel(XParams p) {
             const int c = min(rro + u * RPR, FC_XR - 1);
             v[u] = *reinterpret_cast<const float4*>(base + x_row_off(d, c, d.XP, 2 * q));
         }
-        const int rp = opaque(tid) & 7;  // every thread loads (16 distinct addresses per tile: cache hits), 8 use it
+        const int rp = opaque(tid) & (FC_XH - 1);  // every thread loads (16 distinct addresses per tile: cache hits), 8 use it
         nyA = base[x_row_off(d, rp, d.XP, M)];
-        nyB = base[x_row_off(d, rp + 8, d.XP, M)];
+        nyB = base[x_row_off(d, rp + FC_XH, d.XP, M)];
     };
     long t = blockIdx.x;
     if (FAST && t < ntiles) load_tile(t);
     for (; t < ntiles; t += gridDim.x) {
         const int z = (int)t / gpz;
         const int g = (int)t - z * gpz;
-        const long trow0 = (long)z * d.Y + 8 * g;
+        const long trow0 = (long)z * d.Y + FC_XH * g;
         if (FAST) {
             // undo the Y radix-2 step in registers, write X[p] into LDS (transposed)
 #pragma unroll
             for (int u = 0; u < (HALF > 0 ? HALF : 1); ++u) {
-                const int c = rr + u * RPR;  // < 8
-                const cf w = p.twy[8 * g + c];
+                const int c = rr + u * RPR;  // < FC_XH
+                const cf w = p.twy[FC_XH * g + c];
                 const float4 A = v[u], B = v[(u + HALF) % ROUNDS];
                 const cf ub0 = cmulc(make_float2(B.x, B.y), w), ub1 = cmulc(make_float2(B.z, B.w), w);
                 const cf a0 = make_float2(A.x, A.y), a1 = make_float2(A.z, A.w);
                 buf[(size_t)(2 * q) * FC_XPITCH + c] = cadd(a0, ub0);
-                buf[(size_t)(2 * q) * FC_XPITCH + c + 8] = csub(a0, ub0);
+                buf[(size_t)(2 * q) * FC_XPITCH + c + FC_XH] = csub(a0, ub0);
                 buf[(size_t)(2 * q + 1) * FC_XPITCH + c] = cadd(a1, ub1);
-                buf[(size_t)(2 * q + 1) * FC_XPITCH + c + 8] = csub(a1, ub1);
+                buf[(size_t)(2 * q + 1) * FC_XPITCH + c + FC_XH] = csub(a1, ub1);
             }
-            if (tid < 8) {
-                const cf ub = cmulc(nyB, p.twy[8 * g + tid]);
+            if (tid < FC_XH) {
+                const cf ub = cmulc(nyB, p.twy[FC_XH * g + tid]);
                 buf[(size_t)M * FC_XPITCH + tid] = cadd(nyA, ub);
-                buf[(size_t)M * FC_XPITCH + tid + 8] = csub(nyA, ub);
+                buf[(size_t)M * FC_XPITCH + tid + FC_XH] = csub(nyA, ub);
             }
         } else {
-            for (int idx = tid; idx < 8 * (M + 1); idx += FC_NT) {
+            for (int idx = tid; idx < FC_XH * (M + 1); idx += FC_XNT) {
                 const int pcol = idx % (M + 1);
                 const int rp = idx / (M + 1);
-                const int y = 8 * g + rp;
+                const int y = FC_XH * g + rp;
                 const cf A = p.S[((long)z * d.Y + y) * d.XP + pcol];
                 const cf B = p.S[((long)z * d.Y + y + d.Y / 2) * d.XP + pcol];
                 const cf ub = cmulc(B, p.twy[y]);
                 buf[(size_t)pcol * FC_XPITCH + rp] = cadd(A, ub);
-                buf[(size_t)pcol * FC_XPITCH + rp + 8] = csub(A, ub);
+                buf[(size_t)pcol * FC_XPITCH + rp + FC_XH] = csub(A, ub);
             }
         }
         __syncthreads();
@@ -871,7 +883,7 @@ __global__ __launch_bounds__(FC_NT) void x_inv_kernel(XParams p) {
         }
         untangle_lds<true>(buf, ut, M, tid);
         __syncthreads();
-        fft_lds<true, 1, 1, FC_R16>(buf, M, d.logM, 4, FC_XPITCH, tw, tid);
+        fft_lds<true, 1, 1, FC_R16, false, FC_XNT>(buf, M, d.logM, FC_LOGXR, FC_XPITCH, tw, tid);
         if (!FUSE && EPI != XE_STORE) load_aux();
         // natural order now: z[j] = x[2j] + i x[2j+1]; apply the fused epilogue to the real rows
 #pragma unroll
@@ -933,7 +945,7 @@ bool fftconv_supported(int64_t Z, int64_t Y, int64_t X) {
     auto pow2 = [](int64_t v) { return v > 0 && (v & (v - 1)) == 0; };
     if (!pow2(Z) || !pow2(Y) || !pow2(X)) return false;
     if (X < 64 || X > 2048) return false;          // M = X/2 in [32, 1024]: (M+1)*17*8 + tables <= 160 KiB
-    if (Y < 2 * 16 || Y / 2 > 2048) return false;   // Y/2 rows x >= 8 columns per tile, whole groups of 16 rows
+    if (Y < 2 * 16 || Y / 2 > 2048) return false;   // Y/2 rows x >= 8 columns per tile, whole groups of FC_XR rows
     if (Z < 4 || Z > 2048) return false;
     if ((Y % FC_XR) != 0) return false;
     const int M = (int)X / 2;
@@ -1087,16 +1099,17 @@ static int launch_x(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, cons
     p.eps = eps;
     const size_t lds = (size_t)(pl.d.M + 1) * FC_XPITCH * 8 + (size_t)pl.ntw_x * 8 + (size_t)pl.d.M * 8;
     const long ntiles = (long)pl.d.Z * (pl.d.Y / FC_XR);
-    const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
+    const int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / FC_XNT, (160 * 1024) / (lds + 1024)));
+    const int grid = (int)std::min<long>(ntiles, (long)ctx->num_cus * wgs_per_cu);
     auto run = [&](auto kern) -> int {
         BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(FC_NT), lds, ctx->stream, p);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(FC_XNT), lds, ctx->stream, p);
         BH_CHECK_HIP(hipGetLastError());
         return BH_OK;
     };
     const int QPR = pl.d.M / 2;
-    const int rounds = (int)ceil_div(FC_XR, std::max(1, FC_NT / QPR));
+    const int rounds = (int)ceil_div(FC_XR, std::max(1, FC_XNT / QPR));
 #define BH_X_DISPATCH(R)                                                  \
     if (!inverse) return run(x_fwd_kernel<R>);                            \
     switch (epi) {                                                        \
