@@ -400,9 +400,14 @@ static int stage_rl_psf(bh_ctx* ctx, const float* psf, int64_t pz, int64_t py, i
 // multiply/clip ride in the inverse X passes.
 static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, int64_t pz, int64_t py, int64_t px,
                                  int64_t Z, int64_t Y, int64_t X, int iterations, float eps, float* out) {
+    const int64_t V = Z * Y * X;
+    if (iterations == 0) {  // e0 = max(d, 0): nothing to convolve (the fused passes write `out` only from iteration 1 on)
+        hipLaunchKernelGGL(clip_copy_kernel, grid_for(ctx, V), dim3(256), 0, ctx->stream, d, out, V);
+        BH_CHECK_HIP(hipGetLastError());
+        return BH_OK;
+    }
     ConvPlan* pl;
     BH_TRY(fftconv_plan(ctx, Z, Y, X, &pl));
-    const int64_t V = Z * Y * X;
     const size_t NS = fftconv_spectrum_elems(*pl);
     float* real = nullptr;
     cf *spec, *otf;

@@ -374,6 +374,13 @@ def test_richardson_lucy_fused_engine_vs_oracle(gpu, shape, pshape, monkeypatch)
     v, pt = torch.from_numpy(vol).to(gpu), torch.from_numpy(psf).to(gpu)
     got = richardson_lucy(v, pt, 5, 1e-6).cpu().numpy()
     assert rel_err(got, want) <= FFT_TOL, rel_err(got, want)
+    assert np.array_equal(richardson_lucy(v, pt, 0, 1e-6).cpu().numpy(), np.maximum(vol, 0))  # zero iterations: e0
+    alias = v.clone()
+    from biahub_amd.device import get_context, ptr
+    from biahub_amd import _lib
+    ctx = get_context(gpu)
+    _lib.check(ctx.lib.bh_richardson_lucy(ctx.handle, ptr(alias), ptr(pt), *pshape, *shape, 5, 1e-6, ptr(alias)))
+    assert np.array_equal(alias.cpu().numpy(), got)                                           # in == out is allowed
     monkeypatch.setenv("BH_FFT_BACKEND", "hipfft")
     got_hipfft = richardson_lucy(v, pt, 5, 1e-6).cpu().numpy()
     assert rel_err(got_hipfft, want) <= FFT_TOL
