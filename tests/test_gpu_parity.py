@@ -533,6 +533,16 @@ def test_estimate_registration_recovers_similarity(gpu):
     composed = estimate_czyx(arm_a[None], arm_b[None], init, crop=True)
     assert np.abs(composed.matrix[:3, :3] - M[:3, :3]).max() < 3e-3
     assert np.linalg.norm((composed.matrix @ centre - M @ centre)[:3]) < 0.15
+    # 2-D images are one-plane volumes with in-plane parameters only (registration/ants.py:82-88)
+    img = O.synthetic_volume((1, 192, 192), seed=8, n_blobs=120)[0]
+    M2 = _similarity(1.5, 1.0, (0.0, 2.5, -1.75))
+    img_b = O.affine_pull(img[None], M2, (1,) + img.shape, 1, O.BOUNDARY_ITK)[0]
+    img_b = np.where(img_b == 0, 110.0, img_b).astype(np.float32)
+    f2, i2 = estimate(ref=img_b, mov=img, ants_kwargs={"type_of_transform": "Rigid", "aff_shrink_factors": (2, 1),
+                                                       "aff_iterations": (300, 60), "aff_smoothing_sigmas": (1, 0)})
+    assert f2.matrix.shape == (3, 3) and np.abs(f2.matrix[:2, :2] - M2[1:3, 1:3]).max() < 3e-3
+    c2 = np.array([95.5, 95.5, 1.0])
+    assert np.linalg.norm((f2.matrix @ c2)[:2] - (M2[1:3][:, 1:] @ c2)[:2]) < 0.15
     with pytest.raises(ValueError, match="Dimension mismatch"):
         estimate(ref=arm_b, mov=arm_a[0])
     with pytest.raises(ValueError, match="NaN or zeros"):
