@@ -54,9 +54,19 @@ void set_error(const char* fmt, ...);
 
 enum TimerSlot { T_DESKEW = 0, T_FILL, T_RL_TOTAL, T_TIKHONOV, T_AFFINE, T_CROPFLIP, T_RL_ITER, T_TF, T_FLATFIELD, T_COUNT };
 
+// Library plans of the 3-D real transform of a (Z, Y, X) volume.  Shapes with a non-power-of-two extent (what reaches the
+// library in production: the fused engine in fftconv.hip takes the power-of-two ones) use hipfftPlan3d.  All-power-of-two
+// shapes (only here when BH_FFT_BACKEND=hipfft forces it, or beyond the engine's size limits) are decomposed into batched
+// 1-D real transforms along x and one strided batched 2-D complex transform over (z, y): rocFFT 1.0.36 (ROCm 7.2) returns
+// wrong 3-D real transforms for some power-of-two shapes once 3-D plans of certain other power-of-two shapes exist in the
+// process (tools/hipfft_two_plans.cpp; tools/hipfft_plan3d_sweep.cpp: 8 of 131 power-of-two plans wrong, 0 of 319
+// mixed-radix ones); the decomposition is immune (tools/hipfft_separable_probe.cpp) but ~2.5x slower at large sizes.
 struct FftPlans {
-    hipfftHandle r2c = 0;
-    hipfftHandle c2r = 0;
+    bool separable = false;
+    hipfftHandle r2c = 0, c2r = 0;  // 3-D plans (separable == false)
+    hipfftHandle xr = 0;            // x: Z*Y rows, real X -> complex X/2+1
+    hipfftHandle xi = 0;            // x: complex X/2+1 -> real X
+    hipfftHandle zy = 0;            // (z, y): complex, element stride X/2+1, one batch entry per x
     void* work = nullptr;
     size_t work_bytes = 0;
 };
@@ -90,6 +100,10 @@ namespace bh {
 // returns a device buffer of at least `bytes`, cached under `name`
 int get_scratch(bh_ctx* ctx, const char* name, size_t bytes, void** out);
 int get_plans(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, FftPlans** out);
+// real (Z,Y,X) -> half spectrum (Z,Y,X/2+1), unnormalised
+int fft_forward(const FftPlans* pl, const float* real, float2* spec);
+// half spectrum -> real, unnormalised; the spectrum buffer is overwritten
+int fft_inverse(const FftPlans* pl, float2* spec, float* real);
 
 struct ScopedTimer {
     bh_ctx* ctx;

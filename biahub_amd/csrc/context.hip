@@ -40,24 +40,60 @@ int get_plans(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, FftPlans** out) {
     BH_REQUIRE(Z > 0 && Y > 0 && X > 0 && Z < (1ll << 31) && Y < (1ll << 31) && X < (1ll << 31),
                "invalid FFT shape (%lld,%lld,%lld)", (long long)Z, (long long)Y, (long long)X);
     FftPlans p;
-    size_t ws_r2c = 0, ws_c2r = 0;
-    BH_CHECK_FFT(hipfftCreate(&p.r2c));
-    BH_CHECK_FFT(hipfftSetAutoAllocation(p.r2c, 0));
-    BH_CHECK_FFT(hipfftMakePlan3d(p.r2c, (int)Z, (int)Y, (int)X, HIPFFT_R2C, &ws_r2c));
-    BH_CHECK_FFT(hipfftCreate(&p.c2r));
-    BH_CHECK_FFT(hipfftSetAutoAllocation(p.c2r, 0));
-    BH_CHECK_FFT(hipfftMakePlan3d(p.c2r, (int)Z, (int)Y, (int)X, HIPFFT_C2R, &ws_c2r));
-    p.work_bytes = ws_r2c > ws_c2r ? ws_r2c : ws_c2r;
-    if (p.work_bytes) {
-        // one work area shared by both directions (they never run concurrently on one stream)
-        BH_CHECK_HIP(hipMalloc(&p.work, p.work_bytes));
-        BH_CHECK_FFT(hipfftSetWorkArea(p.r2c, p.work));
-        BH_CHECK_FFT(hipfftSetWorkArea(p.c2r, p.work));
+    auto pow2 = [](int64_t n) { return (n & (n - 1)) == 0; };
+    p.separable = getenv("BH_FFT_SEPARABLE") != nullptr || (pow2(Z) && pow2(Y) && pow2(X));
+    hipfftHandle* hs[3] = {&p.r2c, &p.c2r, nullptr};
+    size_t ws[3] = {0, 0, 0};
+    int nh = 2;
+    if (p.separable) {
+        BH_REQUIRE(Z * Y < (1ll << 31), "FFT batch %lld too large", (long long)(Z * Y));
+        hs[0] = &p.xr, hs[1] = &p.xi, hs[2] = &p.zy;
+        nh = 3;
     }
-    BH_CHECK_FFT(hipfftSetStream(p.r2c, ctx->stream));
-    BH_CHECK_FFT(hipfftSetStream(p.c2r, ctx->stream));
+    for (int i = 0; i < nh; ++i) {
+        BH_CHECK_FFT(hipfftCreate(hs[i]));
+        BH_CHECK_FFT(hipfftSetAutoAllocation(*hs[i], 0));
+    }
+    if (p.separable) {
+        const int Xh = (int)(X / 2 + 1);
+        int nx[1] = {(int)X}, nzy[2] = {(int)Z, (int)Y};
+        BH_CHECK_FFT(hipfftMakePlanMany(p.xr, 1, nx, nullptr, 1, (int)X, nullptr, 1, Xh, HIPFFT_R2C, (int)(Z * Y), &ws[0]));
+        BH_CHECK_FFT(hipfftMakePlanMany(p.xi, 1, nx, nullptr, 1, Xh, nullptr, 1, (int)X, HIPFFT_C2R, (int)(Z * Y), &ws[1]));
+        BH_CHECK_FFT(hipfftMakePlanMany(p.zy, 2, nzy, nzy, Xh, 1, nzy, Xh, 1, HIPFFT_C2C, Xh, &ws[2]));
+    } else {
+        BH_CHECK_FFT(hipfftMakePlan3d(p.r2c, (int)Z, (int)Y, (int)X, HIPFFT_R2C, &ws[0]));
+        BH_CHECK_FFT(hipfftMakePlan3d(p.c2r, (int)Z, (int)Y, (int)X, HIPFFT_C2R, &ws[1]));
+    }
+    for (int i = 0; i < nh; ++i)
+        if (ws[i] > p.work_bytes) p.work_bytes = ws[i];
+    // one work area shared by all plans of the shape (they never run concurrently on one stream)
+    if (p.work_bytes) BH_CHECK_HIP(hipMalloc(&p.work, p.work_bytes));
+    for (int i = 0; i < nh; ++i) {
+        if (p.work_bytes) BH_CHECK_FFT(hipfftSetWorkArea(*hs[i], p.work));
+        BH_CHECK_FFT(hipfftSetStream(*hs[i], ctx->stream));
+    }
     auto ins = ctx->plans.emplace(key, p);
     *out = &ins.first->second;
+    return BH_OK;
+}
+
+int fft_forward(const FftPlans* pl, const float* real, float2* spec) {
+    if (!pl->separable) {
+        BH_CHECK_FFT(hipfftExecR2C(pl->r2c, const_cast<float*>(real), (hipfftComplex*)spec));
+        return BH_OK;
+    }
+    BH_CHECK_FFT(hipfftExecR2C(pl->xr, const_cast<float*>(real), (hipfftComplex*)spec));
+    BH_CHECK_FFT(hipfftExecC2C(pl->zy, (hipfftComplex*)spec, (hipfftComplex*)spec, HIPFFT_FORWARD));
+    return BH_OK;
+}
+
+int fft_inverse(const FftPlans* pl, float2* spec, float* real) {
+    if (!pl->separable) {
+        BH_CHECK_FFT(hipfftExecC2R(pl->c2r, (hipfftComplex*)spec, real));
+        return BH_OK;
+    }
+    BH_CHECK_FFT(hipfftExecC2C(pl->zy, (hipfftComplex*)spec, (hipfftComplex*)spec, HIPFFT_BACKWARD));
+    BH_CHECK_FFT(hipfftExecC2R(pl->xi, (hipfftComplex*)spec, real));
     return BH_OK;
 }
 
@@ -96,8 +132,8 @@ int bh_ctx_release_workspace(bh_ctx* ctx) {
     BH_CHECK_HIP(hipSetDevice(ctx->device));
     BH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     for (auto& kv : ctx->plans) {
-        if (kv.second.r2c) hipfftDestroy(kv.second.r2c);
-        if (kv.second.c2r) hipfftDestroy(kv.second.c2r);
+        for (hipfftHandle h : {kv.second.r2c, kv.second.c2r, kv.second.xr, kv.second.xi, kv.second.zy})
+            if (h) hipfftDestroy(h);
         if (kv.second.work) (void)hipFree(kv.second.work);
     }
     ctx->plans.clear();
@@ -130,8 +166,8 @@ int bh_ctx_set_stream(bh_ctx* ctx, void* hip_stream) {
     BH_REQUIRE(ctx != nullptr, "ctx is NULL");
     ctx->stream = (hipStream_t)hip_stream;
     for (auto& kv : ctx->plans) {
-        BH_CHECK_FFT(hipfftSetStream(kv.second.r2c, ctx->stream));
-        BH_CHECK_FFT(hipfftSetStream(kv.second.c2r, ctx->stream));
+        for (hipfftHandle h : {kv.second.r2c, kv.second.c2r, kv.second.xr, kv.second.xi, kv.second.zy})
+            if (h) BH_CHECK_FFT(hipfftSetStream(h, ctx->stream));
     }
     return BH_OK;
 }

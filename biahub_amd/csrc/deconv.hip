@@ -491,7 +491,7 @@ int bh_transfer_function(bh_ctx* ctx, const float* psf, int64_t pz, int64_t py, 
     pad_before(px, X, &bx);
     hipLaunchKernelGGL(place_psf_kernel, grid_for(ctx, pz * py * px), dim3(256), 0, s, psf, real, (int)pz, (int)py,
                        (int)px, Z, Y, X, bz, by, bx, 0, 0, 0, (const double*)nullptr);
-    BH_CHECK_FFT(hipfftExecR2C(pl->r2c, real, (hipfftComplex*)spec));
+    BH_TRY(fft_forward(pl, real, spec));
     // magnitude goes into the (now free) real buffer: NS floats <= V + slack? NS*4 <= V*4 only when Xh <= X
     float* mag;
     BH_TRY(get_scratch(ctx, "tf_mag", NS * sizeof(float), (void**)&mag));
@@ -541,11 +541,11 @@ int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t
         const int64_t Xh = X / 2 + 1, NS = Z * Y * Xh;
         BH_TRY(get_scratch(ctx, "fft_spec", NS * sizeof(cf), (void**)&s1));
         BH_TRY(get_scratch(ctx, "pcc_spec2", NS * sizeof(cf), (void**)&s2));
-        BH_CHECK_FFT(hipfftExecR2C(pl->r2c, const_cast<float*>(ref), (hipfftComplex*)s1));
-        BH_CHECK_FFT(hipfftExecR2C(pl->r2c, const_cast<float*>(mov), (hipfftComplex*)s2));
+        BH_TRY(fft_forward(pl, ref, s1));
+        BH_TRY(fft_forward(pl, mov, s2));
         hipLaunchKernelGGL(pcc_product_kernel, grid_for(ctx, NS), dim3(256), 0, s, s1, s2, NS, normalization,
                            (float)(1.0 / (double)V));
-        BH_CHECK_FFT(hipfftExecC2R(plc->c2r, (hipfftComplex*)s1, corr));
+        BH_TRY(fft_inverse(plc, s1, corr));
     }
     hipLaunchKernelGGL(pcc_argmax_kernel, dim3(nblk), dim3(256), 0, s, corr, corr_shifted, Z, Y, Xc, partial);
     hipLaunchKernelGGL(pcc_argmax_final_kernel, dim3(1), dim3(256), 0, s, partial, nblk, result);
@@ -586,10 +586,10 @@ int bh_tikhonov(bh_ctx* ctx, const float* in, const float* tf_full, int64_t Z, i
     cf* spec;
     BH_TRY(get_scratch(ctx, "fft_spec", NS * sizeof(cf), (void**)&spec));
     hipStream_t s = ctx->stream;
-    BH_CHECK_FFT(hipfftExecR2C(pl->r2c, const_cast<float*>(in), (hipfftComplex*)spec));
+    BH_TRY(fft_forward(pl, in, spec));
     hipLaunchKernelGGL(tikhonov_filter_kernel, grid_for(ctx, NS), dim3(256), 0, s, spec, tf_full, Z, Y, X,
                        (float)regularization_strength, (float)(1.0 / (double)V));
-    BH_CHECK_FFT(hipfftExecC2R(pl->c2r, (hipfftComplex*)spec, out));
+    BH_TRY(fft_inverse(pl, spec, out));
     BH_CHECK_HIP(hipGetLastError());
     return BH_OK;
 }
@@ -639,7 +639,7 @@ static int richardson_lucy_padfold(bh_ctx* ctx, const float* d, const float* psf
     hipLaunchKernelGGL(psf_sum_kernel, dim3(1), dim3(256), 0, s, psf, pz * py * px, psum);
     hipLaunchKernelGGL(place_psf_kernel, grid_for(ctx, pz * py * px), dim3(256), 0, s, psf, ra, (int)pz, (int)py, (int)px,
                        P[0], P[1], P[2], 0, 0, 0, (int)(pz / 2), (int)(py / 2), (int)(px / 2), (const double*)psum);
-    BH_CHECK_FFT(hipfftExecR2C(pl->r2c, ra, (hipfftComplex*)otf));
+    BH_TRY(fft_forward(pl, ra, otf));
     hipLaunchKernelGGL(scale_spectrum_kernel, grid_for(ctx, NS), dim3(256), 0, s, otf, NS, (float)(1.0 / (double)VP));
     hipLaunchKernelGGL(clip_copy_kernel, grid_for(ctx, V), dim3(256), 0, s, d, out, V);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -651,15 +651,15 @@ static int richardson_lucy_padfold(bh_ctx* ctx, const float* d, const float* psf
     const int64_t n2 = NS / 2;
     for (int it = 0; it < iterations; ++it) {
         hipLaunchKernelGGL(pad_volume_kernel, grid_for(ctx, VP), dim3(256), 0, s, (const float*)out, ra, conv);
-        BH_CHECK_FFT(hipfftExecR2C(pl->r2c, ra, (hipfftComplex*)spec));
+        BH_TRY(fft_forward(pl, ra, spec));
         hipLaunchKernelGGL(cmul_kernel<false>, grid_for(ctx, n2), dim3(256), 0, s, spec, otf, n2);
         if (NS & 1) hipLaunchKernelGGL(cmul_tail_kernel<false>, dim3(1), dim3(1), 0, s, spec, otf, NS - 1);
-        BH_CHECK_FFT(hipfftExecC2R(pl->c2r, (hipfftComplex*)spec, ra));
+        BH_TRY(fft_inverse(pl, spec, ra));
         hipLaunchKernelGGL(fold_ratio_kernel, grid_for(ctx, VP), dim3(256), 0, s, (const float*)ra, d, rb, conv, eps);
-        BH_CHECK_FFT(hipfftExecR2C(pl->r2c, rb, (hipfftComplex*)spec));
+        BH_TRY(fft_forward(pl, rb, spec));
         hipLaunchKernelGGL(cmul_kernel<true>, grid_for(ctx, n2), dim3(256), 0, s, spec, otf, n2);
         if (NS & 1) hipLaunchKernelGGL(cmul_tail_kernel<true>, dim3(1), dim3(1), 0, s, spec, otf, NS - 1);
-        BH_CHECK_FFT(hipfftExecC2R(pl->c2r, (hipfftComplex*)spec, ra));
+        BH_TRY(fft_inverse(pl, spec, ra));
         hipLaunchKernelGGL(fold_update_kernel, grid_for(ctx, V), dim3(256), 0, s, (const float*)ra, out, corr);
     }
     BH_CHECK_HIP(hipGetLastError());
@@ -721,7 +721,7 @@ int bh_richardson_lucy(bh_ctx* ctx, const float* in, const float* psf, int64_t p
     hipLaunchKernelGGL(place_psf_kernel, grid_for(ctx, pz * py * px), dim3(256), 0, s, psf, real, (int)pz, (int)py,
                        (int)px, Z, Y, X, bz, by, bx, bz + (int)(pz / 2), by + (int)(py / 2), bx + (int)(px / 2),
                        (const double*)psum);
-    BH_CHECK_FFT(hipfftExecR2C(pl->r2c, real, (hipfftComplex*)otf));
+    BH_TRY(fft_forward(pl, real, otf));
     hipLaunchKernelGGL(scale_spectrum_kernel, grid_for(ctx, NS), dim3(256), 0, s, otf, NS, (float)(1.0 / (double)V));
     // e0 = max(d, 0)
     hipLaunchKernelGGL(clip_copy_kernel, grid_for(ctx, V), dim3(256), 0, s, d, out, V);
@@ -733,15 +733,15 @@ int bh_richardson_lucy(bh_ctx* ctx, const float* in, const float* psf, int64_t p
     }
     const int64_t n2 = NS / 2;
     for (int it = 0; it < iterations; ++it) {
-        BH_CHECK_FFT(hipfftExecR2C(pl->r2c, out, (hipfftComplex*)spec));
+        BH_TRY(fft_forward(pl, out, spec));
         hipLaunchKernelGGL(cmul_kernel<false>, grid_for(ctx, n2), dim3(256), 0, s, spec, otf, n2);
         if (NS & 1) hipLaunchKernelGGL(cmul_tail_kernel<false>, dim3(1), dim3(1), 0, s, spec, otf, NS - 1);
-        BH_CHECK_FFT(hipfftExecC2R(pl->c2r, (hipfftComplex*)spec, real));
+        BH_TRY(fft_inverse(pl, spec, real));
         hipLaunchKernelGGL(ratio_kernel, grid_for(ctx, V / 4 + 1), dim3(256), 0, s, real, d, V, eps);
-        BH_CHECK_FFT(hipfftExecR2C(pl->r2c, real, (hipfftComplex*)spec));
+        BH_TRY(fft_forward(pl, real, spec));
         hipLaunchKernelGGL(cmul_kernel<true>, grid_for(ctx, n2), dim3(256), 0, s, spec, otf, n2);
         if (NS & 1) hipLaunchKernelGGL(cmul_tail_kernel<true>, dim3(1), dim3(1), 0, s, spec, otf, NS - 1);
-        BH_CHECK_FFT(hipfftExecC2R(pl->c2r, (hipfftComplex*)spec, real));
+        BH_TRY(fft_inverse(pl, spec, real));
         hipLaunchKernelGGL(update_kernel, grid_for(ctx, V / 4 + 1), dim3(256), 0, s, out, real, V);
     }
     BH_CHECK_HIP(hipGetLastError());

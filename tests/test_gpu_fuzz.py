@@ -1,0 +1,76 @@
+"""Seeded randomised parity sweeps (GPU): shapes, dtypes and parameters the hand-picked cases do not enumerate."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fuzz_fused_engine_vs_oracle(gpu):
+    """Fused FFT engine on random power-of-two shapes and PSF extents (even, odd, 1) against the NumPy oracle:
+    R-L, Tikhonov, phase cross-correlation."""
+    from biahub_amd.deconvolve import richardson_lucy, tikhonov_zyx, transfer_function_device
+    from biahub_amd.estimate_stabilization import phase_cross_corr_device
+
+    rng = np.random.default_rng(123)
+    done = 0
+    while done < 14:
+        Z, Y, X = int(2 ** rng.integers(2, 7)), int(2 ** rng.integers(5, 9)), int(2 ** rng.integers(6, 11))
+        if Z * Y * X > 2**22:
+            continue
+        done += 1
+        pshape = tuple(int(min(rng.integers(1, 12), n)) for n in (Z, Y, X))
+        volh = (rng.random((Z, Y, X)) * 300).astype(np.float32)
+        psfh = (rng.random(pshape) + 0.05).astype(np.float32)
+        vol, psf = torch.from_numpy(volh).to(gpu), torch.from_numpy(psfh).to(gpu)
+        got = richardson_lucy(vol, psf, 3, 1e-6).cpu().numpy()
+        assert rel_err(got, O.richardson_lucy_zyx(volh, psfh, iterations=3, eps=1e-6)) <= 1e-4, ((Z, Y, X), pshape)
+        tf = O.compute_transfer_function(psfh, (Z, Y, X))
+        got = tikhonov_zyx(vol, torch.from_numpy(tf).to(gpu), 1e-2).cpu().numpy()
+        assert rel_err(got, O.tikhonov_zyx(volh, tf, 1e-2)) <= 1e-4, ((Z, Y, X), pshape)
+        assert rel_err(transfer_function_device(psf, (Z, Y, X), gpu).cpu().numpy(), tf) <= 1e-5
+        roll = tuple(int(v) for v in rng.integers(-3, 4, 3))
+        movh = np.roll(volh, roll, axis=(0, 1, 2))
+        sh, corr = phase_cross_corr_device(vol, torch.from_numpy(movh).to(gpu), "magnitude")
+        wsh, wcorr = O.phase_cross_corr(volh, movh, "magnitude")
+        assert np.array_equal(sh, wsh) and rel_err(corr.cpu().numpy(), wcorr) <= 1e-4, ((Z, Y, X), roll)
+
+
+def test_fuzz_deskew_flatfield_affine_vs_oracle(gpu):
+    from biahub_amd.deskew import fast_deskew_zyx
+    from biahub_amd.flat_field import flat_field_zyx, median_z_device
+    from biahub_amd.register import apply_affine_transform
+
+    rng = np.random.default_rng(77)
+    for _ in range(12):
+        Z, Y, X = (int(v) for v in rng.integers(3, 40, 3))
+        dt = [np.float32, np.uint16, np.uint8, np.int16][int(rng.integers(0, 4))]
+        vol = (rng.random((Z, Y, X)) * (200 if dt == np.uint8 else 3000)).astype(dt)
+        # deskew: random geometry, both fills
+        ang, ratio, N = float(rng.uniform(20, 50)), float(rng.uniform(0.2, 0.8)), int(rng.integers(1, 4))
+        fill = ["mean", 0, 55.0][int(rng.integers(0, 3))]
+        want = O.fast_deskew_zyx(vol.astype(np.float32), round(ang, 2), round(ratio, 3), True, N, fill)
+        got = fast_deskew_zyx(torch.from_numpy(vol).to(gpu), round(ang, 2), round(ratio, 3), True, N, fill).cpu().numpy()
+        assert got.shape == want.shape and rel_err(got, want) <= 2e-5, (Z, Y, X, dt, ang, ratio, N, fill)
+        # median / flat field
+        data = vol if dt != np.float32 else (vol - 1500).astype(np.float32)
+        assert np.array_equal(median_z_device(data).cpu().numpy(), np.median(data, axis=0).astype(np.float64))
+        if dt == np.uint16:
+            w = O.flat_field_zyx(data + 1).astype(np.float32)
+            assert np.abs(flat_field_zyx(data + 1) - w).max() <= 2e-7 * np.abs(w).max()
+        # affine: random similarity + shear, both interpolations
+        A = np.eye(4)
+        A[:3, :3] += rng.normal(0, 0.08, (3, 3))
+        A[:3, 3] = rng.uniform(-4, 4, 3)
+        out_shape = tuple(int(v) for v in rng.integers(3, 40, 3))
+        fv = vol.astype(np.float32)
+        for interp in ("linear", "nearestneighbor"):
+            w = O.apply_affine_transform(fv, A, out_shape, interp)
+            g = apply_affine_transform(fv, A, out_shape, interpolation=interp)
+            if interp == "linear":
+                assert rel_err(g, w) <= 1e-5, (Z, Y, X, out_shape)
+            else:
+                assert (g != w).mean() <= 1e-3, (Z, Y, X, out_shape)  # float64 ties at half-voxel coordinates

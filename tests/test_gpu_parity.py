@@ -403,6 +403,37 @@ def test_tikhonov_fused_engine_vs_oracle(gpu, shape, monkeypatch):
     assert rel_err(got, got2) <= FFT_TOL
 
 
+def test_library_fft_plan_kinds_agree(gpu, monkeypatch):
+    """csrc/context.hip plans mixed-radix shapes with hipfftPlan3d and all-power-of-two shapes (rocFFT defect)
+    as x-rows + strided (z, y) transforms; BH_FFT_SEPARABLE=1 forces the latter: same results either way, also for the
+    power-of-two pair that breaks hipfftPlan3d."""
+    from biahub_amd.deconvolve import richardson_lucy
+    from biahub_amd.device import get_context
+
+    ctx = get_context(gpu)
+    psf = O.gaussian_psf((5, 7, 9), (1.0, 1.5, 2.0))
+    pt = torch.from_numpy(psf).to(gpu)
+    for shape in ((15, 42, 50), (24, 36, 60)):  # 7-smooth: no pad-and-fold, straight to the library plans
+        vol = O.synthetic_volume(shape, seed=9, n_blobs=6)
+        want = O.richardson_lucy_zyx(vol, psf, iterations=4, eps=1e-6)
+        v = torch.from_numpy(vol).to(gpu)
+        ctx.release_workspace()
+        a = richardson_lucy(v, pt, 4, 1e-6).cpu().numpy()
+        ctx.release_workspace()
+        monkeypatch.setenv("BH_FFT_SEPARABLE", "1")
+        b = richardson_lucy(v, pt, 4, 1e-6).cpu().numpy()
+        monkeypatch.delenv("BH_FFT_SEPARABLE")
+        ctx.release_workspace()
+        assert rel_err(a, want) <= FFT_TOL and rel_err(b, want) <= FFT_TOL, (rel_err(a, want), rel_err(b, want))
+    monkeypatch.setenv("BH_FFT_BACKEND", "hipfft")
+    for shape in ((8, 128, 64), (4, 32, 256), (64, 8, 64), (2, 64, 256)):  # plans stay alive across the loop
+        vol = O.synthetic_volume(shape, seed=10, n_blobs=6)
+        ps = O.gaussian_psf((1, 5, 5), (0.5, 1.0, 1.0))
+        want = O.richardson_lucy_zyx(vol, ps, iterations=3, eps=1e-6)
+        got = richardson_lucy(torch.from_numpy(vol).to(gpu), torch.from_numpy(ps).to(gpu), 3, 1e-6).cpu().numpy()
+        assert rel_err(got, want) <= FFT_TOL, (shape, rel_err(got, want))
+
+
 def test_find_overlapping_volume(gpu):
     from biahub_amd.register import apply_affine_transform, find_overlapping_volume
 
