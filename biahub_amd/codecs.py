@@ -1,0 +1,485 @@
+"""Chunk codecs of the OME-Zarr stores on either side of the hot path.
+
+The reference never touches chunk bytes itself: it reaches them through iohub 0.3.11 -> zarr / numcodecs 0.15.1
+(reference uv.lock:1910-1911, 3160-3161), whose default chunk compressor is Blosc (c-blosc 1.21, zstd inside, bit- or
+byte-shuffle) for NGFF 0.4 stores and the zarr-v3 ``blosc`` / ``zstd`` / ``sharding_indexed`` codecs for NGFF 0.5
+(`biahub/settings.py:43`, `output_ome_zarr_version`).  None of those libraries is in this image, so this module
+restates the published formats:
+
+* the Blosc-1 container (16-byte header, block start table, optional per-byte-plane splits, byte shuffle, bit shuffle)
+  with the zstd / lz4 / zlib / blosclz inner codecs — pinned against streams written by the real c-blosc 1.21.0
+  (tests/golden/blosc_streams.npz, made by tests/golden/make_codec_golden.py);
+* plain zstd / gzip / zlib / lz4 (numcodecs framing) chunk compressors;
+* CRC-32C (Castagnoli), which zarr v3's sharding index carries.
+
+The entropy coders themselves (zstd, lz4) come from pyarrow's bundled copies; zlib from the standard library.  The byte
+permutations (shuffle / bit shuffle) also exist as HIP kernels (csrc/codec.hip: ``bh_blosc_unfilter`` /
+``bh_blosc_filter``) so that a volume headed for the GPU is un-shuffled there, at HBM speed, instead of on a host core.
+"""
+
+from __future__ import annotations
+
+import struct
+import zlib
+
+import numpy as np
+
+BLOSC_NOSHUFFLE, BLOSC_SHUFFLE, BLOSC_BITSHUFFLE = 0, 1, 2
+_BLOSC_MIN_BUFFERSIZE = 128  # c-blosc: buffers below this are stored, blocks below this many elements are not split
+_BLOSC_MAX_SPLITS = 16
+_BLOSC_FORMATS = {0: "blosclz", 1: "lz4", 2: "snappy", 3: "zlib", 4: "zstd"}
+_BLOSC_CNAMES = {"blosclz": 0, "lz4": 1, "lz4hc": 1, "snappy": 2, "zlib": 3, "zstd": 4}
+
+_PA_CODECS: dict = {}
+
+
+def _pa_codec(name: str, level=None):
+    key = (name, level)
+    if key not in _PA_CODECS:
+        import pyarrow as pa
+
+        _PA_CODECS[key] = pa.Codec(name, compression_level=level) if level is not None else pa.Codec(name)
+    return _PA_CODECS[key]
+
+
+def zstd_decompress(buf, nbytes: int) -> np.ndarray:
+    out = _pa_codec("zstd").decompress(memoryview(buf), decompressed_size=int(nbytes))
+    return np.frombuffer(out, np.uint8)
+
+
+def zstd_compress(buf, level: int = 1) -> bytes:
+    return _pa_codec("zstd", int(level)).compress(memoryview(buf), asbytes=True)
+
+
+def lz4_block_decompress(buf, nbytes: int) -> np.ndarray:
+    out = _pa_codec("lz4_raw").decompress(memoryview(buf), decompressed_size=int(nbytes))
+    return np.frombuffer(out, np.uint8)
+
+
+def lz4_block_compress(buf) -> bytes:
+    return _pa_codec("lz4_raw").compress(memoryview(buf), asbytes=True)
+
+
+def zstd_frame_content_size(buf) -> int | None:
+    """Decompressed size from a zstd frame header (RFC 8878 §3.1.1.1), None when the frame does not record it."""
+    b = bytes(memoryview(buf)[:18])
+    if len(b) < 5 or b[:4] != b"\x28\xb5\x2f\xfd":
+        raise ValueError("not a zstd frame")
+    fhd = b[4]
+    fcs_flag, single, did_flag = fhd >> 6, (fhd >> 5) & 1, fhd & 3
+    pos = 5 + (0 if single else 1) + (0, 1, 2, 4)[did_flag]
+    if fcs_flag == 0:
+        return b[pos] if single else None
+    if fcs_flag == 1:
+        return struct.unpack_from("<H", b, pos)[0] + 256
+    if fcs_flag == 2:
+        return struct.unpack_from("<I", b, pos)[0]
+    return struct.unpack_from("<Q", b, pos)[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CRC-32C (Castagnoli, reflected polynomial 0x82F63B78): the checksum of zarr v3's `crc32c` codec
+# ---------------------------------------------------------------------------------------------------------------
+_CRC32C_TABLE = None
+
+
+def _crc32c_table() -> np.ndarray:
+    global _CRC32C_TABLE
+    if _CRC32C_TABLE is None:
+        t = np.arange(256, dtype=np.uint32)
+        for _ in range(8):
+            t = np.where(t & 1, (t >> 1) ^ np.uint32(0x82F63B78), t >> 1).astype(np.uint32)
+        _CRC32C_TABLE = t
+    return _CRC32C_TABLE
+
+
+def crc32c(data, value: int = 0) -> int:
+    """CRC-32C of ``data`` (bytes-like), continuing from ``value``.  Table driven, one byte per step: meant for shard
+    indexes (16 bytes per inner chunk), not for bulk data."""
+    table = _crc32c_table().tolist()
+    crc = (~value) & 0xFFFFFFFF
+    for byte in bytes(memoryview(data)):
+        crc = table[(crc ^ byte) & 0xFF] ^ (crc >> 8)
+    return (~crc) & 0xFFFFFFFF
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# byte permutations of the Blosc container (c-blosc shuffle.c / bitshuffle-generic.c semantics)
+# ---------------------------------------------------------------------------------------------------------------
+def shuffle(block: np.ndarray, typesize: int) -> np.ndarray:
+    """Byte shuffle of one block: byte j of element i goes to plane j; the ``len % typesize`` tail is copied."""
+    block = np.asarray(block, np.uint8)
+    n = block.size // typesize
+    if typesize <= 1 or n == 0:
+        return block.copy()
+    out = np.empty_like(block)
+    out[: n * typesize] = block[: n * typesize].reshape(n, typesize).T.reshape(-1)
+    out[n * typesize:] = block[n * typesize:]
+    return out
+
+
+def unshuffle(block: np.ndarray, typesize: int) -> np.ndarray:
+    block = np.asarray(block, np.uint8)
+    n = block.size // typesize
+    if typesize <= 1 or n == 0:
+        return block.copy()
+    out = np.empty_like(block)
+    out[: n * typesize] = block[: n * typesize].reshape(typesize, n).T.reshape(-1)
+    out[n * typesize:] = block[n * typesize:]
+    return out
+
+
+def bitshuffle(block: np.ndarray, typesize: int) -> np.ndarray:
+    """Bit shuffle of one block: bit k of byte j of element i goes to bit-plane 8 j + k, element i at bit i % 8 (LSB
+    first) of byte i // 8 of the plane.  c-blosc 1.x applies it only when the block holds a multiple of 8 elements
+    and otherwise stores the block unpermuted; a ``len % typesize`` tail is copied."""
+    block = np.asarray(block, np.uint8)
+    n = block.size // typesize
+    if n == 0 or n % 8:
+        return block.copy()
+    out = np.empty_like(block)
+    bits = np.unpackbits(block[: n * typesize].reshape(n, typesize), axis=1, bitorder="little")  # (n, 8 ts)
+    out[: n * typesize] = np.packbits(bits.T, axis=1, bitorder="little").reshape(-1)            # (8 ts, n / 8)
+    out[n * typesize:] = block[n * typesize:]
+    return out
+
+
+def bitunshuffle(block: np.ndarray, typesize: int) -> np.ndarray:
+    block = np.asarray(block, np.uint8)
+    n = block.size // typesize
+    if n == 0 or n % 8:
+        return block.copy()
+    out = np.empty_like(block)
+    planes = np.unpackbits(block[: n * typesize].reshape(8 * typesize, n // 8), axis=1, bitorder="little")  # (8 ts, n)
+    out[: n * typesize] = np.packbits(planes.T, axis=1, bitorder="little").reshape(-1)                      # (n, ts)
+    out[n * typesize:] = block[n * typesize:]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# blosclz (c-blosc's own LZ77 coder, format version 1 — the FastLZ level-2 token stream)
+# ---------------------------------------------------------------------------------------------------------------
+def blosclz_decompress(src, nbytes: int) -> np.ndarray:
+    """Token stream: control byte c < 32 -> c + 1 literals follow; else a match of length (c >> 5) + 2 (7 -> extended
+    by following bytes, 255 continues) at distance ((c & 31) << 8 | next) + 1; distance field 8191 escapes to a 16-bit
+    far distance.  A Python loop per token: rare codec (iohub writes zstd), kept for completeness."""
+    ip = bytes(memoryview(src))
+    n_in = len(ip)
+    out = bytearray(nbytes)
+    op = 0
+    i = 0
+    ctrl = ip[0] & 31
+    i = 1
+    while True:
+        if ctrl >= 32:
+            length = (ctrl >> 5) - 1
+            ofs = (ctrl & 31) << 8
+            if length == 6:
+                while True:
+                    code = ip[i]
+                    i += 1
+                    length += code
+                    if code != 255:
+                        break
+            code = ip[i]
+            i += 1
+            dist = ofs + code
+            if code == 255 and ofs == (31 << 8):
+                dist = ((ip[i] << 8) | ip[i + 1]) + 8191
+                i += 2
+            length += 3
+            ref = op - dist - 1
+            if ref < 0 or op + length > nbytes:
+                raise ValueError("corrupt blosclz stream")
+            if dist + 1 >= length:
+                out[op:op + length] = out[ref:ref + length]
+            else:  # overlapping match: the pattern of dist + 1 bytes repeats
+                pat = bytes(out[ref:op])
+                reps = -(-length // len(pat))
+                out[op:op + length] = (pat * reps)[:length]
+            op += length
+            if i < n_in:
+                ctrl = ip[i]
+                i += 1
+            else:
+                break
+        else:
+            run = ctrl + 1
+            if op + run > nbytes or i + run > n_in:
+                raise ValueError("corrupt blosclz stream")
+            out[op:op + run] = ip[i:i + run]
+            op += run
+            i += run
+            if i < n_in:
+                ctrl = ip[i]
+                i += 1
+            else:
+                break
+    if op != nbytes:
+        raise ValueError(f"blosclz stream decoded to {op} bytes, expected {nbytes}")
+    return np.frombuffer(bytes(out), np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Blosc-1 container
+# ---------------------------------------------------------------------------------------------------------------
+class BloscHeader:
+    __slots__ = ("version", "versionlz", "flags", "typesize", "nbytes", "blocksize", "cbytes")
+
+    def __init__(self, buf):
+        mv = memoryview(buf)
+        if len(mv) < 16:
+            raise ValueError("blosc stream shorter than its 16-byte header")
+        self.version, self.versionlz, self.flags, self.typesize = mv[0], mv[1], mv[2], mv[3]
+        self.nbytes, self.blocksize, self.cbytes = struct.unpack_from("<III", mv, 4)
+        if self.cbytes > len(mv):
+            raise ValueError(f"blosc stream truncated: header says {self.cbytes} bytes, have {len(mv)}")
+
+    @property
+    def memcpyed(self) -> bool:
+        return bool(self.flags & 0x2)
+
+    @property
+    def shuffle_mode(self) -> int:
+        if self.flags & 0x1 and self.typesize > 1:
+            return BLOSC_SHUFFLE
+        if self.flags & 0x4:
+            return BLOSC_BITSHUFFLE
+        return BLOSC_NOSHUFFLE
+
+    @property
+    def codec(self) -> str:
+        return _BLOSC_FORMATS.get(self.flags >> 5, f"format {self.flags >> 5}")
+
+
+def _inner_decompress(codec: str, buf, nbytes: int) -> np.ndarray:
+    if codec == "zstd":
+        return zstd_decompress(buf, nbytes)
+    if codec == "lz4":
+        return lz4_block_decompress(buf, nbytes)
+    if codec == "zlib":
+        return np.frombuffer(zlib.decompress(buf), np.uint8)
+    if codec == "blosclz":
+        return blosclz_decompress(buf, nbytes)
+    raise NotImplementedError(f"blosc inner codec {codec!r} is not supported")
+
+
+def blosc_decode_blocks(buf, out: np.ndarray | None = None) -> tuple[BloscHeader, np.ndarray]:
+    """Entropy-decode a Blosc-1 stream WITHOUT undoing its shuffle: returns the header and the ``nbytes`` still-permuted
+    bytes (block after block).  ``unfilter`` below — or ``bh_blosc_unfilter`` on the GPU — finishes the job."""
+    h = BloscHeader(buf)
+    mv = memoryview(buf)
+    if out is None:
+        out = np.empty(h.nbytes, np.uint8)
+    elif out.size != h.nbytes or out.dtype != np.uint8:
+        raise ValueError("output buffer does not match the stream")
+    if h.nbytes == 0:
+        return h, out
+    if h.memcpyed:
+        out[:] = np.frombuffer(mv, np.uint8, h.nbytes, 16)
+        return h, out
+    nblocks = -(-h.nbytes // h.blocksize)
+    bstarts = struct.unpack_from(f"<{nblocks}i", mv, 16)
+    dont_split = bool(h.flags & 0x10)
+    codec = h.codec
+    for b in range(nblocks):
+        o0 = b * h.blocksize
+        bsize = min(h.blocksize, h.nbytes - o0)
+        leftover = bsize != h.blocksize
+        split = (not dont_split and h.typesize <= _BLOSC_MAX_SPLITS
+                 and h.blocksize // h.typesize >= _BLOSC_MIN_BUFFERSIZE and not leftover)
+        nsplits = h.typesize if split else 1
+        ne = bsize // nsplits
+        pos = bstarts[b]
+        for j in range(nsplits):
+            (cb,) = struct.unpack_from("<i", mv, pos)
+            pos += 4
+            if cb < 0 or pos + cb > len(mv):
+                raise ValueError("corrupt blosc stream")
+            dst = out[o0 + j * ne: o0 + (j + 1) * ne]
+            if cb == ne:
+                dst[:] = np.frombuffer(mv, np.uint8, ne, pos)
+            else:
+                dst[:] = _inner_decompress(codec, mv[pos:pos + cb], ne)
+            pos += cb
+    return h, out
+
+
+def unfilter(shuffled: np.ndarray, nbytes: int, blocksize: int, typesize: int, mode: int,
+             out: np.ndarray | None = None) -> np.ndarray:
+    """Undo the per-block permutation of a Blosc stream on the host (NumPy)."""
+    if out is None:
+        out = np.empty(nbytes, np.uint8)
+    if mode == BLOSC_NOSHUFFLE or nbytes == 0:
+        out[:] = shuffled
+        return out
+    fn = unshuffle if mode == BLOSC_SHUFFLE else bitunshuffle
+    for o0 in range(0, nbytes, blocksize):
+        o1 = min(nbytes, o0 + blocksize)
+        if mode == BLOSC_BITSHUFFLE and o1 - o0 < typesize:
+            out[o0:o1] = shuffled[o0:o1]
+        else:
+            out[o0:o1] = fn(shuffled[o0:o1], typesize)
+    return out
+
+
+def blosc_decompress(buf, out: np.ndarray | None = None) -> np.ndarray:
+    """Full Blosc-1 decode to ``nbytes`` uint8 (what ``numcodecs.Blosc.decode`` returns)."""
+    h, raw = blosc_decode_blocks(buf)
+    if h.memcpyed or h.shuffle_mode == BLOSC_NOSHUFFLE:
+        if out is None:
+            return raw
+        out[:] = raw
+        return out
+    return unfilter(raw, h.nbytes, h.blocksize, h.typesize, h.shuffle_mode, out)
+
+
+def blosc_compress(data, typesize: int, cname: str = "zstd", clevel: int = 1, shuffle_mode: int = BLOSC_BITSHUFFLE,
+                   blocksize: int = 0, prefiltered: bool = False) -> bytes:
+    """Write a Blosc-1 stream any c-blosc >= 1.15 reads.  Blocks are never split (flag 0x10, what c-blosc itself does
+    for zstd / lz4hc / zlib).  ``blocksize == 0`` picks 256 KiB rounded to 8 elements.  ``prefiltered``: ``data`` is
+    already permuted block by block (by ``bh_blosc_filter`` on the GPU) with exactly this blocksize."""
+    raw = np.frombuffer(memoryview(data).cast("B"), np.uint8) if not isinstance(data, np.ndarray) else \
+        np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    nbytes = raw.size
+    if not 1 <= typesize <= 255:
+        typesize = 1
+    if cname not in _BLOSC_CNAMES or cname in ("snappy", "blosclz", "lz4hc"):
+        raise NotImplementedError(f"blosc writer: inner codec {cname!r} is not supported (zstd, lz4, zlib are)")
+    flags = 0x10 | (_BLOSC_CNAMES[cname] << 5)
+    if shuffle_mode == BLOSC_SHUFFLE:
+        flags |= 0x1
+    elif shuffle_mode == BLOSC_BITSHUFFLE:
+        flags |= 0x4
+    if blocksize <= 0:
+        blocksize = default_blocksize(typesize)
+    blocksize = min(blocksize, nbytes) if nbytes else blocksize
+    versionlz = 1
+
+    def stored() -> bytes:
+        if prefiltered:
+            raise ValueError("a prefiltered buffer cannot be stored raw")
+        return struct.pack("<BBBBIII", 2, versionlz, flags | 0x2, typesize, nbytes, blocksize, nbytes + 16) + raw.tobytes()
+
+    if nbytes < _BLOSC_MIN_BUFFERSIZE or clevel == 0:
+        if prefiltered and nbytes:
+            raise ValueError("buffers below 128 bytes are stored raw: do not prefilter them")
+        return stored()
+    nblocks = -(-nbytes // blocksize)
+    parts, bstarts = [], []
+    pos = 16 + 4 * nblocks
+    for b in range(nblocks):
+        blk = raw[b * blocksize: min(nbytes, (b + 1) * blocksize)]
+        if not prefiltered:
+            if shuffle_mode == BLOSC_SHUFFLE and typesize > 1:
+                blk = shuffle(blk, typesize)
+            elif shuffle_mode == BLOSC_BITSHUFFLE and blk.size >= typesize:
+                blk = bitshuffle(blk, typesize)
+        if cname == "zstd":
+            comp = zstd_compress(blk, clevel)
+        elif cname == "lz4":
+            comp = lz4_block_compress(blk)
+        else:
+            comp = zlib.compress(blk, clevel)
+        if len(comp) >= blk.size:  # incompressible: stored, which the reader recognises by cbytes == block bytes
+            comp = blk.tobytes()
+        bstarts.append(pos)
+        parts.append(struct.pack("<i", len(comp)))
+        parts.append(comp)
+        pos += 4 + len(comp)
+    if pos >= nbytes + 16 and not prefiltered:
+        return stored()
+    head = struct.pack("<BBBBIII", 2, versionlz, flags, typesize, nbytes, blocksize, pos)
+    return head + struct.pack(f"<{nblocks}i", *bstarts) + b"".join(parts)
+
+
+def default_blocksize(typesize: int) -> int:
+    unit = 8 * max(1, typesize)
+    return max(unit, ((256 << 10) // unit) * unit)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# zarr compressor configurations -> (decode, encode)
+# ---------------------------------------------------------------------------------------------------------------
+_SHUFFLE_NAMES = {"noshuffle": BLOSC_NOSHUFFLE, "shuffle": BLOSC_SHUFFLE, "bitshuffle": BLOSC_BITSHUFFLE}
+
+
+class ChunkCodec:
+    """bytes <-> bytes stage of a chunk: ``decode(buf, nbytes) -> uint8 array``, ``encode(uint8 array) -> bytes``."""
+
+    def __init__(self, kind: str, **cfg):
+        self.kind = kind
+        self.cfg = cfg
+
+    def decode(self, buf, nbytes: int) -> np.ndarray:
+        k = self.kind
+        if k == "blosc":
+            return blosc_decompress(buf)
+        if k == "zstd":
+            n = zstd_frame_content_size(buf)
+            return zstd_decompress(buf, nbytes if n is None else n)
+        if k in ("zlib", "gzip"):
+            return np.frombuffer(zlib.decompress(buf, 47), np.uint8)  # 47: zlib or gzip wrapper, auto-detected
+        if k == "lz4":  # numcodecs LZ4: int32 little-endian decompressed size, then one raw block
+            (n,) = struct.unpack_from("<i", memoryview(buf), 0)
+            return lz4_block_decompress(memoryview(buf)[4:], n)
+        if k == "crc32c":
+            mv = memoryview(buf)
+            (want,) = struct.unpack_from("<I", mv, len(mv) - 4)
+            if crc32c(mv[:-4]) != want:
+                raise ValueError("crc32c mismatch")
+            return np.frombuffer(mv[:-4], np.uint8)
+        raise NotImplementedError(f"chunk codec {k!r}")
+
+    def encode(self, raw: np.ndarray) -> bytes:
+        k, c = self.kind, self.cfg
+        if k == "blosc":
+            return blosc_compress(raw, c.get("typesize", 1), c.get("cname", "zstd"), c.get("clevel", 1),
+                                  c.get("shuffle", BLOSC_BITSHUFFLE), c.get("blocksize", 0))
+        if k == "zstd":
+            return zstd_compress(raw, c.get("level", 1))
+        if k == "zlib":
+            return zlib.compress(raw, c.get("level", 1))
+        if k == "gzip":
+            co = zlib.compressobj(c.get("level", 1), zlib.DEFLATED, 31)
+            return co.compress(raw) + co.flush()
+        if k == "lz4":
+            return struct.pack("<i", raw.size) + lz4_block_compress(raw)
+        if k == "crc32c":
+            return bytes(raw) + struct.pack("<I", crc32c(raw))
+        raise NotImplementedError(f"chunk codec {k!r}")
+
+
+def codec_from_v2(comp: dict | None, itemsize: int) -> ChunkCodec | None:
+    """zarr v2 ``compressor`` entry (numcodecs configuration) -> codec."""
+    if comp is None:
+        return None
+    cid = comp.get("id")
+    if cid == "blosc":
+        sh = comp.get("shuffle", 1)
+        if sh == -1:  # numcodecs AUTOSHUFFLE
+            sh = BLOSC_BITSHUFFLE if itemsize == 1 else BLOSC_SHUFFLE
+        return ChunkCodec("blosc", cname=comp.get("cname", "lz4"), clevel=comp.get("clevel", 5), shuffle=int(sh),
+                          blocksize=comp.get("blocksize", 0), typesize=itemsize)
+    if cid in ("zstd", "zlib", "gzip"):
+        return ChunkCodec(cid, level=comp.get("level", 1))
+    if cid == "lz4":
+        return ChunkCodec("lz4")
+    raise NotImplementedError(f"zarr v2 compressor {cid!r} is not supported (blosc, zstd, zlib, gzip, lz4 are)")
+
+
+def codec_from_v3(entry: dict, itemsize: int) -> ChunkCodec:
+    """One bytes->bytes entry of a zarr v3 ``codecs`` list."""
+    name, cfg = entry.get("name"), entry.get("configuration", {}) or {}
+    if name == "blosc":
+        sh = cfg.get("shuffle", "noshuffle")
+        return ChunkCodec("blosc", cname=cfg.get("cname", "zstd"), clevel=cfg.get("clevel", 5),
+                          shuffle=_SHUFFLE_NAMES[sh] if isinstance(sh, str) else int(sh),
+                          blocksize=cfg.get("blocksize", 0), typesize=cfg.get("typesize", itemsize))
+    if name == "zstd":
+        return ChunkCodec("zstd", level=cfg.get("level", 0) or 1)
+    if name == "gzip":
+        return ChunkCodec("gzip", level=cfg.get("level", 1))
+    if name == "crc32c":
+        return ChunkCodec("crc32c")
+    raise NotImplementedError(f"zarr v3 codec {name!r} is not supported (bytes, blosc, zstd, gzip, crc32c, sharding_indexed are)")
