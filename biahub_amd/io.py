@@ -1,11 +1,13 @@
-"""Minimal OME-Zarr (NGFF 0.4, zarr v2 directory store) reader/writer and the per-position driver.
+"""OME-Zarr reader/writer (NGFF 0.4 on zarr v2, NGFF 0.5 on zarr v3 with optional sharding; directory stores) and the
+per-position driver.
 
 iohub / zarr / numcodecs are not available in this image, and the reference reaches them only through
 ``open_ome_zarr``, ``create_empty_plate`` and ``process_single_position`` (biahub/deskew.py:608-640,738-749).
 This module provides those three entry points with the argument names the reference uses, over plain files:
-HCS layout ``plate.zarr/<row>/<col>/<fov>/0`` with one 5-D ``(T,C,Z,Y,X)`` array per position, chunks
-``(1,1,zc,Y,X)``, "/" dimension separator, uncompressed or stdlib-zlib chunks.  (blosc/zstd stores written by
-iohub need numcodecs and are refused with a clear error — the codec pipeline is I/O, out of scope here.)
+HCS layout ``plate.zarr/<row>/<col>/<fov>/0`` with one 5-D ``(T,C,Z,Y,X)`` array per position on any regular chunk
+grid; chunk bytes uncompressed or through biahub_amd.codecs (Blosc as iohub writes it, zstd, gzip/zlib, lz4; zarr v3
+``bytes`` / ``blosc`` / ``zstd`` / ``gzip`` / ``crc32c`` / ``sharding_indexed``).  New stores default to chunks
+``(1,1,zc,Y,X)``, "/" keys and no compression (`compressor="blosc"` gives iohub's default).
 """
 
 from __future__ import annotations
@@ -84,85 +86,459 @@ def _host_volume(shape, dtype) -> np.ndarray:
     return np.empty(shape, dtype=dtype)
 
 
+_V3_DTYPES = {"bool": "|b1", "int8": "|i1", "uint8": "|u1", "int16": "<i2", "uint16": "<u2", "int32": "<i4",
+              "uint32": "<u4", "int64": "<i8", "uint64": "<u8", "float16": "<f2", "float32": "<f4", "float64": "<f8"}
+_V3_NAMES = {np.dtype(v): k for k, v in _V3_DTYPES.items()}
+_MISSING = 0xFFFFFFFFFFFFFFFF  # offset and length of an absent inner chunk in a shard index
+
+BLOSC_DEFAULT = {"id": "blosc", "cname": "zstd", "clevel": 1, "shuffle": 2, "blocksize": 0}  # what iohub writes
+
+
+def _fill(value, dtype):
+    if value is None:
+        return 0
+    if isinstance(value, str):
+        return {"NaN": np.nan, "Infinity": np.inf, "-Infinity": -np.inf}.get(value, 0) if dtype.kind == "f" else 0
+    return value
+
+
 class ZarrArray:
-    """5-D zarr v2 array, whole (t, c) volumes in and out."""
+    """5-D ``(T,C,Z,Y,X)`` zarr array — v2 (``.zarray``, NGFF 0.4) or v3 (``zarr.json``, NGFF 0.5, optionally sharded) —
+    read and written in whole (t, c) volumes.  Any regular chunk grid; chunk bytes through biahub_amd.codecs."""
 
     def __init__(self, path: Path):
         self.path = Path(path)
-        meta = json.loads((self.path / ".zarray").read_text())
+        self._locks: dict = {}
+        self._locks_mu = threading.Lock()
+        if (self.path / "zarr.json").exists():
+            self._init_v3(json.loads((self.path / "zarr.json").read_text()))
+        elif (self.path / ".zarray").exists():
+            self._init_v2(json.loads((self.path / ".zarray").read_text()))
+        else:
+            raise FileNotFoundError(f"{path} is not a zarr array")
+        if len(self.shape) != 5 or len(self.chunks) != 5:
+            raise NotImplementedError(f"{path}: expected a 5-D (T,C,Z,Y,X) array, got shape {self.shape}")
+        if any(c % i for c, i in zip(self.chunks, self.inner)):
+            raise ValueError(f"{path}: shard shape {self.chunks} is not a multiple of the chunk shape {self.inner}")
+        self.dtype = self.store_dtype.newbyteorder("=") if self.store_dtype.byteorder == ">" else self.store_dtype
+        self.fill_value = _fill(self.fill_value, self.dtype)
+
+    # ---- metadata -------------------------------------------------------------------------------------------
+    def _init_v2(self, meta):
+        from .codecs import codec_from_v2
+
         if meta.get("zarr_format") != 2:
-            raise ValueError(f"{path}: only zarr v2 arrays are supported")
-        comp = meta.get("compressor")
-        if comp is not None and comp.get("id") != "zlib":
-            raise NotImplementedError(
-                f"{path}: compressor {comp.get('id')!r} needs numcodecs; this reader handles uncompressed and zlib chunks"
-            )
+            raise ValueError(f"{self.path}: .zarray with zarr_format {meta.get('zarr_format')}")
         if meta.get("filters"):
-            raise NotImplementedError(f"{path}: zarr filters are not supported")
+            raise NotImplementedError(f"{self.path}: zarr filters are not supported")
+        if meta.get("order", "C") != "C":
+            raise NotImplementedError(f"{self.path}: only C-order chunks are supported")
+        self.zarr_format = 2
         self.shape = tuple(meta["shape"])
-        self.chunks = tuple(meta["chunks"])
-        self.dtype = np.dtype(meta["dtype"])
-        self.fill_value = meta.get("fill_value", 0) or 0
-        self.compressor = comp
-        self.sep = meta.get("dimension_separator", ".")
-        if len(self.shape) != 5 or self.chunks[0] != 1 or self.chunks[1] != 1 or self.chunks[3:] != self.shape[3:]:
-            raise NotImplementedError(f"{path}: expected a (T,C,Z,Y,X) array chunked (1,1,zc,Y,X), got {self.chunks}")
+        self.chunks = self.inner = tuple(meta["chunks"])
+        self.store_dtype = np.dtype(meta["dtype"])
+        self.fill_value = meta.get("fill_value", 0)
+        self.compressor = meta.get("compressor")
+        c = codec_from_v2(self.compressor, self.store_dtype.itemsize)
+        self.codecs = [c] if c is not None else []
+        self.sharded = False
+        sep = meta.get("dimension_separator", ".")
+        self._key = lambda idx: sep.join(str(v) for v in idx)
 
-    def _chunk_path(self, t, c, zi) -> Path:
-        return self.path / self.sep.join(str(v) for v in (t, c, zi, 0, 0))
+    def _init_v3(self, meta):
+        from .codecs import codec_from_v3
 
+        if meta.get("zarr_format") != 3 or meta.get("node_type") != "array":
+            raise ValueError(f"{self.path}: zarr.json is not a v3 array")
+        self.zarr_format = 3
+        self.shape = tuple(meta["shape"])
+        if meta["data_type"] not in _V3_DTYPES:
+            raise NotImplementedError(f"{self.path}: data type {meta['data_type']!r}")
+        dt = np.dtype(_V3_DTYPES[meta["data_type"]])
+        grid = meta["chunk_grid"]
+        if grid.get("name") != "regular":
+            raise NotImplementedError(f"{self.path}: chunk grid {grid.get('name')!r}")
+        self.chunks = tuple(grid["configuration"]["chunk_shape"])
+        enc = meta.get("chunk_key_encoding", {"name": "default"})
+        sep = (enc.get("configuration") or {}).get("separator", "/" if enc.get("name") == "default" else ".")
+        if enc.get("name") == "default":
+            self._key = lambda idx: "c" + sep + sep.join(str(v) for v in idx)
+        elif enc.get("name") == "v2":
+            self._key = lambda idx: sep.join(str(v) for v in idx)
+        else:
+            raise NotImplementedError(f"{self.path}: chunk key encoding {enc.get('name')!r}")
+        self.fill_value = meta.get("fill_value", 0)
+        self.compressor = None
+
+        def split(codecs):  # -> (endianness of the array->bytes stage or the sharding entry, bytes->bytes codecs)
+            a2b, b2b = None, []
+            for e in codecs:
+                name = e.get("name")
+                if name == "transpose":
+                    order = list((e.get("configuration") or {}).get("order", []))
+                    if order != sorted(order):
+                        raise NotImplementedError(f"{self.path}: transposed chunks are not supported")
+                elif name in ("bytes", "sharding_indexed"):
+                    a2b = e
+                else:
+                    b2b.append(codec_from_v3(e, dt.itemsize))
+            if a2b is None:
+                raise ValueError(f"{self.path}: codec list without an array->bytes codec")
+            return a2b, b2b
+
+        a2b, outer_b2b = split(meta["codecs"])
+        self.sharded = a2b["name"] == "sharding_indexed"
+        if self.sharded:
+            if outer_b2b:
+                raise NotImplementedError(f"{self.path}: codecs after sharding_indexed are not supported")
+            cfg = a2b["configuration"]
+            self.inner = tuple(cfg["chunk_shape"])
+            inner_a2b, self.codecs = split(cfg["codecs"])
+            if inner_a2b["name"] != "bytes":
+                raise NotImplementedError(f"{self.path}: nested sharding is not supported")
+            idx_a2b, idx_b2b = split(cfg.get("index_codecs", [{"name": "bytes"}, {"name": "crc32c"}]))
+            if idx_a2b["name"] != "bytes" or (idx_a2b.get("configuration") or {}).get("endian", "little") != "little" \
+                    or [c.kind for c in idx_b2b] not in ([], ["crc32c"]):
+                raise NotImplementedError(f"{self.path}: shard index codecs other than bytes(+crc32c) are not supported")
+            self.index_crc = bool(idx_b2b)
+            self.index_at_end = cfg.get("index_location", "end") == "end"
+            a2b = inner_a2b
+        else:
+            self.inner = self.chunks
+            self.codecs = outer_b2b
+        endian = (a2b.get("configuration") or {}).get("endian", "little")
+        self.store_dtype = dt.newbyteorder(">") if endian == "big" and dt.itemsize > 1 else dt
+
+    # ---- chunk bytes ----------------------------------------------------------------------------------------
+    def _chunk_path(self, idx) -> Path:
+        return self.path / self._key(idx)
+
+    def _lock(self, f: Path):
+        with self._locks_mu:
+            return self._locks.setdefault(str(f), threading.Lock())
+
+    def _decode(self, buf) -> np.ndarray:
+        n = int(np.prod(self.inner)) * self.store_dtype.itemsize
+        raw = buf
+        for c in reversed(self.codecs):
+            raw = c.decode(raw, n)
+        arr = np.frombuffer(raw, dtype=self.store_dtype, count=int(np.prod(self.inner))).reshape(self.inner)
+        return arr
+
+    def _encode(self, arr5: np.ndarray) -> bytes:
+        raw = np.ascontiguousarray(arr5, dtype=self.store_dtype).view(np.uint8).reshape(-1)
+        for c in self.codecs:
+            raw = c.encode(raw if isinstance(raw, np.ndarray) else np.frombuffer(raw, np.uint8))
+        return raw if isinstance(raw, (bytes, bytearray)) else raw.tobytes()
+
+    def _index_nbytes(self) -> int:
+        return 16 * int(np.prod([c // i for c, i in zip(self.chunks, self.inner)])) + (4 if self.index_crc else 0)
+
+    def _read_index(self, fh, size: int) -> np.ndarray:
+        from .codecs import crc32c
+
+        n = self._index_nbytes()
+        if size < n:
+            raise OSError(f"{fh.name}: shard shorter than its index")
+        fh.seek(size - n if self.index_at_end else 0)
+        raw = fh.read(n)
+        if self.index_crc:
+            if crc32c(raw[:-4]) != int.from_bytes(raw[-4:], "little"):
+                raise OSError(f"{fh.name}: shard index checksum mismatch")
+            raw = raw[:-4]
+        return np.frombuffer(raw, "<u8").reshape(tuple(c // i for c, i in zip(self.chunks, self.inner)) + (2,))
+
+    def _write_file(self, f: Path, payload) -> None:
+        f.parent.mkdir(parents=True, exist_ok=True)
+        tmp = f.with_name(f.name + f".tmp{threading.get_ident()}")
+        with open(tmp, "wb") as fh:
+            for part in payload if isinstance(payload, list) else [payload]:
+                fh.write(part)
+        os.replace(tmp, f)
+
+    def _write_shard(self, f: Path, pieces: dict) -> None:
+        """pieces: inner-chunk grid index (5-tuple) -> encoded bytes; inner chunks not listed are absent."""
+        from .codecs import crc32c
+
+        grid = tuple(c // i for c, i in zip(self.chunks, self.inner))
+        index = np.full(grid + (2,), _MISSING, dtype="<u8")
+        pos = 0 if self.index_at_end else self._index_nbytes()
+        body = []
+        for key in sorted(pieces):
+            index[key] = (pos, len(pieces[key]))
+            body.append(pieces[key])
+            pos += len(pieces[key])
+        raw = index.tobytes()
+        if self.index_crc:
+            raw += crc32c(raw).to_bytes(4, "little")
+        self._write_file(f, body + [raw] if self.index_at_end else [raw] + body)
+
+    def _spatial_blocks(self):
+        Z, Y, X = self.shape[2:]
+        cz, cy, cx = self.chunks[2:]
+        return [(zi, yi, xi) for zi in range(-(-Z // cz)) for yi in range(-(-Y // cy)) for xi in range(-(-X // cx))]
+
+    # ---- volumes --------------------------------------------------------------------------------------------
     def read_volume(self, t: int, c: int) -> np.ndarray:
-        """One (t, c) volume; its z-chunks are read (and inflated) concurrently, straight into the result."""
+        """One (t, c) volume; its chunk files are read (and decoded) concurrently, straight into the result."""
         T, C, Z, Y, X = self.shape
-        zc = self.chunks[2]
+        if not (0 <= t < T and 0 <= c < C):
+            raise IndexError(f"(t, c) = ({t}, {c}) outside {self.shape[:2]}")
+        ct, cc, cz, cy, cx = self.chunks
+        it, ic, iz, iy, ix = self.inner
         out = _host_volume((Z, Y, X), self.dtype)
+        plain = not self.sharded and not self.codecs and ct == 1 and cc == 1 and (cy, cx) == (Y, X) \
+            and self.store_dtype == self.dtype
 
-        def one(zi):
-            f = self._chunk_path(t, c, zi)
-            z0, z1 = zi * zc, min(Z, (zi + 1) * zc)
+        def place(arr5, tt, cc_, z0, y0, x0):  # arr5: a decoded (inner) chunk whose corner sits at (z0, y0, x0)
+            z1, y1, x1 = min(Z, z0 + arr5.shape[2]), min(Y, y0 + arr5.shape[3]), min(X, x0 + arr5.shape[4])
+            out[z0:z1, y0:y1, x0:x1] = arr5[tt, cc_, : z1 - z0, : y1 - y0, : x1 - x0]
+
+        def one(blk):
+            zi, yi, xi = blk
+            z0, y0, x0 = zi * cz, yi * cy, xi * cx
+            z1, y1, x1 = min(Z, z0 + cz), min(Y, y0 + cy), min(X, x0 + cx)
+            f = self._chunk_path((t // ct, c // cc, zi, yi, xi))
             try:
                 fh = open(f, "rb")
             except FileNotFoundError:
-                out[z0:z1] = self.fill_value
+                out[z0:z1, y0:y1, x0:x1] = self.fill_value
                 return
             with fh:
-                if self.compressor is None and z1 - z0 == zc:
+                if plain and z1 - z0 == cz:
                     view = memoryview(out[z0:z1]).cast("B")
                     if fh.readinto(view) != len(view):
                         raise OSError(f"{f}: truncated chunk")
                     return
-                raw = fh.read()
-            if self.compressor is not None:
-                raw = zlib.decompress(raw)  # releases the GIL
-            out[z0:z1] = np.frombuffer(raw, dtype=self.dtype).reshape(zc, Y, X)[: z1 - z0]
+                if not self.sharded:
+                    place(self._decode(fh.read()), t % ct, c % cc, z0, y0, x0)
+                    return
+                index = self._read_index(fh, os.fstat(fh.fileno()).st_size)
+                st, sc = (t % ct) // it, (c % cc) // ic
+                for kz in range(-(-(z1 - z0) // iz)):
+                    for ky in range(-(-(y1 - y0) // iy)):
+                        for kx in range(-(-(x1 - x0) // ix)):
+                            off, nb = (int(v) for v in index[st, sc, kz, ky, kx])
+                            q0, r0, s0 = z0 + kz * iz, y0 + ky * iy, x0 + kx * ix
+                            if off == _MISSING and nb == _MISSING:
+                                out[q0:min(Z, q0 + iz), r0:min(Y, r0 + iy), s0:min(X, s0 + ix)] = self.fill_value
+                                continue
+                            fh.seek(off)
+                            place(self._decode(fh.read(nb)), (t % ct) % it, (c % cc) % ic, q0, r0, s0)
 
-        _io_map(one, range(-(-Z // zc)))
+        _io_map(one, self._spatial_blocks())
         return out
 
     def write_volume(self, t: int, c: int, vol: np.ndarray) -> None:
         T, C, Z, Y, X = self.shape
         if vol.shape != (Z, Y, X):
             raise ValueError(f"volume shape {vol.shape} does not match array {(Z, Y, X)}")
-        zc = self.chunks[2]
+        if not (0 <= t < T and 0 <= c < C):
+            raise IndexError(f"(t, c) = ({t}, {c}) outside {self.shape[:2]}")
+        ct, cc, cz, cy, cx = self.chunks
+        it, ic, iz, iy, ix = self.inner
         vol = np.ascontiguousarray(vol, dtype=self.dtype)
+        plain = not self.sharded and not self.codecs and ct == 1 and cc == 1 and self.store_dtype == self.dtype
 
-        def one(zi):
-            z0, z1 = zi * zc, min(Z, (zi + 1) * zc)
-            chunk = vol[z0:z1]
-            if z1 - z0 < zc:  # zarr stores full chunks
-                pad = np.full((zc - (z1 - z0), Y, X), self.fill_value, dtype=self.dtype)
-                chunk = np.concatenate([chunk, pad])
-            raw = memoryview(chunk).cast("B")
-            if self.compressor is not None:
-                raw = zlib.compress(raw, self.compressor.get("level", 1))
-            f = self._chunk_path(t, c, zi)
-            f.parent.mkdir(parents=True, exist_ok=True)
-            tmp = f.with_name(f.name + ".tmp")
-            with open(tmp, "wb") as fh:
-                fh.write(raw)
-            os.replace(tmp, f)
+        def padded(z0, y0, x0, ez, ey, ex):  # the (ez, ey, ex) box at that corner, fill value outside the array
+            z1, y1, x1 = min(Z, z0 + ez), min(Y, y0 + ey), min(X, x0 + ex)
+            sub = vol[z0:z1, y0:y1, x0:x1]
+            if sub.shape == (ez, ey, ex):
+                return sub
+            box = np.full((ez, ey, ex), self.fill_value, dtype=self.dtype)
+            box[: z1 - z0, : y1 - y0, : x1 - x0] = sub
+            return box
 
-        _io_map(one, range(-(-Z // zc)))
+        def one(blk):
+            zi, yi, xi = blk
+            z0, y0, x0 = zi * cz, yi * cy, xi * cx
+            f = self._chunk_path((t // ct, c // cc, zi, yi, xi))
+            if not self.sharded:
+                box = padded(z0, y0, x0, cz, cy, cx)
+                if ct == 1 and cc == 1:
+                    self._write_file(f, memoryview(np.ascontiguousarray(box)).cast("B") if plain else self._encode(box[None, None]))
+                    return
+                with self._lock(f):  # the chunk file holds other (t, c) too: read, modify, write
+                    try:
+                        arr5 = self._decode(f.read_bytes()).astype(self.dtype)
+                    except FileNotFoundError:
+                        arr5 = np.full(self.chunks, self.fill_value, dtype=self.dtype)
+                    arr5[t % ct, c % cc] = box
+                    self._write_file(f, self._encode(arr5))
+                return
+            st, sc = (t % ct) // it, (c % cc) // ic
+            alone = ct == 1 and cc == 1  # the shard holds this (t, c) only: no need to look at what is on disk
+            with self._lock(f):
+                pieces, old = {}, None
+                if not alone and f.exists():
+                    with open(f, "rb") as fh:
+                        index = self._read_index(fh, os.fstat(fh.fileno()).st_size)
+                        for key in np.ndindex(*index.shape[:-1]):
+                            off, nb = (int(v) for v in index[key])
+                            if not (off == _MISSING and nb == _MISSING):
+                                fh.seek(off)
+                                pieces[key] = fh.read(nb)
+                for kz in range(cz // iz):
+                    for ky in range(cy // iy):
+                        for kx in range(cx // ix):
+                            q0, r0, s0 = z0 + kz * iz, y0 + ky * iy, x0 + kx * ix
+                            if q0 >= Z or r0 >= Y or s0 >= X:
+                                continue
+                            box = padded(q0, r0, s0, iz, iy, ix)
+                            key = (st, sc, kz, ky, kx)
+                            if it == 1 and ic == 1:
+                                pieces[key] = self._encode(box[None, None])
+                            else:
+                                old = pieces.get(key)
+                                arr5 = self._decode(old).astype(self.dtype) if old is not None else \
+                                    np.full(self.inner, self.fill_value, dtype=self.dtype)
+                                arr5[(t % ct) % it, (c % cc) % ic] = box
+                                pieces[key] = self._encode(arr5)
+                self._write_shard(f, pieces)
+
+        _io_map(one, self._spatial_blocks())
+
+    # ---- volumes straight to / from the GPU ----------------------------------------------------------------
+    def _plane_chunks(self):
+        """[(file index, inner key or None, z0, planes)] when every (inner) chunk is a stack of whole planes of one
+        (t, c) and the only codec is Blosc (or none) — the layout iohub writes — else None."""
+        Z, Y, X = self.shape[2:]
+        if self.inner[:2] != (1, 1) or self.inner[3:] != (Y, X) or self.chunks[3:] != (Y, X):
+            return None
+        if len(self.codecs) > 1 or (self.codecs and self.codecs[0].kind != "blosc") or self.store_dtype != self.dtype:
+            return None
+        cz, iz = self.chunks[2], self.inner[2]
+        out = []
+        for zi in range(-(-Z // cz)):
+            for kz in range(cz // iz):
+                z0 = zi * cz + kz * iz
+                if z0 < Z:
+                    out.append((zi, kz if self.sharded else None, z0, iz))
+        return out
+
+    def read_volume_device(self, t: int, c: int, device=None):
+        """One (t, c) volume as a device tensor.  Blosc chunks are entropy-decoded on the I/O threads into one pinned
+        staging block, uploaded still shuffled, and un-shuffled by ``bh_blosc_unfilter`` straight into the volume; other
+        layouts are read on the host and uploaded."""
+        import torch
+
+        from . import codecs
+        from .device import resolve_device
+
+        dev = resolve_device("cuda" if device is None else device)
+        plan = self._plane_chunks()
+        tdt = {np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.uint16, np.dtype(np.int16): torch.int16,
+               np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32,
+               np.dtype(np.float64): torch.float64}.get(self.dtype)
+        if plan is None or tdt is None or not self.codecs:
+            return torch.from_numpy(self.read_volume(t, c)).to(dev)
+        T, C, Z, Y, X = self.shape
+        ct, cc = self.chunks[:2]
+        cbytes = self.inner[2] * Y * X * self.dtype.itemsize
+        stage = torch.empty(len(plan) * cbytes, dtype=torch.uint8, pin_memory=True)
+        stage_np = stage.numpy()
+        heads: list = [None] * len(plan)
+
+        def one(i):
+            zi, kz, z0, _ = plan[i]
+            f = self._chunk_path((t // ct, c // cc, zi, 0, 0))
+            try:
+                fh = open(f, "rb")
+            except FileNotFoundError:
+                return
+            with fh:
+                if kz is None:
+                    buf = fh.read()
+                else:
+                    index = self._read_index(fh, os.fstat(fh.fileno()).st_size)
+                    off, nb = (int(v) for v in index[(t % ct), (c % cc), kz, 0, 0])
+                    if off == _MISSING and nb == _MISSING:
+                        return
+                    fh.seek(off)
+                    buf = fh.read(nb)
+            h, _ = codecs.blosc_decode_blocks(buf, out=stage_np[i * cbytes:(i + 1) * cbytes])
+            heads[i] = h
+
+        _io_map(one, range(len(plan)))
+        out = torch.empty((Z, Y, X), dtype=tdt, device=dev)
+        out8 = out.view(torch.uint8).reshape(-1)
+        dstage = stage.to(dev, non_blocking=True)
+        plane = Y * X * self.dtype.itemsize
+        tmp = None
+        for i, (zi, kz, z0, iz) in enumerate(plan):
+            h = heads[i]
+            dst = out8[z0 * plane:min(Z, z0 + iz) * plane]
+            if h is None:
+                out[z0:z0 + iz] = self.fill_value
+                continue
+            mode = codecs.BLOSC_NOSHUFFLE if h.memcpyed else h.shuffle_mode
+            src = dstage[i * cbytes:(i + 1) * cbytes]
+            if dst.numel() == cbytes:
+                codecs.unfilter_device(src, dst, h.blocksize, h.typesize, mode)
+            else:  # the last chunk overhangs the array: un-shuffle all of it, keep the planes inside
+                tmp = torch.empty(cbytes, dtype=torch.uint8, device=dev) if tmp is None else tmp
+                codecs.unfilter_device(src, tmp, h.blocksize, h.typesize, mode)
+                dst.copy_(tmp[: dst.numel()])
+        torch.cuda.current_stream(dev).synchronize()  # the pinned block may be recycled once we return
+        return out
+
+    def write_volume_device(self, t: int, c: int, vol) -> None:
+        """Store a device tensor as the (t, c) volume.  For Blosc plane-stack chunks the shuffle runs on the GPU
+        (``bh_blosc_filter``), the download lands in pinned memory and the I/O threads only run the entropy coder."""
+        import torch
+
+        from . import codecs
+        from .device import to_host
+
+        T, C, Z, Y, X = self.shape
+        if tuple(vol.shape) != (Z, Y, X):
+            raise ValueError(f"volume shape {tuple(vol.shape)} does not match array {(Z, Y, X)}")
+        plan = self._plane_chunks()
+        cfg = self.codecs[0].cfg if self.codecs else {}
+        if plan is None or not self.codecs or not vol.is_cuda or cfg.get("cname", "zstd") not in ("zstd", "lz4", "zlib") \
+                or codecs.default_blocksize(self.dtype.itemsize) > self.inner[2] * Y * X * self.dtype.itemsize:
+            return self.write_volume(t, c, to_host(vol) if vol.is_cuda else np.asarray(vol))
+        ct, cc = self.chunks[:2]
+        if (ct, cc) != (1, 1) or self.fill_value != 0:
+            return self.write_volume(t, c, to_host(vol))
+        want = {np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.uint16, np.dtype(np.int16): torch.int16,
+                np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32,
+                np.dtype(np.float64): torch.float64}.get(self.dtype)
+        if want is None:
+            return self.write_volume(t, c, to_host(vol))
+        v = vol.contiguous()
+        if v.dtype != want:
+            v = v.to(torch.float32).to(want) if want in (torch.uint16,) else v.to(want)
+        ts = self.dtype.itemsize
+        iz = self.inner[2]
+        plane = Y * X * ts
+        cbytes = iz * plane
+        bsz = int(cfg.get("blocksize", 0)) or codecs.default_blocksize(ts)
+        mode = int(cfg.get("shuffle", codecs.BLOSC_BITSHUFFLE))
+        v8 = v.view(torch.uint8).reshape(-1)
+        dstage = torch.empty(len(plan) * cbytes, dtype=torch.uint8, device=v.device)
+        for i, (zi, kz, z0, _) in enumerate(plan):
+            src = v8[z0 * plane:min(Z, z0 + iz) * plane]
+            if src.numel() != cbytes:  # the overhanging chunk is padded (fill value 0: all-zero bytes)
+                full = torch.zeros(cbytes, dtype=torch.uint8, device=v.device)
+                full[: src.numel()] = src
+                src = full
+            codecs.filter_device(src, dstage[i * cbytes:(i + 1) * cbytes], bsz, ts, mode)
+        host = to_host(dstage)
+        per_file: dict = {}
+
+        def one(i):
+            zi, kz, z0, _ = plan[i]
+            blob = codecs.blosc_compress(host[i * cbytes:(i + 1) * cbytes], ts, cfg.get("cname", "zstd"), cfg.get("clevel", 1),
+                                         mode, bsz, prefiltered=True)
+            if kz is None:
+                self._write_file(self._chunk_path((t, c, zi, 0, 0)), blob)
+            else:
+                per_file.setdefault(zi, {})[(0, 0, kz, 0, 0)] = blob
+
+        _io_map(one, range(len(plan)))
+        for zi, pieces in per_file.items():
+            self._write_shard(self._chunk_path((t, c, zi, 0, 0)), pieces)
 
     def __getitem__(self, key) -> np.ndarray:
         if not isinstance(key, tuple):
@@ -186,14 +562,62 @@ class ZarrArray:
             self.write_volume(int(t), int(c), np.asarray(value))
 
 
+_OME_KEYS = ("multiscales", "omero", "plate", "well", "bioformats2raw.layout", "labels", "image-label")
+
+
+def _group_format(path: Path) -> int | None:
+    if (path / "zarr.json").exists():
+        return 3
+    if (path / ".zgroup").exists():
+        return 2
+    return None
+
+
+def _read_group_attrs(path: Path) -> dict:
+    """Attributes of a group with the NGFF keys at top level whatever the layout: v2 keeps them in ``.zattrs``, NGFF 0.5
+    nests them under ``attributes["ome"]`` of ``zarr.json``."""
+    fmt = _group_format(path)
+    if fmt == 3:
+        meta = json.loads((path / "zarr.json").read_text())
+        if meta.get("node_type") != "group":
+            raise FileNotFoundError(f"{path} is not a zarr group")
+        attrs = dict(meta.get("attributes", {}))
+        ome = attrs.pop("ome", {})
+        flat = {k: v for k, v in ome.items() if k != "version"}
+        if "version" in ome:
+            flat["_ome_version"] = ome["version"]
+        flat.update(attrs)
+        return flat
+    if fmt == 2:
+        return json.loads((path / ".zattrs").read_text()) if (path / ".zattrs").exists() else {}
+    raise FileNotFoundError(f"{path} is not a zarr group")
+
+
+def _write_group(path: Path, fmt: int, attrs: dict | None = None, version: str = "0.5") -> None:
+    path.mkdir(parents=True, exist_ok=True)
+    attrs = dict(attrs or {})
+    attrs.pop("_ome_version", None)
+    if fmt == 2:
+        _write_json(path / ".zgroup", {"zarr_format": 2})
+        if attrs or (path / ".zattrs").exists():
+            _write_json(path / ".zattrs", attrs)
+        return
+    ome = {k: attrs.pop(k) for k in list(attrs) if k in _OME_KEYS}
+    out = dict(attrs)
+    if ome:
+        out["ome"] = {"version": version, **ome}
+    _write_json(path / "zarr.json", {"zarr_format": 3, "node_type": "group", "attributes": out})
+
+
 class Position:
     """One FOV group: ``<store>/<row>/<col>/<fov>`` with array "0" (what ``open_ome_zarr(position_path)`` yields)."""
 
     def __init__(self, path):
         self.path = Path(path)
-        if not (self.path / ".zgroup").exists():
+        self.zarr_format = _group_format(self.path)
+        if self.zarr_format is None:
             raise FileNotFoundError(f"{path} is not a zarr group")
-        self.zattrs = json.loads((self.path / ".zattrs").read_text()) if (self.path / ".zattrs").exists() else {}
+        self.zattrs = _read_group_attrs(self.path)
         self.data = ZarrArray(self.path / "0")
 
     def __enter__(self):
@@ -221,11 +645,13 @@ class Position:
 
     @property
     def version(self) -> str:
-        return str(self.zattrs.get("multiscales", [{}])[0].get("version", "0.4"))
+        if "_ome_version" in self.zattrs:
+            return str(self.zattrs["_ome_version"])
+        return str(self.zattrs.get("multiscales", [{}])[0].get("version", "0.5" if self.zarr_format == 3 else "0.4"))
 
     def update_zattrs(self, extra: dict) -> None:
         self.zattrs.update(extra)
-        _write_json(self.path / ".zattrs", self.zattrs)
+        _write_group(self.path, self.zarr_format, self.zattrs, self.version)
 
 
 def open_ome_zarr(path, mode: str = "r", layout: str = "auto") -> Position:
@@ -238,54 +664,110 @@ def read_fov_array(path) -> ZarrArray:
 
 
 def _position_zattrs(channel_names, scale, version, extra=None):
-    z = {
-        "multiscales": [{
-            "version": version,
-            "axes": _AXES,
-            "datasets": [{"path": "0", "coordinateTransformations": [{"type": "scale", "scale": [float(s) for s in scale]}]}],
-            "name": "0",
-        }],
-        "omero": {"version": version, "channels": [{"label": n, "active": True, "color": "FFFFFF",
-                                                   "window": {"start": 0, "end": 65535, "min": 0, "max": 65535}}
-                                                  for n in channel_names]},
+    ms = {
+        "axes": _AXES,
+        "datasets": [{"path": "0", "coordinateTransformations": [{"type": "scale", "scale": [float(s) for s in scale]}]}],
+        "name": "0",
     }
+    omero = {"channels": [{"label": n, "active": True, "color": "FFFFFF",
+                           "window": {"start": 0, "end": 65535, "min": 0, "max": 65535}} for n in channel_names]}
+    if version == "0.4":  # 0.5 carries the version once, on the enclosing "ome" object
+        ms = {"version": version, **ms}
+        omero = {"version": version, **omero}
+    z = {"multiscales": [ms], "omero": omero}
     if extra:
         z.update(extra)
     return z
 
 
+def _v3_codecs(compressor, itemsize):
+    """bytes->bytes codec entries of a zarr v3 array for a numcodecs-style ``compressor`` configuration."""
+    if compressor is None:
+        return []
+    cid = compressor.get("id")
+    if cid == "blosc":
+        sh = compressor.get("shuffle", 1)
+        sh = {0: "noshuffle", 1: "shuffle", 2: "bitshuffle", -1: "bitshuffle" if itemsize == 1 else "shuffle"}[int(sh)]
+        return [{"name": "blosc", "configuration": {"cname": compressor.get("cname", "zstd"), "clevel": compressor.get("clevel", 1),
+                                                    "shuffle": sh, "typesize": itemsize,
+                                                    "blocksize": compressor.get("blocksize", 0)}}]
+    if cid == "zstd":
+        return [{"name": "zstd", "configuration": {"level": compressor.get("level", 1), "checksum": False}}]
+    if cid in ("gzip", "zlib"):
+        return [{"name": "gzip", "configuration": {"level": compressor.get("level", 1)}}]
+    raise NotImplementedError(f"compressor {cid!r} has no zarr v3 codec here")
+
+
 def create_empty_position(path, channel_names, shape, chunks=None, scale=(1, 1, 1, 1, 1), dtype=np.float32,
-                          version="0.4", compressor=None, metadata=None) -> None:
-    """Idempotent: an existing position with the same shape is left alone (reference: deskew.py:608-610)."""
+                          version="0.4", compressor=None, metadata=None, shards_ratio=None) -> None:
+    """Idempotent: an existing position with the same shape is left alone (reference: deskew.py:608-610).
+    ``version`` "0.4" writes a zarr v2 hierarchy, "0.5" zarr v3; ``shards_ratio`` (v3) groups that many chunks per axis
+    into one shard file (`biahub/settings.py:460`).  ``compressor``: None, a numcodecs-style dict, or "blosc" for
+    what iohub writes (Blosc, zstd level 1, bit shuffle)."""
     path = Path(path)
+    version = str(version)
+    if version not in ("0.4", "0.5"):
+        raise ValueError(f"OME-Zarr version {version!r} (0.4 or 0.5)")
     T, C, Z, Y, X = (int(s) for s in shape)
     if len(channel_names) != C:
         raise ValueError(f"{len(channel_names)} channel names for C={C}")
-    if (path / "0" / ".zarray").exists():
-        if tuple(json.loads((path / "0" / ".zarray").read_text())["shape"]) == (T, C, Z, Y, X):
+    if (path / "0" / ".zarray").exists() or (path / "0" / "zarr.json").exists():
+        if ZarrArray(path / "0").shape == (T, C, Z, Y, X):
             return
         raise ValueError(f"{path} exists with a different shape")
+    if compressor == "blosc":
+        compressor = dict(BLOSC_DEFAULT)
+    dt = np.dtype(dtype)
     if chunks is None:
-        zc = max(1, min(Z, (64 << 20) // max(1, Y * X * np.dtype(dtype).itemsize)))
+        zc = max(1, min(Z, (64 << 20) // max(1, Y * X * dt.itemsize)))
         chunks = (1, 1, zc, Y, X)
+    chunks = tuple(int(c) for c in chunks)
     (path / "0").mkdir(parents=True, exist_ok=True)
-    _write_json(path / ".zgroup", {"zarr_format": 2})
-    _write_json(path / ".zattrs", _position_zattrs(channel_names, scale, version, metadata))
-    _write_json(path / "0" / ".zarray", {
-        "zarr_format": 2, "shape": [T, C, Z, Y, X], "chunks": [int(c) for c in chunks],
-        "dtype": np.dtype(dtype).str, "compressor": compressor, "fill_value": 0, "filters": None, "order": "C",
-        "dimension_separator": "/"})
+    fmt = 2 if version == "0.4" else 3
+    _write_group(path, fmt, _position_zattrs(channel_names, scale, version, metadata), version)
+    if fmt == 2:
+        if shards_ratio:
+            raise ValueError("sharding needs OME-Zarr 0.5 (zarr v3)")
+        _write_json(path / "0" / ".zarray", {
+            "zarr_format": 2, "shape": [T, C, Z, Y, X], "chunks": list(chunks),
+            "dtype": dt.str, "compressor": compressor, "fill_value": 0, "filters": None, "order": "C",
+            "dimension_separator": "/"})
+        return
+    if dt not in _V3_NAMES:
+        raise NotImplementedError(f"dtype {dt} has no zarr v3 name here")
+    inner = [{"name": "bytes", "configuration": {"endian": "little"}}] + _v3_codecs(compressor, dt.itemsize)
+    if shards_ratio:
+        ratio = tuple(int(r) for r in shards_ratio)
+        if len(ratio) != 5 or min(ratio) < 1:
+            raise ValueError("shards_ratio needs five positive integers (T, C, Z, Y, X)")
+        outer = tuple(c * r for c, r in zip(chunks, ratio))
+        codecs = [{"name": "sharding_indexed", "configuration": {
+            "chunk_shape": list(chunks), "codecs": inner,
+            "index_codecs": [{"name": "bytes", "configuration": {"endian": "little"}}, {"name": "crc32c"}],
+            "index_location": "end"}}]
+    else:
+        outer, codecs = chunks, inner
+    _write_json(path / "0" / "zarr.json", {
+        "zarr_format": 3, "node_type": "array", "shape": [T, C, Z, Y, X], "data_type": _V3_NAMES[dt],
+        "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": list(outer)}},
+        "chunk_key_encoding": {"name": "default", "configuration": {"separator": "/"}},
+        "fill_value": 0, "codecs": codecs, "attributes": {}, "dimension_names": ["T", "C", "Z", "Y", "X"],
+        "storage_transformers": []})
 
 
 def create_empty_plate(store_path, position_keys, channel_names, shape, chunks=None, scale=(1, 1, 1, 1, 1),
-                       dtype=np.float32, version="0.4", compressor=None, metadata=None) -> None:
+                       dtype=np.float32, version="0.4", compressor=None, metadata=None, shards_ratio=None) -> None:
     """HCS plate with empty positions — argument names follow iohub's ``create_empty_plate`` as the reference calls
     it (biahub/deskew.py:629-640, register.py:488-504)."""
     store = Path(store_path)
-    store.mkdir(parents=True, exist_ok=True)
-    _write_json(store / ".zgroup", {"zarr_format": 2})
-    attrs = json.loads((store / ".zattrs").read_text()) if (store / ".zattrs").exists() else {}
-    plate = attrs.get("plate", {"version": version, "rows": [], "columns": [], "wells": []})
+    version = str(version)
+    fmt = _group_format(store) or (2 if version == "0.4" else 3)
+    if (fmt == 2) != (version == "0.4"):
+        raise ValueError(f"{store} is a zarr v{fmt} store; cannot add OME-Zarr {version} positions to it")
+    attrs = _read_group_attrs(store) if _group_format(store) else {}
+    plate = attrs.get("plate", {"rows": [], "columns": [], "wells": []})
+    if version == "0.4":
+        plate.setdefault("version", version)
     for key in position_keys:
         row, col, fov = (str(k) for k in key)
         if {"name": row} not in plate["rows"]:
@@ -296,18 +778,21 @@ def create_empty_plate(store_path, position_keys, channel_names, shape, chunks=N
         if not any(w["path"] == wpath for w in plate["wells"]):
             plate["wells"].append({"path": wpath, "rowIndex": [r["name"] for r in plate["rows"]].index(row),
                                    "columnIndex": [c["name"] for c in plate["columns"]].index(col)})
-        (store / row).mkdir(exist_ok=True)
-        _write_json(store / row / ".zgroup", {"zarr_format": 2})
+        if _group_format(store / row) is None:
+            _write_group(store / row, fmt, None, version)
         well = store / row / col
-        well.mkdir(exist_ok=True)
-        _write_json(well / ".zgroup", {"zarr_format": 2})
-        wattrs = json.loads((well / ".zattrs").read_text()) if (well / ".zattrs").exists() else {"well": {"version": version, "images": []}}
-        if not any(i["path"] == fov for i in wattrs["well"]["images"]):
-            wattrs["well"]["images"].append({"path": fov})
-        _write_json(well / ".zattrs", wattrs)
-        create_empty_position(well / fov, channel_names, shape, chunks, scale, dtype, version, compressor, metadata)
+        wattrs = _read_group_attrs(well) if _group_format(well) else {}
+        wmeta = wattrs.get("well", {"images": []})
+        if version == "0.4":
+            wmeta.setdefault("version", version)
+        if not any(i["path"] == fov for i in wmeta["images"]):
+            wmeta["images"].append({"path": fov})
+        wattrs["well"] = wmeta
+        _write_group(well, fmt, wattrs, version)
+        create_empty_position(well / fov, channel_names, shape, chunks, scale, dtype, version, compressor, metadata,
+                              shards_ratio)
     attrs["plate"] = plate
-    _write_json(store / ".zattrs", attrs)
+    _write_group(store, fmt, attrs, version)
 
 
 def process_single_position(func, input_position_path, output_position_path, input_channel_indices=None,

@@ -11,6 +11,10 @@
  *                          <- biahub/flat_field.py:101-120 flat_field_zyx, :56-99 _median_tiled (np.median, axis 0)
  *   bh_bin_reduce, bh_bin_finish
  *                          <- biahub/process_data.py:29-105 binning_czyx
+ *   bh_blosc_unfilter, bh_blosc_filter
+ *                          <- (upstream of the reference) the chunk compressor of the OME-Zarr stores iohub 0.3.11 reads and
+ *                             writes for biahub/deskew.py:608-640,738-749: numcodecs 0.15.1 Blosc (uv.lock:3160-3161) =
+ *                             c-blosc 1.21 shuffle.c / bitshuffle-generic.c; the byte permutation half of it
  *   bh_overhang_fill       <- biahub/deskew.py:339-368  _fill_overhang_torch
  *   bh_transfer_function   <- biahub/deconvolve.py:30-43 compute_tranfser_function
  *   bh_tikhonov            <- biahub/deconvolve.py:46-66 deconvolve (waveorder Tikhonov)
@@ -123,6 +127,23 @@ int bh_bin_reduce(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t 
  * ndarray.astype; out_dtype is one of the BH_DT_* codes. */
 int bh_bin_finish(bh_ctx* ctx, const float* v, int64_t n, int apply, float sub, float mul, float div, int out_dtype,
                   void* out);
+
+/* ---- chunk codec: the byte permutations of the Blosc-1 container ---------------------- */
+#define BH_BLOSC_NOSHUFFLE 0
+#define BH_BLOSC_SHUFFLE 1
+#define BH_BLOSC_BITSHUFFLE 2
+/* src, dst: nbytes device bytes, distinct.  The buffer is ceil(nbytes / blocksize) blocks (the last one shorter), each
+ * permuted on its own exactly as c-blosc 1.x does for elements of `typesize` bytes: byte shuffle (mode 1; a
+ * size % typesize tail stays in place), bit shuffle (mode 2; only blocks holding a multiple of 8 elements, the others are
+ * stored unpermuted), or none (mode 0: copy).  bh_blosc_unfilter undoes what bh_blosc_filter (or a Blosc writer) did. */
+int bh_blosc_unfilter(bh_ctx* ctx, const void* src, void* dst, uint64_t nbytes, uint32_t blocksize, uint32_t typesize,
+                      int mode);
+int bh_blosc_filter(bh_ctx* ctx, const void* src, void* dst, uint64_t nbytes, uint32_t blocksize, uint32_t typesize,
+                    int mode);
+/* The same two permutations on host memory, on the calling thread (no context, no GPU): for volumes that stay on the
+ * host.  Re-entrant; callers parallelise over chunks. */
+int bh_host_blosc_unfilter(const void* src, void* dst, uint64_t nbytes, uint32_t blocksize, uint32_t typesize, int mode);
+int bh_host_blosc_filter(const void* src, void* dst, uint64_t nbytes, uint32_t blocksize, uint32_t typesize, int mode);
 
 /* ---- deskew ------------------------------------------------------------------------ */
 /* Host-only geometry. out_shape = (ceil(Y/n), X, Xp); voxel = (n*sin(t)*px, px, px).

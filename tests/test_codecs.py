@@ -31,12 +31,28 @@ def test_blosc_decode_matches_c_blosc_streams():
         # two-stage form used by the device path: entropy decode, then the permutation on its own
         hh, shuffled = C.blosc_decode_blocks(stream)
         if not hh.memcpyed:
-            assert np.array_equal(C.unfilter(shuffled, hh.nbytes, hh.blocksize, hh.typesize, hh.shuffle_mode), raw), n
+            for native in (True, False):
+                assert np.array_equal(C.unfilter(shuffled, hh.nbytes, hh.blocksize, hh.typesize, hh.shuffle_mode, native=native), raw), n
         seen.add((h.codec, h.shuffle_mode, h.memcpyed, -(-h.nbytes // max(1, h.blocksize)) > 1))
     # the fixture really covers every inner codec, both permutations, stored buffers and multi-block streams
     assert {c for c, *_ in seen} >= {"zstd", "lz4", "zlib", "blosclz"}
     assert {m for _, m, *_ in seen} == {0, 1, 2}
     assert any(s[2] for s in seen) and any(s[3] for s in seen)
+
+
+@pytest.mark.parametrize("typesize", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_native_host_permutations_match_numpy(typesize, mode):
+    """libbhcore's host code (bh_host_blosc_filter / _unfilter) against the NumPy restatement, ragged cases included."""
+    rng = np.random.default_rng(typesize + 10 * mode)
+    for nbytes, blocksize in ((100_003, 4096 * typesize), (70_001, 70_001), (typesize * 8 * 37 + typesize - 1, 1 << 20),
+                              (100, 64), (3, 1 << 10), (12 * typesize, 5 * typesize)):
+        raw = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        want = C.filter_host(raw, blocksize, typesize, mode, native=False)
+        got = C.filter_host(raw, blocksize, typesize, mode, native=True)
+        assert np.array_equal(got, want), (nbytes, blocksize)
+        assert np.array_equal(C.unfilter(want, nbytes, blocksize, typesize, mode, native=True), raw)
+        assert np.array_equal(C.unfilter(want, nbytes, blocksize, typesize, mode, native=False), raw)
 
 
 def test_blosc_rejects_truncated_and_corrupt_streams():
