@@ -25,6 +25,22 @@ from .utils.cluster import echo_resources, estimate_resources, get_submitit_clus
 from .utils.config import model_to_yaml, settings_fingerprint, yaml_to_model
 from .utils.paths import get_output_paths, sbatch_to_submitit
 
+
+def _output_compressor():
+    """Chunk compressor of the stores this CLI creates.  Default: what iohub gives the reference's outputs — Blosc with
+    zstd level 1 and bit shuffle (NGFF 0.4: numcodecs ``Blosc``; 0.5: the zarr v3 ``blosc`` codec).  BH_ZARR_COMPRESSOR =
+    none | blosc | zstd | zlib overrides it."""
+    import os
+
+    kind = os.environ.get("BH_ZARR_COMPRESSOR", "blosc").lower()
+    if kind in ("none", "raw", ""):
+        return None
+    if kind == "blosc":
+        return "blosc"
+    if kind in ("zstd", "zlib", "gzip"):
+        return {"id": kind, "level": 1}
+    raise click.UsageError(f"BH_ZARR_COMPRESSOR={kind!r}: expected none, blosc, zstd, zlib or gzip")
+
 _MULTI = {"-i", "--input-position-dirpaths", "-s", "--source-position-dirpaths", "-t", "--target-position-dirpaths"}
 
 
@@ -126,7 +142,7 @@ def deskew_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor
     out_shape, voxel = get_deskewed_data_shape((Z, Y, X), settings.ls_angle_deg, settings.px_to_scan_ratio,
                                                settings.keep_overhang, settings.average_n_slices, settings.pixel_size_um)
     create_empty_plate(output_dirpath, [p.parts[-3:] for p in input_position_dirpaths], channel_names,
-                       (T, C) + tuple(out_shape), scale=(1, 1) + tuple(voxel), version=version)
+                       (T, C) + tuple(out_shape), scale=(1, 1) + tuple(voxel), version=version, compressor=_output_compressor())
     minutes, cpus, gb = estimate_resources((T, C, Z, Y, X), ram_multiplier=8, time_multiplier=0.5, max_num_cpus=16)
     echo_resources(cpus, cpus * gb, minutes)
     if init_only:
@@ -178,7 +194,7 @@ def process_with_config_cli(input_position_dirpaths, output_dirpath, sbatch_file
             new_scale = scale[:2] + [scale[2] * f[0], scale[3] * f[1], scale[4] * f[2]]
             break
     create_empty_plate(output_dirpath, [p.parts[-3:] for p in input_position_dirpaths], names, out_shape, scale=new_scale,
-                       dtype=np.float32, version=settings.output_ome_zarr_version or version)
+                       dtype=np.float32, version=settings.output_ome_zarr_version or version, compressor=_output_compressor())
     if sbatch_filepath:
         sbatch_to_submitit(sbatch_filepath)
     allc = [list(range(Cn))]
@@ -243,7 +259,7 @@ def _same_shape_plate(inputs, output_dirpath, version_override, dtype=np.float32
     with open_ome_zarr(inputs[0]) as ds:
         names, shape, scale, version = ds.channel_names, ds.data.shape, ds.scale, version_override or ds.version
     create_empty_plate(output_dirpath, [p.parts[-3:] for p in inputs], names, shape, scale=scale, version=version,
-                       dtype=dtype)
+                       dtype=dtype, compressor=_output_compressor())
     return names, shape, scale
 
 
@@ -353,7 +369,7 @@ def register_cli(source_position_dirpaths, target_position_dirpaths, config_file
         click.echo(f"Cropping to the overlapping volume: {crop}")
     out_names = list(dict.fromkeys(list(settings.source_channel_names) + [settings.target_channel_name]))
     create_empty_plate(output_dirpath, [p.parts[-3:] for p in source_position_dirpaths], out_names,
-                       (T, len(out_names)) + out_zyx, scale=out_scale)
+                       (T, len(out_names)) + out_zyx, scale=out_scale, compressor=_output_compressor())
     outs = get_output_paths(source_position_dirpaths, output_dirpath)
     tidx = list(range(T)) if settings.time_indices == "all" else list(np.atleast_1d(settings.time_indices))
 
@@ -528,7 +544,7 @@ def estimate_psf_cli(input_position_dirpaths, config_filepath, output_dirpath):
     click.echo("Detecting beads...")
     psf = estimate_psf(pzyx, zyx_scale, patch_size=patch, verbose=True)
     create_empty_plate(output_dirpath, [("0", "0", "0")], ["PSF"], (1, 1) + psf.shape, chunks=(1, 1) + psf.shape,
-                       scale=(1, 1) + zyx_scale, dtype=np.float32)
+                       scale=(1, 1) + zyx_scale, dtype=np.float32, compressor=_output_compressor())
     open_ome_zarr(Path(output_dirpath) / "0/0/0").data[0, 0] = psf
     click.echo(f"PSF saved to {Path(output_dirpath).resolve()}")
 

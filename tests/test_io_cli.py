@@ -202,6 +202,28 @@ def test_cli_deskew_init_on_cpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_deskew_blosc_input_to_ngff05_output(gpu, tmp_path):
+    """An iohub-style input (NGFF 0.4, Blosc zstd bit-shuffled chunks) deskewed into an NGFF 0.5 (zarr v3) store with
+    the same codec, chosen by `output_ome_zarr_version` (reference settings.py:43, utils/ngff.py:27-39)."""
+    src = tmp_path / "in.zarr"
+    shape = (1, 1, 16, 24, 20)
+    data = make_plate(src, positions=(("A", "1", "0"),), shape=shape, compressor="blosc")
+    assert json.loads((src / "A/1/0/0/.zarray").read_text())["compressor"]["id"] == "blosc"
+    cfg = tmp_path / "deskew.yml"
+    cfg.write_text(DESKEW_YML + "output_ome_zarr_version: '0.5'\n")
+    out = tmp_path / "deskewed.zarr"
+    res = CliRunner().invoke(cli, expand_eat_all(["deskew", "-i", str(src / "A/1/0"), "-c", str(cfg), "-o", str(out), "--cluster", "debug"]))
+    assert res.exit_code == 0, res.output
+    got = io.open_ome_zarr(out / "A/1/0")
+    assert got.version == "0.5" and got.data.zarr_format == 3 and got.data.codecs[0].kind == "blosc"
+    meta = json.loads((out / "A/1/0/0/zarr.json").read_text())
+    assert meta["codecs"][1]["configuration"] == {"cname": "zstd", "clevel": 1, "shuffle": "bitshuffle", "typesize": 4, "blocksize": 0}
+    want = O.fast_deskew_zyx(data[("A", "1", "0", 0, 0)].astype(np.float32), 36.17, 0.371, True, 3, "mean")
+    assert np.abs(got.data[0, 0] - want).max() <= 1e-5 * want.max()
+    assert "biahub-deskew" in got.zattrs["extra_metadata"]
+
+
+@pytest.mark.gpu
 def test_cli_steps_end_to_end(gpu, tmp_path):
     src = tmp_path / "in.zarr"
     shape = (2, 2, 16, 24, 20)
