@@ -42,14 +42,23 @@ _IO_POOL = None
 
 
 def _io_pool():
-    """Shared pool for chunk I/O (file reads/writes and zlib release the GIL); size via BH_IO_THREADS (default 8)."""
+    """Shared pool for chunk I/O (file reads/writes, the entropy coders and the native shuffles release the GIL); size via
+    BH_IO_THREADS (default: the cores this process may use, at most 16)."""
     global _IO_POOL
     if _IO_POOL is None:
         from concurrent.futures import ThreadPoolExecutor
 
-        _IO_POOL = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("BH_IO_THREADS", "8"))),
+        _IO_POOL = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("BH_IO_THREADS", 0) or _default_io_threads())),
                                       thread_name_prefix="bh-io")
     return _IO_POOL
+
+
+def _default_io_threads() -> int:
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 8
+    return max(1, min(16, n))
 
 
 def _io_map(fn, items):

@@ -1,4 +1,5 @@
-"""Zarr-to-zarr throughput of the deskew command on one GPU (I/O + PCIe + kernels), BH_IO_THREADS sweep."""
+"""Zarr-to-zarr throughput of the deskew command on one GPU (I/O + PCIe + kernels): uncompressed stores with 1 and the
+default number of I/O threads, then iohub-style Blosc (zstd-1, bit shuffle) stores on both sides."""
 import os, shutil, subprocess, sys, tempfile, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -7,29 +8,39 @@ from biahub_amd import io
 
 root = Path(tempfile.mkdtemp(prefix="bh_e2e_", dir=os.environ.get("BH_E2E_DIR", "/tmp")))
 shape = (2, 2, 256, 1024, 1024)
-src = root / "in.zarr"
-io.create_empty_plate(src, [("A", "1", "0"), ("A", "2", "0")], ["c0", "c1"], shape, scale=(1, 1, 0.313, 0.116, 0.116), dtype=np.uint16)
 rng = np.random.default_rng(0)
-vol = (rng.random(shape[2:]) * 400 + 100).astype(np.uint16)
-t0 = time.perf_counter()
-for pos in ("A/1/0", "A/2/0"):
-    p = io.open_ome_zarr(src / pos)
-    for t in range(shape[0]):
-        for c in range(shape[1]):
-            p.data[t, c] = vol
-print(f"wrote input plate: {8 * vol.nbytes / (time.perf_counter() - t0) / 1e9:.2f} GB/s", flush=True)
+vol = (rng.poisson(6, shape[2:]) + 110 + (60 * np.sin(np.arange(shape[-1]) / 50.0)).astype(np.int64)).astype(np.uint16)
+srcs = {}
+for comp in (None, "blosc"):
+    src = srcs[comp] = root / f"in_{comp}.zarr"
+    io.create_empty_plate(src, [("A", "1", "0"), ("A", "2", "0")], ["c0", "c1"], shape, scale=(1, 1, 0.313, 0.116, 0.116),
+                          dtype=np.uint16, compressor=comp)
+    t0 = time.perf_counter()
+    for pos in ("A/1/0", "A/2/0"):
+        p = io.open_ome_zarr(src / pos)
+        for t in range(shape[0]):
+            for c in range(shape[1]):
+                p.data[t, c] = vol
+    print(f"wrote input plate ({comp or 'uncompressed'}): {8 * vol.nbytes / (time.perf_counter() - t0) / 1e9:.2f} GB/s", flush=True)
 (root / "d.yml").write_text("pixel_size_um: 0.116\nls_angle_deg: 36.17\npx_to_scan_ratio: 0.371\nscan_step_um: 0.313\n"
                             "keep_overhang: true\naverage_n_slices: 3\noverhang_fill: mean\n")
 V = 8 * int(np.prod(shape[2:]))
-for threads in ("1", "8"):
-    out = root / f"out{threads}.zarr"
-    env = dict(os.environ, BH_IO_THREADS=threads)
+def du(path):
+    return sum(f.stat().st_size for f in Path(path).rglob("*") if f.is_file())
+
+
+for comp, threads in ((None, "1"), (None, ""), ("blosc", "")):
+    out = root / f"out_{comp}_{threads or 'default'}.zarr"
+    src = srcs[comp]
+    env = dict(os.environ, BH_IO_THREADS=threads, BH_ZARR_COMPRESSOR=comp or "none")
     t0 = time.perf_counter()
     r = subprocess.run([sys.executable, "-m", "biahub_amd", "deskew", "-i", str(src / "A/1/0"), str(src / "A/2/0"), "-c",
                         str(root / "d.yml"), "-o", str(out), "--cluster", "debug"], env=env, capture_output=True, text=True,
                        cwd=str(Path(__file__).resolve().parent.parent))
     dt = time.perf_counter() - t0
     assert r.returncode == 0, r.stdout + r.stderr
-    print(f"deskew CLI, BH_IO_THREADS={threads}: {dt:.2f} s for 8 volumes of {shape[2:]} uint16 -> {V / dt / 1e9:.2f} Gvox/s "
-          f"(in {V * 2 / 1e9:.1f} GB, out {8 * 342 * 1024 * 1517 * 4 / 1e9:.1f} GB)", flush=True)
+    print(f"deskew CLI, {comp or 'uncompressed'} stores, BH_IO_THREADS={threads or 'default'}: {dt:.2f} s for 8 volumes of {shape[2:]} "
+          f"uint16 -> {V / dt / 1e9:.2f} Gvox/s (in {du(src) / 1e9:.1f} GB on disk, out {du(out) / 1e9:.1f} GB on disk, "
+          f"{8 * 342 * 1024 * 1517 * 4 / 1e9:.1f} GB raw)", flush=True)
+    shutil.rmtree(out)
 shutil.rmtree(root)
