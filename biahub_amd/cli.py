@@ -65,7 +65,7 @@ def expand_eat_all(argv: list[str]) -> list[str]:
 def _positions(ctx, param, value):
     paths = [Path(v) for v in value]
     for p in paths:
-        if not (p / ".zgroup").exists():
+        if not ((p / ".zgroup").exists() or (p / "zarr.json").exists()):
             raise click.BadParameter(f"{p} is not an OME-Zarr position")
     return sorted(paths)
 
@@ -547,6 +547,56 @@ def estimate_psf_cli(input_position_dirpaths, config_filepath, output_dirpath):
                        scale=(1, 1) + zyx_scale, dtype=np.float32, compressor=_output_compressor())
     open_ome_zarr(Path(output_dirpath) / "0/0/0").data[0, 0] = psf
     click.echo(f"PSF saved to {Path(output_dirpath).resolve()}")
+
+
+@cli.command("concatenate")
+@_config
+@click.option("--output-dirpath", "-o", required=True, type=click.Path(path_type=Path),
+              help="Path to output.zarr (or, with --concat-data-paths, to the resolved YAML)")
+@click.option("--sbatch-filepath", "-sb", default=None, type=click.Path(exists=True), help="Accepted for compatibility.")
+@click.option("--cluster", default=None, type=click.Choice(["slurm", "local", "debug"]))
+@click.option("--monitor", "-m", is_flag=True, default=False, help="Accepted for compatibility.")
+@click.option("--init", "init_only", is_flag=True, default=False, help="Create the output store, print RESOURCES, exit.")
+@click.option("--resume", is_flag=True, default=False, help="Skip the (time, channel) units a previous attempt finished.")
+@click.option("--concat-data-paths", multiple=True, type=str,
+              help="Resolve mode: inject these concat_data_paths into the config and write it to -o (a YAML file), then exit.")
+def concatenate_cli(config_filepath, output_dirpath, sbatch_filepath, cluster, monitor, init_only, resume, concat_data_paths):
+    """Concatenate datasets, with optional cropping (reference: ``biahub concatenate``, biahub/concatenate.py:556-636)."""
+    import yaml
+
+    from .concatenate import concatenate
+    from .settings import ConcatenateSettings
+
+    if concat_data_paths:  # the placeholder is filled in BEFORE validation: a blank list would not validate
+        raw = yaml.safe_load(Path(config_filepath).read_text())
+        raw["concat_data_paths"] = list(concat_data_paths)
+        model_to_yaml(ConcatenateSettings(**raw), output_dirpath)
+        click.echo(f"Resolved config written to {output_dirpath}")
+        return
+    settings = yaml_to_model(config_filepath, ConcatenateSettings)
+    if not init_only:
+        _resolve_cluster(cluster)
+    if sbatch_filepath:
+        sbatch_to_submitit(sbatch_filepath)
+    rank, world = (0, 1) if init_only else parallel.init()
+    if rank != 0:  # one rank lays the plate out; the others wait for it
+        parallel.barrier()
+    prep = concatenate(settings, output_dirpath, init_only=True, compressor=_output_compressor()) if rank == 0 else None
+    if rank == 0:
+        T, C, Z, Y, X = prep["shape"]
+        batch = settings.shards_ratio[0] if settings.shards_ratio else 1
+        _, cpus, gb = estimate_resources((T // batch, C, Z, Y, X), ram_multiplier=8 * batch, max_num_cpus=16)
+        echo_resources(cpus, cpus * gb, 360)
+        if not init_only and world > 1:
+            parallel.barrier()
+    if init_only:
+        return
+    log_dir = Path(output_dirpath).parent / "slurm_output"
+    prep = concatenate(settings, output_dirpath, resume=resume, compressor=_output_compressor(), rank=rank, world=world)
+    if rank == 0:
+        log_dir.mkdir(exist_ok=True)
+        (log_dir / "submitit_jobs_ids.log").write_text("\n".join(f"concatenate-{i}" for i in range(len(prep["all_data_paths"]))))
+    parallel.barrier()
 
 
 @cli.command("flip")

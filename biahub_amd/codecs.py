@@ -400,10 +400,11 @@ def blosc_compress(data, typesize: int, cname: str = "zstd", clevel: int = 1, sh
     nblocks = -(-nbytes // blocksize)
     parts, bstarts = [], []
     pos = 16 + 4 * nblocks
+    work = raw  # `raw` stays the caller's bytes: an incompressible buffer is stored unpermuted
     if not prefiltered and shuffle_mode != BLOSC_NOSHUFFLE:
-        raw = filter_host(raw, blocksize, typesize, shuffle_mode)
+        work = filter_host(raw, blocksize, typesize, shuffle_mode)
     for b in range(nblocks):
-        blk = raw[b * blocksize: min(nbytes, (b + 1) * blocksize)]
+        blk = work[b * blocksize: min(nbytes, (b + 1) * blocksize)]
         if cname == "zstd":
             comp = zstd_compress(blk, clevel)
         elif cname == "lz4":

@@ -635,6 +635,12 @@ class Position:
     def __exit__(self, *exc):
         return False
 
+    def close(self) -> None:
+        """Nothing is held open between calls; present because callers of iohub's nodes close them."""
+
+    def array_keys(self) -> list[str]:
+        return ["0"]
+
     def __getitem__(self, name):
         if str(name) != "0":
             raise KeyError(name)

@@ -236,3 +236,81 @@ class StabilizationSettings(_Strict):
             if np.asarray(m).shape != (4, 4):
                 raise ValueError("Each element in affine_transform_list must be a 4x4 ndarray")
         return v
+
+
+def _is_range(x) -> bool:
+    return isinstance(x, list) and len(x) == 2 and all(isinstance(i, int) for i in x)
+
+
+def _nonneg(r):
+    if not all(i >= 0 for i in r):
+        raise ValueError("Slice indices must be non-negative integers.")
+
+
+class ConcatenateSettings(_Strict):
+    """`biahub/settings.py:452-620`: what to concatenate (glob per source), which channels, optional per-source crops,
+    output chunking / sharding and NGFF version (0.5 by default: concatenate is the migration path into v3 stores)."""
+
+    concat_data_paths: list[str]
+    time_indices: int | list[int] | Literal["all"] = "all"
+    channel_names: list[str | list[str]]
+    X_slice: list | list[list | Literal["all"]] | Literal["all"] = "all"
+    Y_slice: list | list[list | Literal["all"]] | Literal["all"] = "all"
+    Z_slice: list | list[list | Literal["all"]] | Literal["all"] = "all"
+    chunks_czyx: Literal[None] | list[int] = None
+    shards_ratio: list[int] | None = None
+    ensure_unique_positions: bool | None = False
+    output_ome_zarr_version: OmeZarrVersion | None = "0.5"
+
+    @field_validator("X_slice", "Y_slice", "Z_slice")
+    @classmethod
+    def _check_slice(cls, v):
+        if v == "all":
+            return v
+        if not isinstance(v, list):
+            raise ValueError("Slice must be 'all' or a list.")
+        nested = any(isinstance(item, list) and any(isinstance(sub, list) for sub in item) for item in v)
+        if nested:  # one specification per source, each possibly a list of ranges itself
+            for item in v:
+                if item == "all":
+                    continue
+                if _is_range(item):
+                    _nonneg(item)
+                elif isinstance(item, list):
+                    for sub in item:
+                        if sub == "all":
+                            continue
+                        if not _is_range(sub):
+                            raise ValueError("Each slice subitem must be 'all' or a list of two non-negative integers [start, end].")
+                        _nonneg(sub)
+                else:
+                    raise ValueError("Each item in a per-path slice list must be 'all' or a valid slice specification.")
+            return v
+        if _is_range(v):
+            _nonneg(v)
+            return v
+        for item in v:
+            if item == "all":
+                continue
+            if not _is_range(item):
+                raise ValueError("Each slice item must be 'all' or a list of two non-negative integers [start, end].")
+            _nonneg(item)
+        return v
+
+    @field_validator("chunks_czyx")
+    @classmethod
+    def _check_chunks(cls, v):
+        if v is not None and (not isinstance(v, list) or len(v) != 4 or not all(isinstance(i, int) for i in v)):
+            raise ValueError("chunks_czyx must be a list of 4 integers (C, Z, Y, X)")
+        return v
+
+    @model_validator(mode="after")
+    def _check_slice_lengths(self):
+        n = len(self.concat_data_paths)
+        if n:
+            for axis in ("X", "Y", "Z"):
+                s = getattr(self, f"{axis}_slice")
+                if isinstance(s, list) and len(s) != n and not _is_range(s):
+                    raise ValueError(f"{axis}_slice must be 'all', a single slice specification, or a list with the same length "
+                                     f"as concat_data_paths ({n})")
+        return self

@@ -17,6 +17,7 @@ Fixtures written:
   transfer_function.npz   compute_tranfser_function (odd/even psf x odd/even volume)
   transform_scipy.npz     core.transform.Transform.apply (SciPy), orders 0/1
   phase_cross_corr.npz    estimate_stabilization.phase_cross_corr (three normalisations)
+  concatenate.json        biahub.concatenate slicing/channel-layout helpers, ConcatenateSettings validation
   helpers.json            settings dumps, fingerprints, estimate_resources, output paths,
                           sbatch parsing, matrix builders
 """
@@ -156,7 +157,92 @@ def binning_vectors():
     print("binning.npz written")
 
 
+def concatenate_vectors():
+    """biahub.concatenate helpers + ConcatenateSettings validation -> concatenate.json.  The one reference function that
+    opens stores (get_channel_combiner_metadata) is pointed at biahub_amd's reader through the module attribute it looks
+    `open_ome_zarr` up by; the plates it reads are made here with biahub_amd.io and described in the fixture."""
+    import biahub.concatenate as rc
+    from biahub.settings import ConcatenateSettings
+    from biahub_amd import io
+
+    out = {}
+    params = ["all", [2, 9], [[0, 4], [3, 7]], [[0, 4], "all", [1, 5]], [[[0, 2], [4, 6]], "all"], ["all", [1, 3]]]
+    out["get_path_slice_param"] = [
+        {"param": p_, "index": i, "total": n, "result": rc.get_path_slice_param(p_, i, n)}
+        for p_ in params for n in (2, 4) for i in range(n)]
+    out["get_slice"] = []
+    for p_ in ("all", [0, 5], [3, 3], [7, 2], [1], [1, 2, 3], [0.5, 2], "x", None):
+        try:
+            s_ = rc.get_slice(p_, 11)
+            out["get_slice"].append({"param": p_, "max": 11, "result": [s_.start, s_.stop]})
+        except ValueError as e:
+            out["get_slice"].append({"param": p_, "max": 11, "error": str(e)})
+    out["create_path_slicing_params"] = []
+    for z, y, x in (("all", "all", "all"), ([1, 3], "all", [0, 8]), ([0, 2], [2, 6], [4, 12])):
+        r = rc.create_path_slicing_params(z, y, x, (3, 2, 5, 9, 13))
+        out["create_path_slicing_params"].append({"z": z, "y": y, "x": x, "shape": [3, 2, 5, 9, 13], "result": [[q.start, q.stop] for q in r]})
+    out["calculate_cropped_size"] = [
+        {"slices": sl, "result": list(rc.calculate_cropped_size([slice(*q) for q in sl]))}
+        for sl in ([[0, 4], [0, 6], [0, 8]], [[2, 4], [6, 1], [3, 3]])]
+    out["validate_slicing_params_zyx"] = []
+    for group in ([[[0, 4], [0, 6], [0, 8]], [[1, 5], [2, 8], [4, 12]]], [[[0, 4], [0, 6], [0, 8]], [[0, 4], [0, 5], [0, 8]]]):
+        try:
+            rc.validate_slicing_params_zyx([[slice(*q) for q in sl] for sl in group])
+            out["validate_slicing_params_zyx"].append({"slices": group, "error": None})
+        except ValueError as e:
+            out["validate_slicing_params_zyx"].append({"slices": group, "error": str(e)})
+    # settings: accepted / rejected configurations
+    base = {"concat_data_paths": ["a/*/*/*", "b/*/*/*"], "channel_names": ["all", ["GFP"]]}
+    trials = [{}, {"X_slice": [0, 10]}, {"X_slice": [[0, 10], [5, 15]]}, {"X_slice": [[0, 10], "all"]}, {"X_slice": "half"},
+              {"X_slice": [-1, 5]}, {"X_slice": [[0, 10]]}, {"X_slice": [[0, 10], [1, 2], [3, 4]]}, {"Y_slice": [[0, 1, 2], [3, 4]]},
+              {"Z_slice": [[[0, 2], [4, 6]], "all"]}, {"Z_slice": [[[0, 2], [4, -6]], "all"]}, {"Z_slice": [[[0, 2], "x"], "all"]},
+              {"Z_slice": [[[0, 2]], 5]}, {"Z_slice": ["all", "all"]}, {"Z_slice": 3},
+              {"chunks_czyx": [1, 4, 8, 8]}, {"chunks_czyx": [4, 8, 8]}, {"shards_ratio": [1, 1, 2, 2, 2]},
+              {"time_indices": [0, 2]}, {"time_indices": 1}, {"time_indices": "some"}, {"output_ome_zarr_version": "0.4"},
+              {"output_ome_zarr_version": None}, {"output_ome_zarr_version": "0.3"}, {"channel_names": "all"},
+              {"concat_data_paths": "a"}, {"unknown": 1}, {"ensure_unique_positions": True}]
+    out["settings"] = []
+    for t_ in trials:
+        cfg = {**base, **t_}
+        try:
+            out["settings"].append({"config": cfg, "dump": ConcatenateSettings(**cfg).model_dump()})
+        except Exception as e:  # pydantic ValidationError
+            msgs = sorted({err["msg"] for err in e.errors()}) if hasattr(e, "errors") else [str(e)]
+            out["settings"].append({"config": cfg, "errors": msgs})
+    # channel layout over real (small) plates
+    rc.open_ome_zarr = io.open_ome_zarr
+    rc.natsorted = lambda seq: sorted(seq, key=lambda s_: [int(k) if k.isdigit() else k for k in __import__("re").split(r"(\d+)", s_)])
+    out["channel_combiner"] = []
+    with tempfile.TemporaryDirectory() as tmp:
+        tmp = Path(tmp)
+        plates = {"p1": (["DAPI", "Cy5"], [("A", "1", "0"), ("A", "2", "0"), ("A", "10", "0")]),
+                  "p2": (["GFP", "RFP", "DAPI"], [("A", "1", "0"), ("A", "2", "0"), ("A", "10", "0")]),
+                  "p3": (["BF"], [("B", "1", "0")])}
+        for name, (chans, poss) in plates.items():
+            io.create_empty_plate(tmp / f"{name}.zarr", poss, chans, (2, len(chans), 4, 6, 8), dtype=np.uint16)
+        out["channel_combiner_plates"] = {k: {"channels": v[0], "positions": ["/".join(p_) for p_ in v[1]], "shape": [2, len(v[0]), 4, 6, 8]} for k, v in plates.items()}
+        cases = [(["p1.zarr/*/*/*", "p2.zarr/*/*/*"], ["all", "all"], ["all", "all", "all"]),
+                 (["p1.zarr/*/*/*", "p2.zarr/*/*/*"], [["Cy5"], ["RFP", "GFP", "nope"]], [[0, 2], [[0, 3], [3, 6]], "all"]),
+                 (["p2.zarr/A/1/0", "p1.zarr/A/*/0", "p3.zarr/*/*/*"], ["all", ["DAPI"], "all"], ["all", [1, 5], [[0, 4], [2, 6], [4, 8]]]),
+                 (["p1.zarr/*/*/*", "p2.zarr/*/*/*"], ["all", "all"], [[[0, 2], [0, 3]], "all", "all"])]
+        for globs, chans, slicing in cases:
+            rec = {"globs": globs, "channels": chans, "slicing_zyx": slicing}
+            try:
+                paths, names, cin, cout, sl = rc.get_channel_combiner_metadata([str(tmp / g) for g in globs], chans, slicing)
+                rec.update(paths=[str(Path(p_).relative_to(tmp)) for p_ in paths], names=names, input_idx=cin, output_idx=cout,
+                           slices=[[[q.start, q.stop] for q in s_] for s_ in sl])
+            except ValueError as e:
+                rec["error"] = str(e)
+            out["channel_combiner"].append(rec)
+    (HERE / "concatenate.json").write_text(json.dumps(out, indent=1))
+    print("concatenate.json written")
+
+
 def main():
+    if sys.argv[1:] == ["concatenate"]:
+        load_reference()
+        concatenate_vectors()
+        return 0
     if sys.argv[1:] == ["binning"]:
         load_reference()
         binning_vectors()

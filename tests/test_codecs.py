@@ -96,10 +96,28 @@ def test_blosc_writer_round_trip_and_is_readable_by_c_blosc(cname, mode, dtype, 
     if os.path.exists(lib_path):
         lib = ctypes.CDLL(lib_path)
         lib.blosc_decompress_ctx.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-        src = np.frombuffer(stream, np.uint8).copy()
-        back = np.empty(arr.nbytes, np.uint8)
-        assert lib.blosc_decompress_ctx(src.ctypes.data, back.ctypes.data, back.size, 1) == arr.nbytes
-        assert np.array_equal(back, arr.view(np.uint8))
+        noise = rng.integers(0, 256, max(arr.nbytes, 1), dtype=np.uint8)[: arr.nbytes].view(arr.dtype)  # stored blocks / buffer
+        mixed = np.concatenate([noise, arr])
+        for a in (arr, noise, mixed):
+            src = np.frombuffer(C.blosc_compress(a, a.dtype.itemsize, cname, 1, mode, blocksize=4096 * a.dtype.itemsize), np.uint8).copy()
+            back = np.empty(a.nbytes, np.uint8)
+            assert lib.blosc_decompress_ctx(src.ctypes.data, back.ctypes.data, back.size, 1) == a.nbytes
+            assert np.array_equal(back, a.view(np.uint8))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("n", [720, 100_000])
+def test_blosc_writer_incompressible_data_is_stored_unpermuted(mode, n):
+    noise = np.random.default_rng(4).integers(1, 60000, n).astype(np.uint16)
+    stream = C.blosc_compress(noise, 2, "zstd", 1, mode)
+    h = C.BloscHeader(stream)
+    assert h.memcpyed and len(stream) == noise.nbytes + 16
+    assert np.array_equal(C.blosc_decompress(stream), noise.view(np.uint8))
+    # half noise, half zeros: compressible as a whole, with incompressible blocks stored inside the stream
+    mixed = np.concatenate([noise, np.zeros(n, np.uint16)])
+    stream = C.blosc_compress(mixed, 2, "zstd", 1, mode, blocksize=1024)
+    assert not C.BloscHeader(stream).memcpyed
+    assert np.array_equal(C.blosc_decompress(stream), mixed.view(np.uint8))
 
 
 def test_crc32c_check_values():
