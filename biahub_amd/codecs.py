@@ -13,8 +13,10 @@ restates the published formats:
 * CRC-32C (Castagnoli), which zarr v3's sharding index carries.
 
 The entropy coders themselves (zstd, lz4) come from pyarrow's bundled copies; zlib from the standard library.  The byte
-permutations (shuffle / bit shuffle) also exist as HIP kernels (csrc/codec.hip: ``bh_blosc_unfilter`` /
-``bh_blosc_filter``) so that a volume headed for the GPU is un-shuffled there, at HBM speed, instead of on a host core.
+permutations (shuffle / bit shuffle) are native code in libbhcore: HIP kernels (csrc/codec.hip: ``bh_blosc_unfilter`` /
+``bh_blosc_filter``) so that a volume headed for the GPU is un-shuffled there, at HBM speed, instead of on a host core,
+and the same loops as host code (``bh_host_blosc_*``) for volumes that stay on the host.  Their NumPy restatement is
+oracle/codec_np.py (tests only).
 """
 
 from __future__ import annotations
@@ -101,59 +103,6 @@ def crc32c(data, value: int = 0) -> int:
     for byte in bytes(memoryview(data)):
         crc = table[(crc ^ byte) & 0xFF] ^ (crc >> 8)
     return (~crc) & 0xFFFFFFFF
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# byte permutations of the Blosc container (c-blosc shuffle.c / bitshuffle-generic.c semantics)
-# ---------------------------------------------------------------------------------------------------------------
-def shuffle(block: np.ndarray, typesize: int) -> np.ndarray:
-    """Byte shuffle of one block: byte j of element i goes to plane j; the ``len % typesize`` tail is copied."""
-    block = np.asarray(block, np.uint8)
-    n = block.size // typesize
-    if typesize <= 1 or n == 0:
-        return block.copy()
-    out = np.empty_like(block)
-    out[: n * typesize] = block[: n * typesize].reshape(n, typesize).T.reshape(-1)
-    out[n * typesize:] = block[n * typesize:]
-    return out
-
-
-def unshuffle(block: np.ndarray, typesize: int) -> np.ndarray:
-    block = np.asarray(block, np.uint8)
-    n = block.size // typesize
-    if typesize <= 1 or n == 0:
-        return block.copy()
-    out = np.empty_like(block)
-    out[: n * typesize] = block[: n * typesize].reshape(typesize, n).T.reshape(-1)
-    out[n * typesize:] = block[n * typesize:]
-    return out
-
-
-def bitshuffle(block: np.ndarray, typesize: int) -> np.ndarray:
-    """Bit shuffle of one block: bit k of byte j of element i goes to bit-plane 8 j + k, element i at bit i % 8 (LSB
-    first) of byte i // 8 of the plane.  c-blosc 1.x applies it only when the block holds a multiple of 8 elements
-    and otherwise stores the block unpermuted; a ``len % typesize`` tail is copied."""
-    block = np.asarray(block, np.uint8)
-    n = block.size // typesize
-    if n == 0 or n % 8:
-        return block.copy()
-    out = np.empty_like(block)
-    bits = np.unpackbits(block[: n * typesize].reshape(n, typesize), axis=1, bitorder="little")  # (n, 8 ts)
-    out[: n * typesize] = np.packbits(bits.T, axis=1, bitorder="little").reshape(-1)            # (8 ts, n / 8)
-    out[n * typesize:] = block[n * typesize:]
-    return out
-
-
-def bitunshuffle(block: np.ndarray, typesize: int) -> np.ndarray:
-    block = np.asarray(block, np.uint8)
-    n = block.size // typesize
-    if n == 0 or n % 8:
-        return block.copy()
-    out = np.empty_like(block)
-    planes = np.unpackbits(block[: n * typesize].reshape(8 * typesize, n // 8), axis=1, bitorder="little")  # (8 ts, n)
-    out[: n * typesize] = np.packbits(planes.T, axis=1, bitorder="little").reshape(-1)                      # (n, ts)
-    out[n * typesize:] = block[n * typesize:]
-    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -305,53 +254,40 @@ def blosc_decode_blocks(buf, out: np.ndarray | None = None) -> tuple[BloscHeader
     return h, out
 
 
-def _native_filter(name: str, src: np.ndarray, out: np.ndarray, blocksize: int, typesize: int, mode: int) -> bool:
-    """Run the permutation in libbhcore's host code (csrc/codec.hip, ``bh_host_blosc_*``: releases the GIL, ~50x the
-    NumPy formulation below).  False when the library is not built — the NumPy restatement then does the work."""
-    try:
-        from . import _lib
+def _native_filter(name: str, src: np.ndarray, out: np.ndarray, blocksize: int, typesize: int, mode: int) -> None:
+    """The per-block permutation in libbhcore's host code (csrc/codec.hip, ``bh_host_blosc_*``; releases the GIL).  Like
+    every other operator of this package it needs the built library: there is no NumPy fallback (the NumPy restatement
+    lives in oracle/codec_np.py and is test infrastructure)."""
+    from . import _lib
 
-        lib = _lib.load()
-    except ImportError:
-        return False
+    lib = _lib.load()
     src = np.ascontiguousarray(src)
     _lib.check(getattr(lib, name)(src.ctypes.data, out.ctypes.data, src.size, int(blocksize), int(typesize), int(mode)))
-    return True
 
 
 def unfilter(shuffled: np.ndarray, nbytes: int, blocksize: int, typesize: int, mode: int,
-             out: np.ndarray | None = None, native: bool = True) -> np.ndarray:
+             out: np.ndarray | None = None) -> np.ndarray:
     """Undo the per-block permutation of a Blosc stream on the host."""
-    if out is None:
-        out = np.empty(nbytes, np.uint8)
+    if out is None or not out.flags.c_contiguous:
+        res = np.empty(nbytes, np.uint8)
+    else:
+        res = out
     if mode == BLOSC_NOSHUFFLE or nbytes == 0:
-        out[:] = shuffled
+        res[:] = shuffled
+    else:
+        _native_filter("bh_host_blosc_unfilter", shuffled, res, blocksize, typesize, mode)
+    if out is not None and res is not out:
+        out[:] = res
         return out
-    if native and out.flags.c_contiguous and _native_filter("bh_host_blosc_unfilter", shuffled, out, blocksize, typesize, mode):
-        return out
-    fn = unshuffle if mode == BLOSC_SHUFFLE else bitunshuffle
-    for o0 in range(0, nbytes, blocksize):
-        o1 = min(nbytes, o0 + blocksize)
-        if mode == BLOSC_BITSHUFFLE and o1 - o0 < typesize:
-            out[o0:o1] = shuffled[o0:o1]
-        else:
-            out[o0:o1] = fn(shuffled[o0:o1], typesize)
-    return out
+    return res
 
 
-def filter_host(raw: np.ndarray, blocksize: int, typesize: int, mode: int, native: bool = True) -> np.ndarray:
+def filter_host(raw: np.ndarray, blocksize: int, typesize: int, mode: int) -> np.ndarray:
     """The per-block permutation a Blosc writer applies (inverse of ``unfilter``)."""
     raw = np.asarray(raw, np.uint8).reshape(-1)
     out = np.empty_like(raw)
-    if native and raw.size and _native_filter("bh_host_blosc_filter", raw, out, max(1, blocksize), typesize, mode):
-        return out
-    for o0 in range(0, raw.size, max(1, blocksize)):
-        blk = raw[o0:o0 + blocksize]
-        if mode == BLOSC_SHUFFLE and typesize > 1:
-            blk = shuffle(blk, typesize)
-        elif mode == BLOSC_BITSHUFFLE and blk.size >= typesize:
-            blk = bitshuffle(blk, typesize)
-        out[o0:o0 + blk.size] = blk
+    if raw.size:
+        _native_filter("bh_host_blosc_filter", raw, out, max(1, blocksize), typesize, mode)
     return out
 
 

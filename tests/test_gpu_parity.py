@@ -796,16 +796,17 @@ def test_binning_golden_and_oracle(gpu):
 @pytest.mark.parametrize("typesize", [1, 2, 3, 4, 8])
 @pytest.mark.parametrize("mode", [1, 2])
 def test_blosc_filters_device_bit_exact(gpu, typesize, mode):
-    """bh_blosc_filter / bh_blosc_unfilter against the NumPy restatement (itself pinned to c-blosc streams): full blocks,
+    """bh_blosc_filter / bh_blosc_unfilter against the NumPy oracle (itself pinned to c-blosc streams): full blocks,
     ragged last blocks, blocks whose element count is not a multiple of 8 (bit shuffle then leaves them alone), tails
     shorter than one element."""
     from biahub_amd import codecs
+    from oracle import codec_np
 
     rng = np.random.default_rng(typesize * 7 + mode)
     for nbytes, blocksize in ((1 << 20, 1 << 16), (1_000_003, 4096 * typesize), (70_001, 70_001), (5000 * typesize + 1, 2048 * typesize),
                               (typesize * 8 * 37 + typesize - 1, 1 << 20), (100, 64), (3, 1 << 10), (12 * typesize, 5 * typesize)):
         raw = rng.integers(0, 256, nbytes, dtype=np.uint8)
-        want = codecs.filter_host(raw, blocksize, typesize, mode)
+        want = codec_np.filter_blocks(raw, blocksize, typesize, mode)
         src = torch.from_numpy(raw).to(gpu)
         dst = torch.empty_like(src)
         codecs.filter_device(src, dst, blocksize, typesize, mode)
@@ -813,7 +814,7 @@ def test_blosc_filters_device_bit_exact(gpu, typesize, mode):
         back = torch.empty_like(src)
         codecs.unfilter_device(dst, back, blocksize, typesize, mode)
         assert np.array_equal(back.cpu().numpy(), raw), (nbytes, blocksize)
-        assert np.array_equal(codecs.unfilter(want, nbytes, blocksize, typesize, mode), raw)
+        assert np.array_equal(codec_np.unfilter(want, nbytes, blocksize, typesize, mode), raw)
 
 
 @pytest.mark.gpu
