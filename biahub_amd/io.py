@@ -74,22 +74,29 @@ def _io_map(fn, items):
 _TORCH_DT = None
 
 
+def _torch_dtype(dtype):
+    """torch dtype of a numpy dtype a volume can have, or None."""
+    global _TORCH_DT
+    if _TORCH_DT is None:
+        import torch
+
+        _TORCH_DT = {np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.uint16, np.dtype(np.int16): torch.int16,
+                     np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64, np.dtype(np.int32): torch.int32}
+    return _TORCH_DT.get(np.dtype(dtype))
+
+
 def _host_volume(shape, dtype) -> np.ndarray:
     """Destination of a volume read: pinned host memory from torch's caching host allocator when a GPU is present (the
     upload that follows is then a direct DMA, and a plate's equally shaped volumes reuse the blocks), plain numpy else."""
-    global _TORCH_DT
     dtype = np.dtype(dtype)
     if int(np.prod(shape)) * dtype.itemsize >= (8 << 20):
         try:
             import torch
 
             if torch.cuda.is_available():
-                if _TORCH_DT is None:
-                    _TORCH_DT = {np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.uint16,
-                                 np.dtype(np.int16): torch.int16, np.dtype(np.float32): torch.float32,
-                                 np.dtype(np.float64): torch.float64, np.dtype(np.int32): torch.int32}
-                if dtype in _TORCH_DT:
-                    return torch.empty(tuple(int(v) for v in shape), dtype=_TORCH_DT[dtype], pin_memory=True).numpy()
+                tdt = _torch_dtype(dtype)
+                if tdt is not None:
+                    return torch.empty(tuple(int(v) for v in shape), dtype=tdt, pin_memory=True).numpy()
         except Exception:  # no torch / no pinned memory: pageable is always correct
             pass
     return np.empty(shape, dtype=dtype)
@@ -436,9 +443,7 @@ class ZarrArray:
 
         dev = resolve_device("cuda" if device is None else device)
         plan = self._plane_chunks()
-        tdt = {np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.uint16, np.dtype(np.int16): torch.int16,
-               np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32,
-               np.dtype(np.float64): torch.float64}.get(self.dtype)
+        tdt = _torch_dtype(self.dtype)
         if plan is None or tdt is None or not self.codecs:
             return torch.from_numpy(self.read_volume(t, c)).to(dev)
         T, C, Z, Y, X = self.shape
@@ -510,9 +515,7 @@ class ZarrArray:
         ct, cc = self.chunks[:2]
         if (ct, cc) != (1, 1) or self.fill_value != 0:
             return self.write_volume(t, c, to_host(vol))
-        want = {np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.uint16, np.dtype(np.int16): torch.int16,
-                np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32,
-                np.dtype(np.float64): torch.float64}.get(self.dtype)
+        want = _torch_dtype(self.dtype)
         if want is None:
             return self.write_volume(t, c, to_host(vol))
         v = vol.contiguous()
