@@ -1196,6 +1196,25 @@ int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, con
     return BH_OK;
 }
 
+// One Richardson-Lucy iteration on a volume the CALLER keeps wrap-padded (deconv.hip: richardson_lucy_engine_padded).
+// est_p is read by the forward X pass and updated in place, on all of the padded box, by the last inverse X pass; only the
+// interior the caller cares about is meaningful afterwards, so the update cannot be fused into the next forward transform
+// (the margins must be re-wrapped first): 10 passes instead of 8.  d_p is the wrap-padded data term, zero outside its
+// extended box, which also zeroes the ratio there.
+int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, float* est_p, const float* d_p, const cf* otf, cf* spec,
+                                float eps) {
+    BH_TRY(launch_x(ctx, pl, false, 0, est_p, spec, nullptr, nullptr, 0.f));
+    BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));
+    BH_TRY(launch_col(ctx, pl, COL_CONV, true, spec, otf, 1.f));
+    BH_TRY(launch_col(ctx, pl, COL_INV, false, spec, nullptr, 1.f));
+    BH_TRY(launch_x(ctx, pl, true, XE_RATIO, nullptr, spec, nullptr, d_p, eps, true));
+    BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));
+    BH_TRY(launch_col(ctx, pl, COL_CORR, true, spec, otf, 1.f));
+    BH_TRY(launch_col(ctx, pl, COL_INV, false, spec, nullptr, 1.f));
+    BH_TRY(launch_x(ctx, pl, true, XE_UPDATE, nullptr, spec, est_p, est_p, eps, false));
+    return BH_OK;
+}
+
 // Bare transform pair for callers that do their own spectral arithmetic (phase cross-correlation): forward leaves the
 // true DFT coefficients in the engine's scrambled half-spectrum layout, inverse returns real space scaled by V/2
 // (multiply the spectrum by 2/V first for a normalised irfftn).  Any element-wise operation that treats both spectra

@@ -186,6 +186,8 @@ def test_richardson_lucy_vs_oracle(gpu, shape, pshape):
     ((37, 53, 71), (4, 6, 8)),      # even PSF extents: the kernel reaches further below 0 than above N-1
     ((32, 53, 64), (9, 7, 5)),      # only Y is awkward; Z and X wrap on their own
     ((19, 40, 134), (5, 3, 11)),    # 134 = 2 * 67
+    ((21, 64, 150), (7, 5, 9)),     # Y a power of two the engine keeps as it is, Z and X wrap-padded to 64 and 256
+    ((40, 70, 64), (9, 9, 3)),      # X stays, Z -> 64, Y -> 128
 ])
 def test_richardson_lucy_awkward_sizes_pad_fold(gpu, shape, pshape, monkeypatch):
     """Axes with a large prime factor are zero-padded to a 7-smooth FFT size and the wrapped part of the linear
@@ -200,11 +202,19 @@ def test_richardson_lucy_awkward_sizes_pad_fold(gpu, shape, pshape, monkeypatch)
     psf[0, 0, 0] += 0.02    # asymmetric: convolution and correlation differ
     want = O.richardson_lucy_zyx(vol, psf, iterations=6, eps=1e-6)
     v, pt = torch.from_numpy(vol).to(gpu), torch.from_numpy(psf).to(gpu)
-    got = richardson_lucy(v, pt, 6, 1e-6).cpu().numpy()
+    got = richardson_lucy(v, pt, 6, 1e-6).cpu().numpy()          # whichever back-end the cost model picks
     assert rel_err(got, want) <= FFT_TOL, rel_err(got, want)
+    monkeypatch.setenv("BH_RL_ENGINE_PAD", "0")                   # library transforms at the 7-smooth box
+    lib = richardson_lucy(v, pt, 6, 1e-6).cpu().numpy()
+    assert rel_err(lib, want) <= FFT_TOL, rel_err(lib, want)
     monkeypatch.setenv("BH_RL_NOPAD", "1")
     plain = richardson_lucy(v, pt, 6, 1e-6).cpu().numpy()
-    assert rel_err(plain, want) <= FFT_TOL and rel_err(got, plain) <= FFT_TOL
+    assert rel_err(plain, want) <= FFT_TOL and rel_err(lib, plain) <= FFT_TOL
+    monkeypatch.delenv("BH_RL_NOPAD")
+    monkeypatch.setenv("BH_RL_ENGINE_PAD", "1")                   # fused engine at the wrap-padded power-of-two box
+    eng = richardson_lucy(v, pt, 6, 1e-6).cpu().numpy()
+    assert rel_err(eng, want) <= FFT_TOL, rel_err(eng, want)
+    assert np.array_equal(richardson_lucy(v, pt, 0, 1e-6).cpu().numpy(), np.maximum(vol, 0))
 
 
 # ----------------------------------------------------------------------------- affine

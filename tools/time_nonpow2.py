@@ -15,11 +15,28 @@ psf = gaussian_psf((33, 17, 17), (3, 1.5, 1.5))
 for shape in ((342, 1024, 1517), (256, 1024, 1024), (384, 1024, 1536)):
     V = np.prod(shape)
     vol = torch.rand(shape, device=dev) * 100
-    for _ in range(2):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        out = richardson_lucy(vol, psf, 10, 1e-6); torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    print(f"RL x10 {shape}: {dt*1e3:.1f} ms -> {V/dt/1e9:.2f} Gvox/s", flush=True)
+    import os
+    res = {}
+    for force, name in (("0", "library FFT, 7-smooth pad-and-fold"), ("1", "fused engine, wrap-padded power-of-two box"), (None, "default")):
+        if force is None:
+            os.environ.pop("BH_RL_ENGINE_PAD", None)
+        else:
+            os.environ["BH_RL_ENGINE_PAD"] = force
+        try:
+            for _ in range(2):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                out = richardson_lucy(vol, psf, 10, 1e-6); torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+        except Exception as e:  # the forced engine box can be outside the engine's range
+            print(f"RL x10 {shape} [{name}]: {type(e).__name__}: {e}", flush=True)
+            continue
+        res[name] = out.clone()
+        print(f"RL x10 {shape} [{name}]: {dt*1e3:.1f} ms -> {V/dt/1e9:.2f} Gvox/s", flush=True)
+        ctx.release_workspace()
+    ks = list(res)
+    if len(ks) >= 2:
+        print(f"   max |engine - library| / max = {float((res[ks[0]] - res[ks[1]]).abs().max() / res[ks[0]].abs().max()):.2e}", flush=True)
+    res.clear()
     tf = transfer_function_device(psf, shape, dev)
     for _ in range(2):
         out = tikhonov_zyx(vol, tf, 1e-3); ms = ctx.elapsed_ms(_lib.T_TIKHONOV)
