@@ -375,6 +375,7 @@ static void pad_before(int64_t p, int64_t S, int* before) { *before = (int)((S -
 // fused FFT-convolution engine (fftconv.hip)
 struct ConvPlan;
 bool fftconv_supported(int64_t Z, int64_t Y, int64_t X);
+bool fftconv_supported_ex(int64_t Z, int64_t Y, int64_t X, bool radix3);
 int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out);
 size_t fftconv_spectrum_elems(const ConvPlan& pl);
 int fftconv_make_otf(bh_ctx* ctx, const ConvPlan& pl, const float* padded_psf, cf* otf);
@@ -494,21 +495,37 @@ static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, 
     return BH_OK;
 }
 
+static bool is_smooth(int64_t n) {  // only the radices hipFFT has native kernels for
+    for (int p : {2, 3, 5, 7})
+        while (n % p == 0) n /= p;
+    return n == 1;
+}
+static int64_t next_smooth(int64_t n) {
+    while (!is_smooth(n)) ++n;
+    return n;
+}
 static bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
 
 // Box the fused engine could run an awkward volume at: power-of-two axes inside the engine's range stay as they are (they
 // wrap by themselves), the others grow to the next power of two >= N + 2 (K - 1) (room for the twice-extended estimate).
 static bool engine_pad_box(const int64_t N[3], const int64_t K[3], int64_t P[3]) {
+    static const bool radix3 = getenv("BH_FC_NORADIX3") == nullptr;
     for (int a = 0; a < 3; ++a) {
-        if (is_pow2(N[a])) {
+        // axes the engine transforms as they are wrap by themselves: powers of two, and 3 * 2^k along z and y
+        if (is_pow2(N[a]) || (radix3 && a < 2 && N[a] % 3 == 0 && is_pow2(N[a] / 3) &&
+                              fftconv_supported_ex(a == 0 ? N[a] : 64, a == 1 ? N[a] : 64, 64, true))) {
             P[a] = N[a];
             continue;
         }
+        const int64_t need = N[a] + 2 * (K[a] - 1);
         P[a] = 1;
-        while (P[a] < N[a] + 2 * (K[a] - 1)) P[a] *= 2;
+        while (P[a] < need) P[a] *= 2;
+        // z and y columns may also be 3 * 2^k long (radix-3 first step of the column passes); rows along x may not
+        if (radix3 && a < 2 && P[a] >= 8 && 3 * (P[a] / 4) >= need && fftconv_supported_ex(a == 0 ? 3 * (P[a] / 4) : 64, a == 1 ? 3 * (P[a] / 4) : 64, 64, true))
+            P[a] = 3 * (P[a] / 4);
         if (K[a] - 1 >= N[a]) return false;  // the wrap below assumes margins shorter than the axis
     }
-    return fftconv_supported(P[0], P[1], P[2]);
+    return fftconv_supported_ex(P[0], P[1], P[2], true);
 }
 
 // Richardson-Lucy for an awkward shape on the fused engine.  Padded axes carry the estimate wrap-extended by K - 1 on both
@@ -596,6 +613,34 @@ static int richardson_lucy_engine_padded(bh_ctx* ctx, const float* d, const floa
         (void)hipEventDestroy(e1);
     }
     return BH_OK;
+}
+
+// Which transform box and back-end Richardson-Lucy uses for a shape (host logic only; bh_richardson_lucy_plan exports it).
+static int rl_plan(int64_t pz, int64_t py, int64_t px, int64_t Z, int64_t Y, int64_t X, int64_t box[3]) {
+    const int64_t N[3] = {Z, Y, X}, K[3] = {pz, py, px};
+    box[0] = Z, box[1] = Y, box[2] = X;
+    if (use_fused_engine(Z, Y, X)) return BH_RL_ENGINE;
+    const char* be0 = getenv("BH_FFT_BACKEND");
+    if (!(be0 && strcmp(be0, "hipfft") == 0) && getenv("BH_FC_NORADIX3") == nullptr && fftconv_supported_ex(Z, Y, X, true))
+        return BH_RL_ENGINE;  // z and / or y of 3 * 2^k: the fused iteration as it is, radix-3 first step in the column passes
+    int64_t P[3], PE[3];
+    const bool nopad = getenv("BH_RL_NOPAD") != nullptr;
+    for (int a = 0; a < 3; ++a) P[a] = (nopad || is_smooth(N[a])) ? N[a] : next_smooth(N[a] + K[a] - 1);
+    // The fused engine at a power-of-two (or 3 * 2^k) box against hipFFT at the 7-smooth one: the engine moves a voxel of its
+    // box about 2.2x faster (10 passes at ~4.3 Gvox/s against the library path's ~1.9 Gvox/s), so it wins
+    // unless its box is more than twice as large.  BH_RL_ENGINE_PAD=0 / 1 forces the choice.
+    const char* force = getenv("BH_RL_ENGINE_PAD");
+    const char* be = getenv("BH_FFT_BACKEND");
+    const bool hipfft_forced = be != nullptr && strcmp(be, "hipfft") == 0;
+    if (!hipfft_forced && !nopad && !(force && force[0] == '0') && engine_pad_box(N, K, PE)) {
+        const double cost_engine = (double)PE[0] * PE[1] * PE[2] / 4.3, cost_lib = (double)P[0] * P[1] * P[2] / 1.9;
+        if ((force && force[0] == '1') || cost_engine < cost_lib) {
+            for (int a = 0; a < 3; ++a) box[a] = PE[a];
+            return BH_RL_ENGINE_PADDED;
+        }
+    }
+    for (int a = 0; a < 3; ++a) box[a] = P[a];
+    return BH_RL_LIBRARY;
 }
 
 }  // namespace bh
@@ -733,15 +778,6 @@ int bh_tikhonov(bh_ctx* ctx, const float* in, const float* tf_full, int64_t Z, i
     return BH_OK;
 }
 
-static bool is_smooth(int64_t n) {  // only the radices hipFFT has native kernels for
-    for (int p : {2, 3, 5, 7})
-        while (n % p == 0) n /= p;
-    return n == 1;
-}
-static int64_t next_smooth(int64_t n) {
-    while (!is_smooth(n)) ++n;
-    return n;
-}
 
 // Richardson-Lucy for a volume with an awkward axis (a large prime factor makes hipFFT fall back to Bluestein: the
 // deskewed (342, 1024, 1517) runs 10x slower per voxel than a power of two).  Awkward axes are zero-padded to the next
@@ -814,6 +850,14 @@ static int richardson_lucy_padfold(bh_ctx* ctx, const float* d, const float* psf
     return BH_OK;
 }
 
+int bh_richardson_lucy_plan(int64_t pz, int64_t py, int64_t px, int64_t Z, int64_t Y, int64_t X, int64_t box[3],
+                            int* backend) {
+    BH_REQUIRE(box != nullptr && backend != nullptr, "NULL argument");
+    BH_REQUIRE(pz > 0 && py > 0 && px > 0 && pz <= Z && py <= Y && px <= X, "PSF must fit inside the volume");
+    *backend = rl_plan(pz, py, px, Z, Y, X, box);
+    return BH_OK;
+}
+
 int bh_richardson_lucy(bh_ctx* ctx, const float* in, const float* psf, int64_t pz, int64_t py, int64_t px, int64_t Z,
                        int64_t Y, int64_t X, int iterations, float eps, float* out) {
     BH_REQUIRE(ctx && in && psf && out, "NULL argument");
@@ -829,28 +873,13 @@ int bh_richardson_lucy(bh_ctx* ctx, const float* in, const float* psf, int64_t p
         BH_CHECK_HIP(hipMemcpyAsync(dcopy, in, V * sizeof(float), hipMemcpyDeviceToDevice, s));
         d = dcopy;
     }
-    if (use_fused_engine(Z, Y, X)) return richardson_lucy_fused(ctx, d, psf, pz, py, px, Z, Y, X, iterations, eps, out);
-    {
-        const int64_t N[3] = {Z, Y, X}, K[3] = {pz, py, px};
-        int64_t P[3], PE[3];
-        bool padded = false;
-        for (int a = 0; a < 3; ++a) {
-            P[a] = is_smooth(N[a]) ? N[a] : next_smooth(N[a] + K[a] - 1);
-            padded = padded || P[a] != N[a];
-        }
-        // The fused engine at a power-of-two box against hipFFT at the 7-smooth one: the engine moves a voxel of its box
-        // about 2.2x faster (10 passes at ~4.3 Gvox/s against the library path's ~1.9 Gvox/s), so it wins
-        // unless its box is more than twice as large.  BH_RL_ENGINE_PAD=0 / 1 forces the choice.
-        const char* force = getenv("BH_RL_ENGINE_PAD");
-        const bool hipfft_forced = getenv("BH_FFT_BACKEND") != nullptr && strcmp(getenv("BH_FFT_BACKEND"), "hipfft") == 0;
-        if (!hipfft_forced && !(force && force[0] == '0') && engine_pad_box(N, K, PE)) {
-            const double cost_engine = (double)PE[0] * PE[1] * PE[2] / 4.3, cost_lib = (double)P[0] * P[1] * P[2] / 1.9;
-            if ((force && force[0] == '1') || cost_engine < cost_lib)
-                return richardson_lucy_engine_padded(ctx, d, psf, pz, py, px, Z, Y, X, PE, iterations, eps, out);
-        }
-        if (padded && getenv("BH_RL_NOPAD") == nullptr)
-            return richardson_lucy_padfold(ctx, d, psf, pz, py, px, Z, Y, X, P, iterations, eps, out);
-    }
+    int64_t box[3];
+    const int backend = rl_plan(pz, py, px, Z, Y, X, box);
+    if (backend == BH_RL_ENGINE) return richardson_lucy_fused(ctx, d, psf, pz, py, px, Z, Y, X, iterations, eps, out);
+    if (backend == BH_RL_ENGINE_PADDED)
+        return richardson_lucy_engine_padded(ctx, d, psf, pz, py, px, Z, Y, X, box, iterations, eps, out);
+    if (box[0] != Z || box[1] != Y || box[2] != X)
+        return richardson_lucy_padfold(ctx, d, psf, pz, py, px, Z, Y, X, box, iterations, eps, out);
     FftPlans* pl;
     BH_TRY(get_plans(ctx, Z, Y, X, &pl));
     cf *spec, *otf;

@@ -180,11 +180,12 @@ __device__ __forceinline__ void radix4_step(cf* buf, int N, int logW, int P, int
     }
 }
 
+// `rows` >= N: the buffer holds rows / N independent length-N sequences one after the other (see fft_lds)
 template <bool INV, int BPT, int CPT, int NT = FC_NT>
-__device__ __forceinline__ void radix2_step(cf* buf, int N, int logW, int P, const cf* t, int tid) {
+__device__ __forceinline__ void radix2_step(cf* buf, int N, int logW, int P, const cf* t, int tid, int rows) {
     const int h = N >> 1;
     const int lw = logW - (CPT == 2 ? 1 : 0);
-    const int total = h << lw;
+    const int total = (rows >> 1) << lw;
     const size_t hP = (size_t)h * P;
     constexpr int B2 = 2 * BPT;  // a radix-2 step has twice the butterflies of a radix-4 step
     const bool ragged = (total % (B2 * NT)) != 0;
@@ -196,8 +197,9 @@ __device__ __forceinline__ void radix2_step(cf* buf, int N, int logW, int P, con
     for (int k = 0; k < B2; ++k) {
         const int idx = min(g0 + tid + k * NT, total - 1);
         const int c = (idx & ((1 << lw) - 1)) * CPT;
-        const int j = idx >> lw;
-        pa[k] = buf + (size_t)j * P + c;
+        const int jj = idx >> lw;
+        const int j = jj & (h - 1);                 // butterfly within its sequence
+        pa[k] = buf + (size_t)(((jj - j) << 1) + j) * P + c;
         a[k] = CV<CPT>::ld(pa[k]);
         b[k] = CV<CPT>::ld(pa[k] + hP);
         w[k] = t[j];
@@ -290,12 +292,54 @@ __device__ __forceinline__ void radix16_step(cf* buf, int N, int logW, int P, in
     }
 }
 
+// Radix-3 step for a column of N = 3 L rows (L a power of two), two complex columns per thread.  Forward (decimation in
+// frequency): rows (m, m + L, m + 2L) -> the three length-L sequences y_k[m] = (x[m] + w3^k x[m+L] + w3^2k x[m+2L]) w_N^(k m),
+// left in rows [k L, (k + 1) L); their length-L transforms are X[3 j + k].  Inverse: the mirror image with conjugate
+// twiddles, unnormalised.  t3[2 m] = w_N^m, t3[2 m + 1] = w_N^2m.
+__device__ __forceinline__ CV<2> vscale2(const CV<2>& x, float f) {
+    return CV<2>{make_float2(x.a.x * f, x.a.y * f), make_float2(x.b.x * f, x.b.y * f)};
+}
+template <bool INV, int NT = FC_NT>
+__device__ __forceinline__ void radix3_step(cf* buf, int L, int logW, int P, const cf* t3, int tid) {
+    const int lw = logW - 1;
+    const int total = L << lw;
+    const size_t LP = (size_t)L * P;
+    const float S3 = 0.86602540378443865f;
+    for (int idx = tid; idx < total; idx += NT) {
+        const int c = (idx & ((1 << lw) - 1)) * 2;
+        const int m = idx >> lw;
+        cf* p0 = buf + (size_t)m * P + c;
+        const CV<2> a = CV<2>::ld(p0);
+        CV<2> b = CV<2>::ld(p0 + LP), cc = CV<2>::ld(p0 + 2 * LP);
+        const cf w1 = t3[2 * m], w2 = t3[2 * m + 1];
+        if (INV) {
+            b = vmulc<2>(b, w1);
+            cc = vmulc<2>(cc, w2);
+        }
+        const CV<2> sm = vadd<2>(b, cc), df = vsub<2>(b, cc);
+        const CV<2> base = vsub<2>(a, vscale2(sm, 0.5f));
+        const CV<2> rot = vscale2(INV ? vmul_pi<2>(df) : vmul_mi<2>(df), S3);
+        vadd<2>(a, sm).st(p0);
+        if (!INV) {
+            vmul<2>(vadd<2>(base, rot), w1).st(p0 + LP);
+            vmul<2>(vsub<2>(base, rot), w2).st(p0 + 2 * LP);
+        } else {
+            vadd<2>(base, rot).st(p0 + LP);
+            vsub<2>(base, rot).st(p0 + 2 * LP);
+        }
+    }
+}
+
 // R16: pair consecutive radix-4 steps into radix-16 steps (one column per thread); a leftover radix-4 step and
 // the radix-2 step of an odd log2(N) use <BPT, CPT>.
 // SKIP2: leave out the h = 2 radix-4 step (last forward / first inverse; its twiddles are all 1) — the convolution
 // passes run it fused with the spectral multiply in registers (conv_mid_step).
+// rows: total rows in the buffer when it holds several length-N sequences back to back (the thirds of a 3 * 2^k column
+// after radix3_step); every step then runs over all of them at once — the step functions take their butterfly count from
+// `rows` and their geometry from the half-size h.  0 = one sequence.
 template <bool INV, int BPT, int CPT, bool R16 = false, bool SKIP2 = false, int NT = FC_NT>
-__device__ __forceinline__ void fft_lds(cf* buf, int N, int logN, int logW, int P, const cf* tw, int tid) {
+__device__ __forceinline__ void fft_lds(cf* buf, int N, int logN, int logW, int P, const cf* tw, int tid, int rows = 0) {
+    if (rows == 0) rows = N;
     const bool odd = logN & 1;
     const int H0 = odd ? (N >> 2) : (N >> 1);
     const cf* t4 = tw + (odd ? (N >> 1) : 0);
@@ -303,31 +347,31 @@ __device__ __forceinline__ void fft_lds(cf* buf, int N, int logN, int logW, int 
     const int n16 = R16 ? (L4 >> 1) : 0;          // of which fused pairwise
     if (!INV) {
         if (odd) {
-            radix2_step<false, BPT, CPT, NT>(buf, N, logW, P, tw, tid);
+            radix2_step<false, BPT, CPT, NT>(buf, N, logW, P, tw, tid, rows);
             __syncthreads();
         }
         int h = H0;
         for (int s = 0; s < n16; ++s, h >>= 4) {
-            radix16_step<false, NT>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), t4 + (2 * H0 - 2 * (h >> 2)), tid);
+            radix16_step<false, NT>(buf, rows, logW, P, h, t4 + (2 * H0 - 2 * h), t4 + (2 * H0 - 2 * (h >> 2)), tid);
             __syncthreads();
         }
         for (; h >= (SKIP2 ? 8 : 2); h >>= 2) {
-            radix4_step<false, BPT, CPT, NT>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
+            radix4_step<false, BPT, CPT, NT>(buf, rows, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
             __syncthreads();
         }
     } else {
         const int hr = H0 >> (4 * n16);  // largest half-size left to plain radix-4 steps
         for (int h = SKIP2 ? 8 : 2; h <= hr; h <<= 2) {
-            radix4_step<true, BPT, CPT, NT>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
+            radix4_step<true, BPT, CPT, NT>(buf, rows, logW, P, h, t4 + (2 * H0 - 2 * h), tid);
             __syncthreads();
         }
         for (int s = n16 - 1; s >= 0; --s) {
             const int h = H0 >> (4 * s);
-            radix16_step<true, NT>(buf, N, logW, P, h, t4 + (2 * H0 - 2 * h), t4 + (2 * H0 - 2 * (h >> 2)), tid);
+            radix16_step<true, NT>(buf, rows, logW, P, h, t4 + (2 * H0 - 2 * h), t4 + (2 * H0 - 2 * (h >> 2)), tid);
             __syncthreads();
         }
         if (odd) {
-            radix2_step<true, BPT, CPT, NT>(buf, N, logW, P, tw, tid);
+            radix2_step<true, BPT, CPT, NT>(buf, N, logW, P, tw, tid, rows);
             __syncthreads();
         }
     }
@@ -386,7 +430,9 @@ struct ColParams {
     const cf* otf;
     const cf* tw;       // twiddles for length N
     int ntw;
-    int N, logN, W, logW;  // FFT length, tile width (complex columns)
+    int N, logN, W, logW;  // column length (rows of the tile), log2 of its power-of-two part L, tile width (complex columns)
+    int L;              // N (power of two) or N / 3: the radix-3 step splits a 3 * 2^k column into three length-L transforms
+    const cf* tw3;      // radix-3 twiddles (2 L entries) when L != N
     int XP;             // valid columns per row
     long row_stride;    // complex elements between consecutive n
     long outer_stride;  // base(o) = (o / nsub) * outer_stride + (o % nsub) * sub_stride
@@ -409,6 +455,28 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
     cf* tw = reinterpret_cast<cf*>(smem + (size_t)p.N * p.W * 8);  // twiddles
     const int tid = threadIdx.x;
     for (int i = tid; i < p.ntw; i += FC_NT) tw[i] = p.tw[i];
+    const int L_ = p.L;
+    const bool r3 = L_ != p.N;
+    cf* tw3 = tw + p.ntw;
+    if (r3)
+        for (int i = tid; i < 2 * L_; i += FC_NT) tw3[i] = p.tw3[i];
+    // column transform = [radix-3 step] + power-of-two transform of the 1 or 3 length-L sequences
+#define BH_FFT_FWD(...)                                                     \
+    {                                                                       \
+        if (r3) {                                                           \
+            radix3_step<false>(buf, L_, logW, W_, tw3, tid);                \
+            __syncthreads();                                                \
+        }                                                                   \
+        fft_lds<false, __VA_ARGS__>(buf, L_, logN, logW, W_, tw, tid, N_);  \
+    }
+#define BH_FFT_INV(...)                                                     \
+    {                                                                       \
+        fft_lds<true, __VA_ARGS__>(buf, L_, logN, logW, W_, tw, tid, N_);   \
+        if (r3) {                                                           \
+            radix3_step<true>(buf, L_, logW, W_, tw3, tid);                 \
+            __syncthreads();                                                \
+        }                                                                   \
+    }
 
     const int LPS = p.W >> 1;           // lanes per row segment (float4 = 2 complex)
     const int RPR = FC_NT / LPS;        // rows per round
@@ -519,7 +587,7 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
                 BH_LDM(0) BH_LDM(1) BH_LDM(2) BH_LDM(3) BH_LDM(4) BH_LDM(5) BH_LDM(6) BH_LDM(7)
 #undef BH_LDM
             }
-            fft_lds<false, 1, 2, false, true>(buf, N_, logN, logW, W_, tw, tid);
+            BH_FFT_FWD(1, 2, false, true)
 #define BH_SPEC_MUL(a, b)                                                                                          \
     (MODE == COL_FILTER ? make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w)                                  \
      : MODE == COL_CONV ? make_float4(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x, a.z * b.z - a.w * b.w,         \
@@ -560,26 +628,28 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
 #undef BH_SPEC_MUL
             __syncthreads();
             if (tn < ntiles) BH_LOAD_TILE(S, tn)
-            fft_lds<true, 1, 2, false, true>(buf, N_, logN, logW, W_, tw, tid);
+            BH_FFT_INV(1, 2, false, true)
         } else if (HAS_OTF) {
             // this tile's OTF arrives behind the forward FFT; the next tile's data behind the inverse FFT
             if (MODE == COL_FILTER) BH_LOAD_FILTER(t) else BH_LOAD_TILE(otf, t)
-            fft_lds<false, 1, 2, FC_R16>(buf, N_, logN, logW, W_, tw, tid);
+            BH_FFT_FWD(1, 2, FC_R16)
             BH_FOR8(BH_OTF_MUL)
             __syncthreads();
             if (tn < ntiles) BH_LOAD_TILE(S, tn)
-            fft_lds<true, 1, 2, FC_R16>(buf, N_, logN, logW, W_, tw, tid);
+            BH_FFT_INV(1, 2, FC_R16)
         } else {
             if (tn < ntiles) BH_LOAD_TILE(S, tn)  // prefetch the next tile behind the FFT
             if (MODE == COL_INV) {
-                fft_lds<true, 1, 2, FC_R16>(buf, N_, logN, logW, W_, tw, tid);
+                BH_FFT_INV(1, 2, FC_R16)
             } else {
-                fft_lds<false, 1, 2, FC_R16>(buf, N_, logN, logW, W_, tw, tid);
+                BH_FFT_FWD(1, 2, FC_R16)
             }
         }
         BH_FOR8(BH_STORE)  // LDS -> global
         __syncthreads();
     }
+#undef BH_FFT_FWD
+#undef BH_FFT_INV
 #undef BH_LD
 #undef BH_LDF
 #undef BH_LOAD_FILTER
@@ -933,6 +1003,8 @@ struct ConvPlan {
     cf *tw_x = nullptr, *tw_y = nullptr, *tw_z = nullptr, *untangle = nullptr, *twy = nullptr;
     int ntw_x = 0, ntw_y = 0, ntw_z = 0;
     int Wy = 0, Wz = 0;
+    int Lyh = 0, Lz = 0;                      // power-of-two part of Y/2 and Z (== them, or a third of them)
+    cf *tw3_y = nullptr, *tw3_z = nullptr;    // radix-3 twiddles where the axis is 3 * 2^k
 };
 
 static int ilog2(long v) {
@@ -941,17 +1013,25 @@ static int ilog2(long v) {
     return l;
 }
 
-bool fftconv_supported(int64_t Z, int64_t Y, int64_t X) {
+// Shapes the engine runs: X a power of two; Y and Z powers of two or — `radix3` — three times one (the column passes then
+// start with a radix-3 step).  Callers whose spectral arithmetic knows the scrambled coefficient order (Tikhonov's filter
+// staging) ask without `radix3`; order-agnostic ones (Richardson-Lucy at a padded box) may ask with it.
+bool fftconv_supported_ex(int64_t Z, int64_t Y, int64_t X, bool radix3) {
     auto pow2 = [](int64_t v) { return v > 0 && (v & (v - 1)) == 0; };
-    if (!pow2(Z) || !pow2(Y) || !pow2(X)) return false;
+    auto ok = [&](int64_t v) { return pow2(v) || (radix3 && v % 3 == 0 && pow2(v / 3)); };
+    if (!ok(Z) || !ok(Y) || !pow2(X)) return false;
     if (X < 64 || X > 2048) return false;          // M = X/2 in [32, 1024]: (M+1)*17*8 + tables <= 160 KiB
     if (Y < 2 * 16 || Y / 2 > 2048) return false;   // Y/2 rows x >= 8 columns per tile, whole groups of FC_XR rows
     if (Z < 4 || Z > 2048) return false;
     if ((Y % FC_XR) != 0) return false;
+    if (!pow2(Z) && Z < 24) return false;   // radix-3 columns: at least 3 x 8 rows
+    if (!pow2(Y) && Y < 96) return false;
     const int M = (int)X / 2;
     const size_t xlds = (size_t)(M + 1) * FC_XPITCH * 8 + (size_t)twiddle_count(M) * 8 + (size_t)M * 8;
     return xlds <= 160 * 1024;
 }
+
+bool fftconv_supported(int64_t Z, int64_t Y, int64_t X) { return fftconv_supported_ex(Z, Y, X, false); }
 
 static std::map<std::tuple<int, int64_t, int64_t, int64_t>, ConvPlan> g_plans;  // twiddle tables per (device, shape): a few KiB, never freed
 static std::mutex g_plans_mu;                                                    // contexts of different threads share the cache
@@ -976,19 +1056,34 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     pl.d.X = (int)X;
     pl.d.M = (int)X / 2;
     pl.d.XP = (int)X / 2 + 16;
+    auto pow2part = [](int64_t n) { return (int)((n & (n - 1)) == 0 ? n : n / 3); };
+    pl.Lyh = pow2part(Y / 2);
+    pl.Lz = pow2part(Z);
     pl.d.logM = ilog2(X / 2);
-    pl.d.logYh = ilog2(Y / 2);
-    pl.d.logZ = ilog2(Z);
+    pl.d.logYh = ilog2(pl.Lyh);
+    pl.d.logZ = ilog2(pl.Lz);
     std::vector<cf> h;
     make_twiddles(pl.d.M, h);
     pl.ntw_x = (int)h.size();
     BH_TRY(upload(h, &pl.tw_x));
-    make_twiddles((int)Y / 2, h);
+    make_twiddles(pl.Lyh, h);
     pl.ntw_y = (int)h.size();
     BH_TRY(upload(h, &pl.tw_y));
-    make_twiddles((int)Z, h);
+    make_twiddles(pl.Lz, h);
     pl.ntw_z = (int)h.size();
     BH_TRY(upload(h, &pl.tw_z));
+    auto radix3_twiddles = [&](int n, int L, cf** dptr) -> int {  // [w_n^m, w_n^2m], m < L = n / 3
+        if (L == n) return BH_OK;
+        h.resize(2 * (size_t)L);
+        for (int m = 0; m < L; ++m)
+            for (int k = 1; k <= 2; ++k) {
+                const double a = -2.0 * M_PI * (double)m * k / (double)n;
+                h[2 * m + k - 1] = make_float2((float)std::cos(a), (float)std::sin(a));
+            }
+        return upload(h, dptr);
+    };
+    BH_TRY(radix3_twiddles((int)Y / 2, pl.Lyh, &pl.tw3_y));
+    BH_TRY(radix3_twiddles((int)Z, pl.Lz, &pl.tw3_z));
     h.resize(pl.d.M);
     for (int pp = 0; pp < pl.d.M; ++pp) {
         int k = 0;
@@ -1005,7 +1100,8 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     }
     BH_TRY(upload(h, &pl.twy));
     auto tile_w = [&](int64_t N) {
-        int w = (int)(FC_TILE / N);
+        int w = 1;
+        while (2 * w * N <= FC_TILE) w *= 2;  // widest power-of-two tile of N rows in 128 KiB
         if (w > 64) w = 64;       // 512-B row segments are plenty
         if (w > pl.d.XP) w = 16;
         return w < 2 ? 2 : w;
@@ -1033,6 +1129,8 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
         p.W = pl.Wy;
         p.tw = pl.tw_y;
         p.ntw = pl.ntw_y;
+        p.L = pl.Lyh;
+        p.tw3 = pl.tw3_y;
         p.row_stride = pl.d.XP;
         p.outer_stride = (long)pl.d.Y * pl.d.XP;
         p.sub_stride = (long)(pl.d.Y / 2) * pl.d.XP;
@@ -1044,6 +1142,8 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
         p.W = pl.Wz;
         p.tw = pl.tw_z;
         p.ntw = pl.ntw_z;
+        p.L = pl.Lz;
+        p.tw3 = pl.tw3_z;
         p.row_stride = (long)pl.d.Y * pl.d.XP;
         p.outer_stride = pl.d.XP;
         p.sub_stride = 0;
@@ -1055,7 +1155,7 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
     p.ncoltiles = (int)ceil_div(pl.d.XP, p.W);
     BH_REQUIRE((long)p.N * p.W <= FC_TILE && (long)p.N * (p.W / 2) <= 16l * FC_NT && (FC_NT % (p.W / 2)) == 0,
                "internal: column tile %dx%d unsupported", p.N, p.W);
-    const size_t lds = (size_t)p.N * p.W * 8 + (size_t)p.ntw * 8;
+    const size_t lds = (size_t)p.N * p.W * 8 + (size_t)p.ntw * 8 + (p.L != p.N ? (size_t)2 * p.L * 8 : 0);
     const long ntiles = (long)p.nouter * p.ncoltiles;
     const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
     auto run = [&](auto kern) -> int {

@@ -111,6 +111,20 @@ def richardson_lucy(zyx, psf_zyx, iterations: int = 10, eps: float = 1e-6) -> to
     return out
 
 
+def richardson_lucy_plan(psf_shape_zyx, volume_shape_zyx) -> tuple[tuple[int, int, int], str]:
+    """(transform box, back-end) ``richardson_lucy`` uses for a shape — "engine" (fused FFT engine at the volume's shape),
+    "engine-padded" (the engine at a larger wrap-padded box) or "library" (hipFFT, 7-smooth pad-and-fold box if needed).
+    Host logic only (``bh_richardson_lucy_plan``): no GPU involved."""
+    import ctypes
+
+    lib = _lib.load()
+    box = (ctypes.c_int64 * 3)()
+    backend = ctypes.c_int()
+    _lib.check(lib.bh_richardson_lucy_plan(*(int(k) for k in psf_shape_zyx), *(int(n) for n in volume_shape_zyx), box,
+                                           ctypes.byref(backend)))
+    return tuple(int(b) for b in box), ("engine", "engine-padded", "library")[backend.value]
+
+
 def richardson_lucy_czyx(czyx_raw_data: np.ndarray, psf_zyx: np.ndarray, iterations: int = 10, eps: float = 1e-6,
                          device="cuda") -> np.ndarray:
     """CZYX numpy adapter with the reference's operator signature ``func(czyx, **kwargs)``."""

@@ -174,6 +174,15 @@ int bh_transfer_function(bh_ctx* ctx, const float* psf, int64_t pz, int64_t py, 
 int bh_tikhonov(bh_ctx* ctx, const float* in, const float* tf_full, int64_t Z, int64_t Y, int64_t X,
                 double regularization_strength, float* out);
 
+/* Host-only: the transform box and back-end bh_richardson_lucy picks for a shape.  BH_RL_ENGINE: the fused FFT engine at
+ * the volume's own (power-of-two) shape; BH_RL_ENGINE_PADDED: the engine at a larger box (axes of 2^k or, for z and y,
+ * 3 * 2^k) that carries the volume wrap-extended by K - 1; BH_RL_LIBRARY: hipFFT at the shape itself or, for axes with a
+ * prime factor above 7, at a 7-smooth pad-and-fold box.  All three compute the circular Richardson-Lucy at size (Z,Y,X). */
+#define BH_RL_ENGINE 0
+#define BH_RL_ENGINE_PADDED 1
+#define BH_RL_LIBRARY 2
+int bh_richardson_lucy_plan(int64_t pz, int64_t py, int64_t px, int64_t Z, int64_t Y, int64_t X, int64_t box[3],
+                            int* backend);
 /* Richardson-Lucy with circular (FFT) boundary; psf is normalised to unit sum on device.
  * e0 = max(in,0); e <- max(e * corr(d / max(conv(e), eps)), 0).  in/out float32, may alias. */
 int bh_richardson_lucy(bh_ctx* ctx, const float* in, const float* psf, int64_t pz, int64_t py,

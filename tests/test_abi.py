@@ -144,3 +144,24 @@ def test_invalid_arguments_return_status_not_crash(lib_built):
     nb = I64x3()
     assert lib.bh_block_peaks(None, None, 24, 40, 36, 3, Ix3(8, 8, 8), None, None, nb) == _lib.BH_OK
     assert tuple(nb) == (4, 6, 5)  # torch: floor((N + 2*(b//2) - b) / b) + 1
+
+
+def test_richardson_lucy_plan_boxes(monkeypatch):
+    """The back-end choice is host logic (bh_richardson_lucy_plan): power-of-two and 3 * 2^k shapes run the fused engine as
+    they are, awkward ones at a wrap-padded box when that is cheaper than the 7-smooth library box."""
+    from biahub_amd.deconvolve import richardson_lucy_plan as plan
+
+    assert plan((33, 17, 17), (512, 2048, 2048)) == ((512, 2048, 2048), "engine")
+    assert plan((33, 17, 17), (384, 1024, 1024)) == ((384, 1024, 1024), "engine")
+    assert plan((33, 17, 17), (342, 1024, 1517)) == ((512, 1024, 2048), "engine-padded")       # 342 + 2 * 32 > 384
+    assert plan((33, 17, 17), (384, 1024, 1536)) == ((384, 1024, 2048), "engine-padded")       # x cannot be 3 * 2^k
+    assert plan((33, 17, 17), (1068, 256, 1664)) == ((1536, 256, 2048), "engine-padded")       # a mantis position
+    assert plan((33, 17, 17), (683, 2048, 3034)) == ((720, 2048, 3072), "library")             # x beyond the engine's 2048
+    assert plan((5, 5, 5), (15, 42, 50)) == ((15, 42, 50), "library")                          # 7-smooth and small
+    monkeypatch.setenv("BH_RL_ENGINE_PAD", "0")
+    assert plan((33, 17, 17), (342, 1024, 1517)) == ((375, 1024, 1536), "library")
+    monkeypatch.setenv("BH_RL_ENGINE_PAD", "1")
+    assert plan((7, 5, 9), (21, 64, 150)) == ((48, 64, 256), "engine-padded")
+    assert plan((9, 9, 3), (40, 70, 64)) == ((64, 96, 64), "engine-padded")
+    with pytest.raises(ValueError):
+        plan((9, 9, 9), (4, 64, 64))

@@ -186,8 +186,10 @@ def test_richardson_lucy_vs_oracle(gpu, shape, pshape):
     ((37, 53, 71), (4, 6, 8)),      # even PSF extents: the kernel reaches further below 0 than above N-1
     ((32, 53, 64), (9, 7, 5)),      # only Y is awkward; Z and X wrap on their own
     ((19, 40, 134), (5, 3, 11)),    # 134 = 2 * 67
-    ((21, 64, 150), (7, 5, 9)),     # Y a power of two the engine keeps as it is, Z and X wrap-padded to 64 and 256
-    ((40, 70, 64), (9, 9, 3)),      # X stays, Z -> 64, Y -> 128
+    ((21, 64, 150), (7, 5, 9)),     # Y a power of two the engine keeps as it is; Z -> 48 = 3 * 16 (radix-3 columns), X -> 256
+    ((40, 70, 64), (9, 9, 3)),      # X stays, Z -> 64, Y -> 96 = 3 * 32 (radix-3 columns of 3 * 16)
+    ((80, 150, 64), (5, 5, 5)),     # Z -> 96 (odd log2 of the power-of-two part), Y -> 192
+    ((170, 64, 64), (9, 3, 3)),     # Z -> 192 = 3 * 64
 ])
 def test_richardson_lucy_awkward_sizes_pad_fold(gpu, shape, pshape, monkeypatch):
     """Axes with a large prime factor are zero-padded to a 7-smooth FFT size and the wrapped part of the linear
@@ -215,6 +217,28 @@ def test_richardson_lucy_awkward_sizes_pad_fold(gpu, shape, pshape, monkeypatch)
     eng = richardson_lucy(v, pt, 6, 1e-6).cpu().numpy()
     assert rel_err(eng, want) <= FFT_TOL, rel_err(eng, want)
     assert np.array_equal(richardson_lucy(v, pt, 0, 1e-6).cpu().numpy(), np.maximum(vol, 0))
+
+
+@pytest.mark.parametrize("shape,pshape", [((48, 96, 64), (5, 7, 3)), ((24, 32, 128), (3, 3, 9)), ((64, 192, 64), (9, 5, 5)),
+                                          ((96, 64, 256), (7, 3, 3))])
+def test_richardson_lucy_radix3_columns_fused(gpu, shape, pshape, monkeypatch):
+    """z and / or y of 3 * 2^k: the fused 8-pass iteration runs at the volume's own shape, the column passes starting with a
+    radix-3 step (csrc/fftconv.hip radix3_step); oracle parity and agreement with the library-FFT path."""
+    from biahub_amd.deconvolve import richardson_lucy, richardson_lucy_plan
+
+    assert richardson_lucy_plan(pshape, shape) == (shape, "engine")
+    vol = O.synthetic_volume(shape, seed=12, n_blobs=10)
+    vol[0, :, 0] += 400.0
+    psf = O.gaussian_psf(pshape, tuple(max(p / 4.0, 0.8) for p in pshape))
+    psf[0, 0, 0] += 0.02
+    want = O.richardson_lucy_zyx(vol, psf, iterations=5, eps=1e-6)
+    v, pt = torch.from_numpy(vol).to(gpu), torch.from_numpy(psf).to(gpu)
+    got = richardson_lucy(v, pt, 5, 1e-6).cpu().numpy()
+    assert rel_err(got, want) <= FFT_TOL, rel_err(got, want)
+    monkeypatch.setenv("BH_FFT_BACKEND", "hipfft")
+    assert richardson_lucy_plan(pshape, shape) == (shape, "library")
+    lib = richardson_lucy(v, pt, 5, 1e-6).cpu().numpy()
+    assert rel_err(got, lib) <= FFT_TOL
 
 
 # ----------------------------------------------------------------------------- affine

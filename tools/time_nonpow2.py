@@ -12,10 +12,11 @@ def gaussian_psf(shape, sigma):
     p = g[0][:, None, None] * g[1][None, :, None] * g[2][None, None, :]
     return (p / p.sum()).float()
 psf = gaussian_psf((33, 17, 17), (3, 1.5, 1.5))
-for shape in ((342, 1024, 1517), (256, 1024, 1024), (384, 1024, 1536)):
+for shape in ((342, 1024, 1517), (256, 1024, 1024), (384, 1024, 1536), (384, 1024, 1024), (1068, 256, 1664)):
     V = np.prod(shape)
     vol = torch.rand(shape, device=dev) * 100
     import os
+    from biahub_amd.deconvolve import richardson_lucy_plan
     res = {}
     for force, name in (("0", "library FFT, 7-smooth pad-and-fold"), ("1", "fused engine, wrap-padded power-of-two box"), (None, "default")):
         if force is None:
@@ -31,7 +32,7 @@ for shape in ((342, 1024, 1517), (256, 1024, 1024), (384, 1024, 1536)):
             print(f"RL x10 {shape} [{name}]: {type(e).__name__}: {e}", flush=True)
             continue
         res[name] = out.clone()
-        print(f"RL x10 {shape} [{name}]: {dt*1e3:.1f} ms -> {V/dt/1e9:.2f} Gvox/s", flush=True)
+        print(f"RL x10 {shape} [{name}] plan {richardson_lucy_plan(psf.shape, shape)}: {dt*1e3:.1f} ms -> {V/dt/1e9:.2f} Gvox/s", flush=True)
         ctx.release_workspace()
     ks = list(res)
     if len(ks) >= 2:
