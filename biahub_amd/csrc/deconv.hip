@@ -395,6 +395,12 @@ static bool use_fused_engine(int64_t Z, int64_t Y, int64_t X) {
         if (strcmp(e, "hipfft") == 0) return false;
     return fftconv_supported(Z, Y, X);
 }
+// callers whose spectral arithmetic treats every coefficient alike may also take z / y of 3 * 2^k (radix-3 column passes)
+static bool use_fused_engine_any_order(int64_t Z, int64_t Y, int64_t X) {
+    if (const char* e = getenv("BH_FFT_BACKEND"))
+        if (strcmp(e, "hipfft") == 0) return false;
+    return fftconv_supported_ex(Z, Y, X, getenv("BH_FC_NORADIX3") == nullptr);
+}
 
 // order-sensitive 64-bit content hash of a small device array (one block; the PSF is a few thousand floats)
 __global__ __launch_bounds__(256) void content_hash_kernel(const uint32_t* __restrict__ data, int64_t n,
@@ -619,10 +625,7 @@ static int richardson_lucy_engine_padded(bh_ctx* ctx, const float* d, const floa
 static int rl_plan(int64_t pz, int64_t py, int64_t px, int64_t Z, int64_t Y, int64_t X, int64_t box[3]) {
     const int64_t N[3] = {Z, Y, X}, K[3] = {pz, py, px};
     box[0] = Z, box[1] = Y, box[2] = X;
-    if (use_fused_engine(Z, Y, X)) return BH_RL_ENGINE;
-    const char* be0 = getenv("BH_FFT_BACKEND");
-    if (!(be0 && strcmp(be0, "hipfft") == 0) && getenv("BH_FC_NORADIX3") == nullptr && fftconv_supported_ex(Z, Y, X, true))
-        return BH_RL_ENGINE;  // z and / or y of 3 * 2^k: the fused iteration as it is, radix-3 first step in the column passes
+    if (use_fused_engine_any_order(Z, Y, X)) return BH_RL_ENGINE;  // z / y of 3 * 2^k: radix-3 first step in the column passes
     int64_t P[3], PE[3];
     const bool nopad = getenv("BH_RL_NOPAD") != nullptr;
     for (int a = 0; a < 3; ++a) P[a] = (nopad || is_smooth(N[a])) ? N[a] : next_smooth(N[a] + K[a] - 1);
@@ -705,8 +708,9 @@ int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t
     BH_TRY(get_scratch(ctx, "pcc_partial", (nblk + 1) * sizeof(ArgMax), (void**)&partial));
     result = partial + nblk;
     hipStream_t s = ctx->stream;
-    if (use_fused_engine(Z, Y, X)) {
-        // power-of-two volume: six in-place passes each way on the fused engine instead of hipFFT's transposing pipeline
+    if (use_fused_engine_any_order(Z, Y, X)) {
+        // power-of-two (z, y also 3 * 2^k) volume: six in-place passes each way on the fused engine instead of hipFFT's
+        // transposing pipeline; the normalised product treats every coefficient alike, so their order does not matter
         ConvPlan* cp;
         BH_TRY(fftconv_plan(ctx, Z, Y, X, &cp));
         const size_t NSf = fftconv_spectrum_elems(*cp);
@@ -754,7 +758,7 @@ int bh_tikhonov(bh_ctx* ctx, const float* in, const float* tf_full, int64_t Z, i
     BH_REQUIRE(Z > 0 && Y > 0 && X > 0, "invalid shape");
     BH_CHECK_HIP(hipSetDevice(ctx->device));
     ScopedTimer timer(ctx, T_TIKHONOV);
-    if (use_fused_engine(Z, Y, X)) {
+    if (use_fused_engine_any_order(Z, Y, X)) {
         ConvPlan* cp;
         BH_TRY(fftconv_plan(ctx, Z, Y, X, &cp));
         const size_t NSf = fftconv_spectrum_elems(*cp);

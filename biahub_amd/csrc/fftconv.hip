@@ -417,7 +417,8 @@ struct ConvDims {
     int Z, Y, X;   // real volume
     int M;         // X / 2 (complex FFT length along x)
     int XP;        // spectrum row pitch in complex elements
-    int logM, logYh, logZ;
+    int logM, logYh, logZ;  // log2 of M and of the power-of-two parts of Y/2 and Z
+    int Lyh, Lz;            // those parts: Y/2 and Z themselves, or a third of them (radix-3 column passes)
 };
 
 // ================================================================================================
@@ -1062,6 +1063,8 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     pl.d.logM = ilog2(X / 2);
     pl.d.logYh = ilog2(pl.Lyh);
     pl.d.logZ = ilog2(pl.Lz);
+    pl.d.Lyh = pl.Lyh;
+    pl.d.Lz = pl.Lz;
     std::vector<cf> h;
     make_twiddles(pl.d.M, h);
     pl.ntw_x = (int)h.size();
@@ -1255,9 +1258,14 @@ __global__ __launch_bounds__(256) void tikhonov_filter_rows_kernel(const float* 
     const int Yh = d.Y / 2;
     for (long row = blockIdx.x; row < (long)d.Z * d.Y; row += gridDim.x) {
         const int zs = (int)(row / d.Y), ys = (int)(row - (long)zs * d.Y);
-        const int kz = (int)(__brev((unsigned)zs) >> (32 - d.logZ));
+        // stored position -> frequency: a 3 * 2^k column holds X[3 j + t] in third t at the bit-reversed j
+        const int tz = zs / d.Lz, rz = zs - tz * d.Lz;
+        const int jz = (int)(__brev((unsigned)rz) >> (32 - d.logZ));
+        const int kz = d.Lz == d.Z ? jz : 3 * jz + tz;
         const int half = ys / Yh, r = ys - half * Yh;
-        const int ky = 2 * (int)(__brev((unsigned)r) >> (32 - d.logYh)) + half;
+        const int ty = r / d.Lyh, ry = r - ty * d.Lyh;
+        const int jy = (int)(__brev((unsigned)ry) >> (32 - d.logYh));
+        const int ky = 2 * (d.Lyh == Yh ? jy : 3 * jy + ty) + half;
         const float* src = tf + ((long)kz * d.Y + ky) * d.X;
         for (int kx = threadIdx.x; kx < d.XP; kx += 256) {
             float f = 0.0f;

@@ -421,7 +421,8 @@ def test_richardson_lucy_fused_engine_vs_oracle(gpu, shape, pshape, monkeypatch)
     assert rel_err(got, got_hipfft) <= FFT_TOL
 
 
-@pytest.mark.parametrize("shape", [(16, 32, 64), (8, 64, 128), (32, 128, 256), (128, 32, 1024)])
+@pytest.mark.parametrize("shape", [(16, 32, 64), (8, 64, 128), (32, 128, 256), (128, 32, 1024),
+                                   (48, 96, 64), (24, 64, 128), (64, 192, 64)])   # the last three: radix-3 columns
 def test_tikhonov_fused_engine_vs_oracle(gpu, shape, monkeypatch):
     from biahub_amd.deconvolve import compute_tranfser_function, deconvolve
 
@@ -526,6 +527,15 @@ def test_phase_cross_corr_golden_and_oracle(gpu):
         for norm in (None, "magnitude", "classic"):
             want, wcorr = O.phase_cross_corr(big, mov, norm)
             got, corr = phase_cross_corr(big, mov, normalization=norm)
+            assert np.array_equal(got, want), (roll, norm, got, want)
+            assert rel_err(corr, wcorr) <= FFT_TOL, (roll, norm)
+    # z / y of 3 * 2^k: the engine's column passes start with a radix-3 step; the coefficient order changes, the answers do not
+    r3 = rng.random((48, 96, 64), dtype=np.float32)
+    for roll in ((0, 0, 0), (7, -40, 21), (-24, 48, -32)):
+        mov = np.roll(r3, roll, axis=(0, 1, 2)) + 0.05 * rng.random(r3.shape, dtype=np.float32)
+        for norm in (None, "magnitude", "classic"):
+            want, wcorr = O.phase_cross_corr(r3, mov, norm)
+            got, corr = phase_cross_corr(r3, mov, normalization=norm)
             assert np.array_equal(got, want), (roll, norm, got, want)
             assert rel_err(corr, wcorr) <= FFT_TOL, (roll, norm)
     with pytest.raises(ValueError):
