@@ -89,6 +89,7 @@ struct bh_ctx {
     std::map<std::tuple<int64_t, int64_t, int64_t>, bh::FftPlans> plans;
     std::map<std::string, bh::Scratch> scratch;
     int num_cus = 256;
+    int plans_replaced = 0;  // 3-D library plans that failed their self-check and were rebuilt decomposed (context.hip)
     // Richardson-Lucy OTF cache: the OTF in "fc_otf" belongs to the PSF with this content hash / these shapes
     bool otf_valid = false;
     unsigned long long otf_hash = 0;

@@ -30,18 +30,43 @@ int get_scratch(bh_ctx* ctx, const char* name, size_t bytes, void** out) {
     return BH_OK;
 }
 
-int get_plans(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, FftPlans** out) {
-    auto key = std::make_tuple(Z, Y, X);
-    auto it = ctx->plans.find(key);
-    if (it != ctx->plans.end()) {
-        *out = &it->second;
-        return BH_OK;
+// ---- plan self-check ---------------------------------------------------------------------------------------------
+// rocFFT 1.0.36 (ROCm 7.2) can hand back a 3-D real plan that computes garbage, depending on which other plans the process
+// created before (tools/hipfft_two_plans.cpp, tools/hipfft_plan3d_sweep.cpp).  Such a plan is wrong from its
+// first execution on and stays wrong; a plan that passes stays right.  So every library plan runs one round trip on
+// pseudo-random data when it is created; a 3-D plan that fails is replaced by the decomposed one, which is checked too.
+__device__ __forceinline__ float check_value(int64_t i) {
+    unsigned h = (unsigned)i * 2654435761u + (unsigned)(i >> 32) * 40503u;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+__global__ void check_fill_kernel(float* x, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = check_value(i);
+}
+__global__ void check_compare_kernel(const float* x, int64_t n, float inv_n, unsigned* worst) {
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float e = fabsf(x[i] * inv_n - check_value(i));
+        m = fmaxf(m, e == e ? e : 1e30f);  // a NaN counts as a failure
     }
-    BH_REQUIRE(Z > 0 && Y > 0 && X > 0 && Z < (1ll << 31) && Y < (1ll << 31) && X < (1ll << 31),
-               "invalid FFT shape (%lld,%lld,%lld)", (long long)Z, (long long)Y, (long long)X);
-    FftPlans p;
-    auto pow2 = [](int64_t n) { return (n & (n - 1)) == 0; };
-    p.separable = getenv("BH_FFT_SEPARABLE") != nullptr || (pow2(Z) && pow2(Y) && pow2(X));
+    atomicMax(worst, __float_as_uint(m));  // non-negative floats order like their bit patterns
+}
+
+static void destroy_handles(FftPlans& p) {
+    for (hipfftHandle* h : {&p.r2c, &p.c2r, &p.xr, &p.xi, &p.zy})
+        if (*h) {
+            hipfftDestroy(*h);
+            *h = 0;
+        }
+    if (p.work) (void)hipFree(p.work);
+    p.work = nullptr;
+    p.work_bytes = 0;
+}
+
+static int make_handles(bh_ctx* ctx, FftPlans& p, int64_t Z, int64_t Y, int64_t X) {
     hipfftHandle* hs[3] = {&p.r2c, &p.c2r, nullptr};
     size_t ws[3] = {0, 0, 0};
     int nh = 2;
@@ -71,6 +96,65 @@ int get_plans(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, FftPlans** out) {
     for (int i = 0; i < nh; ++i) {
         if (p.work_bytes) BH_CHECK_FFT(hipfftSetWorkArea(*hs[i], p.work));
         BH_CHECK_FFT(hipfftSetStream(*hs[i], ctx->stream));
+    }
+    return BH_OK;
+}
+
+// round trip on the context's own scratch (the buffers the caller is about to use at this size anyway)
+static int plan_round_trip_error(bh_ctx* ctx, const FftPlans& p, int64_t Z, int64_t Y, int64_t X, float* err) {
+    const int64_t V = Z * Y * X, NS = Z * Y * (X / 2 + 1);
+    float* real;
+    float2* spec;
+    unsigned* worst;
+    BH_TRY(get_scratch(ctx, "fft_real", V * sizeof(float), (void**)&real));
+    BH_TRY(get_scratch(ctx, "fft_spec", NS * sizeof(float2), (void**)&spec));
+    BH_TRY(get_scratch(ctx, "plan_check", 64, (void**)&worst));
+    hipStream_t s = ctx->stream;
+    const int grid = (int)std::min<int64_t>(ceil_div(V, 256), (int64_t)ctx->num_cus * 16);
+    BH_CHECK_HIP(hipMemsetAsync(worst, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(check_fill_kernel, dim3(grid), dim3(256), 0, s, real, V);
+    BH_TRY(fft_forward(&p, real, spec));
+    BH_TRY(fft_inverse(&p, spec, real));
+    hipLaunchKernelGGL(check_compare_kernel, dim3(grid), dim3(256), 0, s, (const float*)real, V, (float)(1.0 / (double)V), worst);
+    BH_CHECK_HIP(hipGetLastError());
+    unsigned bits = 0;
+    BH_CHECK_HIP(hipMemcpyAsync(&bits, worst, sizeof(bits), hipMemcpyDeviceToHost, s));
+    BH_CHECK_HIP(hipStreamSynchronize(s));
+    memcpy(err, &bits, sizeof(float));
+    return BH_OK;
+}
+
+int get_plans(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, FftPlans** out) {
+    auto key = std::make_tuple(Z, Y, X);
+    auto it = ctx->plans.find(key);
+    if (it != ctx->plans.end()) {
+        *out = &it->second;
+        return BH_OK;
+    }
+    BH_REQUIRE(Z > 0 && Y > 0 && X > 0 && Z < (1ll << 31) && Y < (1ll << 31) && X < (1ll << 31),
+               "invalid FFT shape (%lld,%lld,%lld)", (long long)Z, (long long)Y, (long long)X);
+    FftPlans p;
+    auto pow2 = [](int64_t n) { return (n & (n - 1)) == 0; };
+    p.separable = getenv("BH_FFT_SEPARABLE") != nullptr || (pow2(Z) && pow2(Y) && pow2(X));
+    const bool check = getenv("BH_FFT_NOCHECK") == nullptr;
+    const float tol = 1e-3f;  // a sound float32 round trip of values in [0, 1) errs by ~1e-6; a bad plan by ~1
+    float err = 0.0f;
+    BH_TRY(make_handles(ctx, p, Z, Y, X));
+    if (check) {
+        BH_TRY(plan_round_trip_error(ctx, p, Z, Y, X, &err));
+        if (!(err < tol) && !p.separable) {
+            destroy_handles(p);
+            p.separable = true;
+            BH_TRY(make_handles(ctx, p, Z, Y, X));
+            BH_TRY(plan_round_trip_error(ctx, p, Z, Y, X, &err));
+            ++ctx->plans_replaced;
+        }
+        if (!(err < tol)) {
+            destroy_handles(p);
+            set_error("hipFFT plan for (%lld,%lld,%lld) fails its round-trip self-check (error %g): the FFT library is "
+                      "returning wrong transforms", (long long)Z, (long long)Y, (long long)X, (double)err);
+            return BH_ERR_HIP;
+        }
     }
     auto ins = ctx->plans.emplace(key, p);
     *out = &ins.first->second;
@@ -150,6 +234,12 @@ int bh_ctx_workspace_bytes(bh_ctx* ctx, uint64_t* bytes) {
     for (auto& kv : ctx->plans) b += kv.second.work_bytes;
     for (auto& kv : ctx->scratch) b += kv.second.bytes;
     *bytes = b;
+    return BH_OK;
+}
+
+int bh_ctx_fft_plans_replaced(bh_ctx* ctx, int* count) {
+    BH_REQUIRE(ctx != nullptr && count != nullptr, "NULL argument");
+    *count = ctx->plans_replaced;
     return BH_OK;
 }
 

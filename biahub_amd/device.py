@@ -81,6 +81,14 @@ class Context:
     def release_workspace(self):
         _lib.check(self.lib.bh_ctx_release_workspace(self.handle))
 
+    def fft_plans_replaced(self) -> int:
+        """hipFFT 3-D plans that failed their creation-time round trip and were rebuilt decomposed."""
+        import ctypes
+
+        n = ctypes.c_int()
+        _lib.check(self.lib.bh_ctx_fft_plans_replaced(self.handle, ctypes.byref(n)))
+        return n.value
+
 
 def get_context(device) -> Context:
     dev = resolve_device(device)

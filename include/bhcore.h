@@ -99,6 +99,10 @@ int bh_ctx_set_stream(bh_ctx* ctx, void* hip_stream);
 int bh_ctx_synchronize(bh_ctx* ctx);
 int bh_ctx_release_workspace(bh_ctx* ctx); /* frees cached plans + scratch             */
 int bh_ctx_workspace_bytes(bh_ctx* ctx, uint64_t* bytes);
+/* Every hipFFT plan runs a round trip on pseudo-random data when it is created (rocFFT 1.0.36 can return 3-D real plans
+ * that compute garbage, depending on the plans created before); a 3-D plan that fails is rebuilt as batched 1-D + strided
+ * 2-D transforms, which are checked too (BH_ERR_HIP if those fail as well).  count = plans rebuilt so far in this context. */
+int bh_ctx_fft_plans_replaced(bh_ctx* ctx, int* count);
 
 /* device-memory helpers for hosts that do not bring their own allocator */
 int bh_malloc(void** dptr, uint64_t bytes);

@@ -39,6 +39,43 @@ def test_fuzz_fused_engine_vs_oracle(gpu):
         assert np.array_equal(sh, wsh) and rel_err(corr.cpu().numpy(), wcorr) <= 1e-4, ((Z, Y, X), roll)
 
 
+def test_fuzz_richardson_lucy_backends_vs_oracle(gpu, monkeypatch):
+    """Random shapes (awkward, 7-smooth, 3 * 2^k, powers of two) and PSF extents: whatever back-end the cost model picks, and
+    the wrap-padded engine box and the library box when forced, all give the oracle's circular Richardson-Lucy."""
+    from biahub_amd.deconvolve import richardson_lucy, richardson_lucy_plan
+
+    rng = np.random.default_rng(2024)
+    pools = ([11, 13, 17, 19, 23, 29, 31, 37, 41, 53], [15, 21, 28, 30, 36, 42, 45, 50, 60], [24, 48, 96], [16, 32, 64])
+    seen = set()
+    for trial in range(18):
+        dims = []
+        for a in range(3):
+            pool = pools[int(rng.integers(0, 4))]
+            n = int(pool[int(rng.integers(0, len(pool)))])
+            dims.append(n * (2 if a == 1 else 1) * (2 if a == 2 and n < 40 else 1))  # y >= 22, x a little longer
+        shape = tuple(dims) if trial < 16 else ((24, 64, 64), (32, 96, 128))[trial - 16]  # two the engine takes as they are
+        pshape = tuple(int(min(rng.integers(1, 8), n // 2)) for n in shape)
+        volh = (rng.random(shape) * 300).astype(np.float32)
+        volh[0, :, -1] += 500.0
+        psfh = (rng.random(pshape) + 0.05).astype(np.float32)
+        want = O.richardson_lucy_zyx(volh, psfh, iterations=3, eps=1e-6)
+        vol, psf = torch.from_numpy(volh).to(gpu), torch.from_numpy(psfh).to(gpu)
+        for force in (None, "1", "0"):
+            if force is None:
+                monkeypatch.delenv("BH_RL_ENGINE_PAD", raising=False)
+            else:
+                monkeypatch.setenv("BH_RL_ENGINE_PAD", force)
+            box, backend = richardson_lucy_plan(pshape, shape)
+            seen.add(backend)
+            got = richardson_lucy(vol, psf, 3, 1e-6).cpu().numpy()
+            assert rel_err(got, want) <= 1e-4, (shape, pshape, force, box, backend, rel_err(got, want))
+    assert seen == {"engine", "engine-padded", "library"}
+    from biahub_amd.device import get_context
+
+    # informational: how many 3-D library plans the creation-time self-check had to rebuild in this process
+    print("hipFFT plans rebuilt after a failed self-check:", get_context(gpu).fft_plans_replaced())
+
+
 def test_fuzz_deskew_flatfield_affine_vs_oracle(gpu):
     from biahub_amd.deskew import fast_deskew_zyx
     from biahub_amd.flat_field import flat_field_zyx, median_z_device
