@@ -298,6 +298,56 @@ __global__ __launch_bounds__(256) void remap_kernel(const float* __restrict__ sr
     }
 }
 
+// Update step of the padded engine path.  corr: linear correlation of the zero-padded ratio on the box P (volume voxel n at
+// n + off); est_old / est_new: the estimate on the same box, wrap-extended by lo below and hi above the volume.  Every box
+// voxel inside the extended volume gets  max(est_old[n] * fold(corr)[n], 0)  for the volume voxel n it stands for — fold
+// adds the tails the linear correlation left below 0 and above N - 1 (n + N when n < hi, n - N when n >= N - lo; both
+// inside the box because P >= N + lo + hi) — everything else 0.
+struct FoldBox {
+    int64_t P[3];
+    int N[3], off[3], lo[3], hi[3];
+};
+
+__global__ __launch_bounds__(256) void fold_update_rewrap_kernel(const float* __restrict__ corr, const float* __restrict__ est_old,
+                                                                 float* __restrict__ est_new, FoldBox f) {
+    const int64_t rows = f.P[0] * f.P[1];
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int y = (int)(row % f.P[1]), z = (int)(row / f.P[1]);
+        int qz = z - f.off[0], qy = y - f.off[1];
+        const bool in_zy = qz >= -f.lo[0] && qz < f.N[0] + f.hi[0] && qy >= -f.lo[1] && qy < f.N[1] + f.hi[1];
+        qz += qz < 0 ? f.N[0] : (qz >= f.N[0] ? -f.N[0] : 0);
+        qy += qy < 0 ? f.N[1] : (qy >= f.N[1] ? -f.N[1] : 0);
+        // fold taps along z and y: the voxel itself and at most one wrapped tail (lo + hi < N)
+        int tz[2] = {qz + f.off[0], 0}, ty[2] = {qy + f.off[1], 0};
+        int nz = 1, ny = 1;
+        if (qz < f.hi[0]) tz[nz++] = qz + f.N[0] + f.off[0];
+        else if (qz >= f.N[0] - f.lo[0]) tz[nz++] = qz - f.N[0] + f.off[0];
+        if (qy < f.hi[1]) ty[ny++] = qy + f.N[1] + f.off[1];
+        else if (qy >= f.N[1] - f.lo[1]) ty[ny++] = qy - f.N[1] + f.off[1];
+        const float* erow = est_old + ((int64_t)tz[0] * f.P[1] + ty[0]) * f.P[2] + f.off[2];
+        float* drow = est_new + row * f.P[2];
+        for (int x = blockIdx.x * 256 + threadIdx.x; x < f.P[2]; x += gridDim.x * 256) {
+            int qx = x - f.off[2];
+            float v = 0.0f;
+            if (in_zy && qx >= -f.lo[2] && qx < f.N[2] + f.hi[2]) {
+                qx += qx < 0 ? f.N[2] : (qx >= f.N[2] ? -f.N[2] : 0);
+                int tx[2] = {qx + f.off[2], 0};
+                int nx = 1;
+                if (qx < f.hi[2]) tx[nx++] = qx + f.N[2] + f.off[2];
+                else if (qx >= f.N[2] - f.lo[2]) tx[nx++] = qx - f.N[2] + f.off[2];
+                float acc = 0.0f;
+                for (int a = 0; a < nz; ++a)
+                    for (int b = 0; b < ny; ++b) {
+                        const float* crow = corr + ((int64_t)tz[a] * f.P[1] + ty[b]) * f.P[2];
+                        for (int c = 0; c < nx; ++c) acc += crow[tx[c]];
+                    }
+                v = fmaxf(erow[qx] * acc, 0.0f);
+            }
+            drow[x] = v;
+        }
+    }
+}
+
 // out <- max(in, 0)
 __global__ void clip_copy_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -383,8 +433,8 @@ int fftconv_apply(bh_ctx* ctx, const ConvPlan& pl, const float* in, const cf* ot
                   int epilogue, const float* aux, float eps, float* out);
 int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, const cf* otf, cf* spec, int iterations,
                             float eps, float* est);
-int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, float* est_p, const float* d_p, const cf* otf, cf* spec,
-                                float eps);
+int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, const float* est_p, const float* d_p, const cf* otf,
+                                cf* spec, float eps, float* corr_p);
 int fftconv_forward(bh_ctx* ctx, const ConvPlan& pl, const float* in, cf* spec);
 int fftconv_inverse(bh_ctx* ctx, const ConvPlan& pl, cf* spec, float* out);
 int fftconv_tikhonov(bh_ctx* ctx, const ConvPlan& pl, const float* in, const float* tf_full, float reg, cf* spec,
@@ -512,8 +562,9 @@ static int64_t next_smooth(int64_t n) {
 }
 static bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
 
-// Box the fused engine could run an awkward volume at: power-of-two axes inside the engine's range stay as they are (they
-// wrap by themselves), the others grow to the next power of two >= N + 2 (K - 1) (room for the twice-extended estimate).
+// Box the fused engine could run an awkward volume at: axes it transforms as they are stay (they wrap by themselves), the
+// others grow to the next 2^k (3 * 2^k for z, y) >= N + K - 1: room for the wrap-extended estimate going into the
+// convolution, and for the tails of the linear correlation coming out.
 static bool engine_pad_box(const int64_t N[3], const int64_t K[3], int64_t P[3]) {
     static const bool radix3 = getenv("BH_FC_NORADIX3") == nullptr;
     for (int a = 0; a < 3; ++a) {
@@ -523,7 +574,7 @@ static bool engine_pad_box(const int64_t N[3], const int64_t K[3], int64_t P[3])
             P[a] = N[a];
             continue;
         }
-        const int64_t need = N[a] + 2 * (K[a] - 1);
+        const int64_t need = N[a] + K[a] - 1;
         P[a] = 1;
         while (P[a] < need) P[a] *= 2;
         // z and y columns may also be 3 * 2^k long (radix-3 first step of the column passes); rows along x may not
@@ -534,10 +585,12 @@ static bool engine_pad_box(const int64_t N[3], const int64_t K[3], int64_t P[3])
     return fftconv_supported_ex(P[0], P[1], P[2], true);
 }
 
-// Richardson-Lucy for an awkward shape on the fused engine.  Padded axes carry the estimate wrap-extended by K - 1 on both
-// sides (position n sits at n + K - 1): the convolution is then right on the once-extended box, the ratio there is the
-// wrap-extended ratio the correlation needs, and the correlation is right on the N box — the circular convolution at size
-// N the definition asks for, from transforms of size P.  After each update the margins are rebuilt from the interior.
+// Richardson-Lucy for an awkward shape on the fused engine at a larger box P.  On a padded axis the volume voxel n sits at
+// n + off, off = K - 1 - K/2, and the estimate is wrap-extended by off below and K/2 above it: the convolution (taps at
+// -K/2 .. K - 1 - K/2) is then the circular one on the volume's own box.  The data term is zero outside that box, so the
+// ratio is too, and the correlation that follows is the LINEAR correlation of the zero-padded ratio; its tails (off below,
+// K/2 above, inside the box because P >= N + K - 1) are folded back — the circular correlation at size N the definition
+// asks for — by the kernel that also multiplies, clips and rebuilds the wrap-extension for the next iteration.
 static int richardson_lucy_engine_padded(bh_ctx* ctx, const float* d, const float* psf, int64_t pz, int64_t py, int64_t px,
                                          int64_t Z, int64_t Y, int64_t X, const int64_t P[3], int iterations, float eps,
                                          float* out) {
@@ -552,11 +605,12 @@ static int richardson_lucy_engine_padded(bh_ctx* ctx, const float* d, const floa
     ConvPlan* pl;
     BH_TRY(fftconv_plan(ctx, P[0], P[1], P[2], &pl));
     const size_t NS = fftconv_spectrum_elems(*pl);
-    float *a, *b, *dp;
+    float *a, *b, *c, *dp;
     cf *spec, *otf;
     double* psum;
     BH_TRY(get_scratch(ctx, "fft_real", VP * sizeof(float), (void**)&a));
     BH_TRY(get_scratch(ctx, "rl_real2", VP * sizeof(float), (void**)&b));
+    BH_TRY(get_scratch(ctx, "rl_corr_p", VP * sizeof(float), (void**)&c));
     BH_TRY(get_scratch(ctx, "rl_data_p", VP * sizeof(float), (void**)&dp));
     BH_TRY(get_scratch(ctx, "fc_spec", NS * sizeof(cf), (void**)&spec));
     BH_TRY(get_scratch(ctx, "fc_otf", NS * sizeof(cf), (void**)&otf));
@@ -566,33 +620,27 @@ static int richardson_lucy_engine_padded(bh_ctx* ctx, const float* d, const floa
     BH_TRY(stage_rl_psf(ctx, psf, pz, py, px, P[0], P[1], P[2], a, psum));
     BH_TRY(fftconv_make_otf(ctx, *pl, a, otf));
 
-    RemapDims pad, rewrap, crop;
+    RemapDims pad, crop;
+    FoldBox fold;
     for (int i = 0; i < 3; ++i) {
         const bool padded = P[i] != N[i];
-        const int off = padded ? (int)(K[i] - 1) : 0;
-        pad.D[i] = rewrap.D[i] = P[i];
-        pad.S[i] = N[i];
-        rewrap.S[i] = crop.S[i] = P[i];
-        crop.D[i] = N[i];
-        pad.N[i] = rewrap.N[i] = crop.N[i] = (int)N[i];
-        pad.doff[i] = rewrap.doff[i] = off;
-        crop.doff[i] = 0;
-        pad.soff[i] = 0;
-        rewrap.soff[i] = crop.soff[i] = off;
-        pad.lo[i] = pad.hi[i] = rewrap.lo[i] = rewrap.hi[i] = off;  // twice-extended: K - 1 on both sides
+        const int lo = padded ? (int)(K[i] - 1 - K[i] / 2) : 0, hi = padded ? (int)(K[i] / 2) : 0;
+        pad.D[i] = crop.S[i] = fold.P[i] = P[i];
+        pad.S[i] = crop.D[i] = N[i];
+        pad.N[i] = crop.N[i] = fold.N[i] = (int)N[i];
+        pad.doff[i] = crop.soff[i] = fold.off[i] = lo;
+        pad.soff[i] = crop.doff[i] = 0;
+        pad.lo[i] = fold.lo[i] = lo;
+        pad.hi[i] = fold.hi[i] = hi;
         crop.lo[i] = crop.hi[i] = 0;
     }
-    RemapDims pad_d = pad;  // the data term lives on the once-extended box (where the ratio is needed), zero elsewhere
-    for (int i = 0; i < 3; ++i) {
-        const bool padded = P[i] != N[i];
-        pad_d.lo[i] = padded ? (int)(K[i] / 2) : 0;               // correlation reaches K/2 below ...
-        pad_d.hi[i] = padded ? (int)(K[i] - 1 - K[i] / 2) : 0;    // ... and K - 1 - K/2 above the N box
-    }
-    auto grid2 = [&](const RemapDims& r) {
-        return dim3((unsigned)std::min<int64_t>(ceil_div(r.D[2], 256), 16), (unsigned)std::min<int64_t>(r.D[0] * r.D[1], 65535));
+    RemapDims pad_d = pad;  // the data term: the volume's own box only
+    for (int i = 0; i < 3; ++i) pad_d.lo[i] = pad_d.hi[i] = 0;
+    auto grid2 = [&](const int64_t D[3]) {  // a block walks up to 2048 voxels of one row: the per-row index work is paid once
+        return dim3((unsigned)std::min<int64_t>(ceil_div(D[2], 2048), 16), (unsigned)std::min<int64_t>(D[0] * D[1], 65535));
     };
-    hipLaunchKernelGGL(remap_kernel<false>, grid2(pad_d), dim3(256), 0, s, d, dp, pad_d);
-    hipLaunchKernelGGL(remap_kernel<true>, grid2(pad), dim3(256), 0, s, d, a, pad);  // e0 = max(d, 0), wrap-extended
+    hipLaunchKernelGGL(remap_kernel<false>, grid2(pad_d.D), dim3(256), 0, s, d, dp, pad_d);
+    hipLaunchKernelGGL(remap_kernel<true>, grid2(pad.D), dim3(256), 0, s, d, a, pad);  // e0 = max(d, 0), wrap-extended
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {
         BH_CHECK_HIP(hipEventCreate(&e0));
@@ -601,13 +649,11 @@ static int richardson_lucy_engine_padded(bh_ctx* ctx, const float* d, const floa
     }
     float *cur = a, *nxt = b;
     for (int it = 0; it < iterations; ++it) {
-        BH_TRY(fftconv_rl_iteration_padded(ctx, *pl, cur, dp, otf, spec, eps));
-        if (it + 1 < iterations) {
-            hipLaunchKernelGGL(remap_kernel<false>, grid2(rewrap), dim3(256), 0, s, (const float*)cur, nxt, rewrap);
-            std::swap(cur, nxt);
-        }
+        BH_TRY(fftconv_rl_iteration_padded(ctx, *pl, cur, dp, otf, spec, eps, c));
+        hipLaunchKernelGGL(fold_update_rewrap_kernel, grid2(fold.P), dim3(256), 0, s, (const float*)c, (const float*)cur, nxt, fold);
+        std::swap(cur, nxt);
     }
-    hipLaunchKernelGGL(remap_kernel<false>, grid2(crop), dim3(256), 0, s, (const float*)cur, out, crop);
+    hipLaunchKernelGGL(remap_kernel<false>, grid2(crop.D), dim3(256), 0, s, (const float*)cur, out, crop);
     BH_CHECK_HIP(hipGetLastError());
     if (e0) {
         BH_CHECK_HIP(hipEventRecord(e1, s));
@@ -630,13 +676,13 @@ static int rl_plan(int64_t pz, int64_t py, int64_t px, int64_t Z, int64_t Y, int
     const bool nopad = getenv("BH_RL_NOPAD") != nullptr;
     for (int a = 0; a < 3; ++a) P[a] = (nopad || is_smooth(N[a])) ? N[a] : next_smooth(N[a] + K[a] - 1);
     // The fused engine at a power-of-two (or 3 * 2^k) box against hipFFT at the 7-smooth one: the engine moves a voxel of its
-    // box about 2.2x faster (10 passes at ~4.3 Gvox/s against the library path's ~1.9 Gvox/s), so it wins
+    // box about 2x faster (9 passes + fold at ~3.9 Gvox/s against the library path's ~1.9 Gvox/s), so it wins
     // unless its box is more than twice as large.  BH_RL_ENGINE_PAD=0 / 1 forces the choice.
     const char* force = getenv("BH_RL_ENGINE_PAD");
     const char* be = getenv("BH_FFT_BACKEND");
     const bool hipfft_forced = be != nullptr && strcmp(be, "hipfft") == 0;
     if (!hipfft_forced && !nopad && !(force && force[0] == '0') && engine_pad_box(N, K, PE)) {
-        const double cost_engine = (double)PE[0] * PE[1] * PE[2] / 4.3, cost_lib = (double)P[0] * P[1] * P[2] / 1.9;
+        const double cost_engine = (double)PE[0] * PE[1] * PE[2] / 3.9, cost_lib = (double)P[0] * P[1] * P[2] / 1.9;
         if ((force && force[0] == '1') || cost_engine < cost_lib) {
             for (int a = 0; a < 3; ++a) box[a] = PE[a];
             return BH_RL_ENGINE_PADDED;

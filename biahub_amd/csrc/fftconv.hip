@@ -1304,13 +1304,14 @@ int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, con
     return BH_OK;
 }
 
-// One Richardson-Lucy iteration on a volume the CALLER keeps wrap-padded (deconv.hip: richardson_lucy_engine_padded).
-// est_p is read by the forward X pass and updated in place, on all of the padded box, by the last inverse X pass; only the
-// interior the caller cares about is meaningful afterwards, so the update cannot be fused into the next forward transform
-// (the margins must be re-wrapped first): 10 passes instead of 8.  d_p is the wrap-padded data term, zero outside its
-// extended box, which also zeroes the ratio there.
-int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, float* est_p, const float* d_p, const cf* otf, cf* spec,
-                                float eps) {
+// The transform passes of one Richardson-Lucy iteration on a volume the CALLER keeps padded (deconv.hip:
+// richardson_lucy_engine_padded): forward X of est_p, convolution, [inverse X -> d_p / max(., eps) -> forward X] fused,
+// correlation, inverse X stored to corr_p.  est_p is wrap-extended so that the convolution is right on the volume's own box;
+// d_p is zero outside that box, which zeroes the ratio there, so corr_p is the LINEAR correlation of the zero-padded ratio:
+// the caller folds its wrapped-around tails back, multiplies, and rebuilds est_p.  9 transform passes (8 when nothing is
+// padded and update -> forward can stay fused).
+int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, const float* est_p, const float* d_p, const cf* otf,
+                                cf* spec, float eps, float* corr_p) {
     BH_TRY(launch_x(ctx, pl, false, 0, est_p, spec, nullptr, nullptr, 0.f));
     BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));
     BH_TRY(launch_col(ctx, pl, COL_CONV, true, spec, otf, 1.f));
@@ -1319,7 +1320,7 @@ int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, float* est_p, c
     BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));
     BH_TRY(launch_col(ctx, pl, COL_CORR, true, spec, otf, 1.f));
     BH_TRY(launch_col(ctx, pl, COL_INV, false, spec, nullptr, 1.f));
-    BH_TRY(launch_x(ctx, pl, true, XE_UPDATE, nullptr, spec, est_p, est_p, eps, false));
+    BH_TRY(launch_x(ctx, pl, true, XE_STORE, nullptr, spec, corr_p, nullptr, 0.f));
     return BH_OK;
 }
 

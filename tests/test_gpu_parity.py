@@ -186,8 +186,8 @@ def test_richardson_lucy_vs_oracle(gpu, shape, pshape):
     ((37, 53, 71), (4, 6, 8)),      # even PSF extents: the kernel reaches further below 0 than above N-1
     ((32, 53, 64), (9, 7, 5)),      # only Y is awkward; Z and X wrap on their own
     ((19, 40, 134), (5, 3, 11)),    # 134 = 2 * 67
-    ((21, 64, 150), (7, 5, 9)),     # Y a power of two the engine keeps as it is; Z -> 48 = 3 * 16 (radix-3 columns), X -> 256
-    ((40, 70, 64), (9, 9, 3)),      # X stays, Z -> 64, Y -> 96 = 3 * 32 (radix-3 columns of 3 * 16)
+    ((21, 64, 150), (7, 5, 9)),     # engine box: Y a power of two kept as it is, Z -> 32, X -> 256
+    ((40, 70, 64), (9, 9, 3)),      # X stays, Z -> 48 = 3 * 16 (radix-3 columns), Y -> 96 (columns of 48 = 3 * 16)
     ((80, 150, 64), (5, 5, 5)),     # Z -> 96 (odd log2 of the power-of-two part), Y -> 192
     ((170, 64, 64), (9, 3, 3)),     # Z -> 192 = 3 * 64
 ])
