@@ -566,20 +566,19 @@ static bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
 // others grow to the next 2^k (3 * 2^k for z, y) >= N + K - 1: room for the wrap-extended estimate going into the
 // convolution, and for the tails of the linear correlation coming out.
 static bool engine_pad_box(const int64_t N[3], const int64_t K[3], int64_t P[3]) {
-    static const bool radix3 = getenv("BH_FC_NORADIX3") == nullptr;
+    const bool radix3 = getenv("BH_FC_NORADIX3") == nullptr;
     for (int a = 0; a < 3; ++a) {
-        // axes the engine transforms as they are wrap by themselves: powers of two, and 3 * 2^k along z and y
-        if (is_pow2(N[a]) || (radix3 && a < 2 && N[a] % 3 == 0 && is_pow2(N[a] / 3) &&
-                              fftconv_supported_ex(a == 0 ? N[a] : 64, a == 1 ? N[a] : 64, 64, true))) {
+        // axes the engine transforms as they are wrap by themselves: powers of two and 3 * 2^k
+        auto alone = [&](int64_t n) { return fftconv_supported_ex(a == 0 ? n : 64, a == 1 ? n : 64, a == 2 ? n : 64, true); };
+        if (is_pow2(N[a]) || (radix3 && N[a] % 3 == 0 && is_pow2(N[a] / 3) && alone(N[a]))) {
             P[a] = N[a];
             continue;
         }
         const int64_t need = N[a] + K[a] - 1;
         P[a] = 1;
         while (P[a] < need) P[a] *= 2;
-        // z and y columns may also be 3 * 2^k long (radix-3 first step of the column passes); rows along x may not
-        if (radix3 && a < 2 && P[a] >= 8 && 3 * (P[a] / 4) >= need && fftconv_supported_ex(a == 0 ? 3 * (P[a] / 4) : 64, a == 1 ? 3 * (P[a] / 4) : 64, 64, true))
-            P[a] = 3 * (P[a] / 4);
+        // 3 * 2^k (radix-3 first step of that axis' transform) when it is enough
+        if (radix3 && P[a] >= 8 && 3 * (P[a] / 4) >= need && alone(3 * (P[a] / 4))) P[a] = 3 * (P[a] / 4);
         if (K[a] - 1 >= N[a]) return false;  // the wrap below assumes margins shorter than the axis
     }
     return fftconv_supported_ex(P[0], P[1], P[2], true);

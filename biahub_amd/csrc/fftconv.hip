@@ -296,36 +296,41 @@ __device__ __forceinline__ void radix16_step(cf* buf, int N, int logW, int P, in
 // frequency): rows (m, m + L, m + 2L) -> the three length-L sequences y_k[m] = (x[m] + w3^k x[m+L] + w3^2k x[m+2L]) w_N^(k m),
 // left in rows [k L, (k + 1) L); their length-L transforms are X[3 j + k].  Inverse: the mirror image with conjugate
 // twiddles, unnormalised.  t3[2 m] = w_N^m, t3[2 m + 1] = w_N^2m.
-__device__ __forceinline__ CV<2> vscale2(const CV<2>& x, float f) {
+template <int CPT>
+__device__ __forceinline__ CV<CPT> vscale(const CV<CPT>& x, float f);
+template <>
+__device__ __forceinline__ CV<1> vscale<1>(const CV<1>& x, float f) { return CV<1>{make_float2(x.a.x * f, x.a.y * f)}; }
+template <>
+__device__ __forceinline__ CV<2> vscale<2>(const CV<2>& x, float f) {
     return CV<2>{make_float2(x.a.x * f, x.a.y * f), make_float2(x.b.x * f, x.b.y * f)};
 }
-template <bool INV, int NT = FC_NT>
+template <bool INV, int CPT = 2, int NT = FC_NT>
 __device__ __forceinline__ void radix3_step(cf* buf, int L, int logW, int P, const cf* t3, int tid) {
-    const int lw = logW - 1;
+    const int lw = logW - (CPT == 2 ? 1 : 0);
     const int total = L << lw;
     const size_t LP = (size_t)L * P;
     const float S3 = 0.86602540378443865f;
     for (int idx = tid; idx < total; idx += NT) {
-        const int c = (idx & ((1 << lw) - 1)) * 2;
+        const int c = (idx & ((1 << lw) - 1)) * CPT;
         const int m = idx >> lw;
         cf* p0 = buf + (size_t)m * P + c;
-        const CV<2> a = CV<2>::ld(p0);
-        CV<2> b = CV<2>::ld(p0 + LP), cc = CV<2>::ld(p0 + 2 * LP);
+        const CV<CPT> a = CV<CPT>::ld(p0);
+        CV<CPT> b = CV<CPT>::ld(p0 + LP), cc = CV<CPT>::ld(p0 + 2 * LP);
         const cf w1 = t3[2 * m], w2 = t3[2 * m + 1];
         if (INV) {
-            b = vmulc<2>(b, w1);
-            cc = vmulc<2>(cc, w2);
+            b = vmulc<CPT>(b, w1);
+            cc = vmulc<CPT>(cc, w2);
         }
-        const CV<2> sm = vadd<2>(b, cc), df = vsub<2>(b, cc);
-        const CV<2> base = vsub<2>(a, vscale2(sm, 0.5f));
-        const CV<2> rot = vscale2(INV ? vmul_pi<2>(df) : vmul_mi<2>(df), S3);
-        vadd<2>(a, sm).st(p0);
+        const CV<CPT> sm = vadd<CPT>(b, cc), df = vsub<CPT>(b, cc);
+        const CV<CPT> base = vsub<CPT>(a, vscale<CPT>(sm, 0.5f));
+        const CV<CPT> rot = vscale<CPT>(INV ? vmul_pi<CPT>(df) : vmul_mi<CPT>(df), S3);
+        vadd<CPT>(a, sm).st(p0);
         if (!INV) {
-            vmul<2>(vadd<2>(base, rot), w1).st(p0 + LP);
-            vmul<2>(vsub<2>(base, rot), w2).st(p0 + 2 * LP);
+            vmul<CPT>(vadd<CPT>(base, rot), w1).st(p0 + LP);
+            vmul<CPT>(vsub<CPT>(base, rot), w2).st(p0 + 2 * LP);
         } else {
-            vadd<2>(base, rot).st(p0 + LP);
-            vsub<2>(base, rot).st(p0 + 2 * LP);
+            vadd<CPT>(base, rot).st(p0 + LP);
+            vsub<CPT>(base, rot).st(p0 + 2 * LP);
         }
     }
 }
@@ -419,6 +424,7 @@ struct ConvDims {
     int XP;        // spectrum row pitch in complex elements
     int logM, logYh, logZ;  // log2 of M and of the power-of-two parts of Y/2 and Z
     int Lyh, Lz;            // those parts: Y/2 and Z themselves, or a third of them (radix-3 column passes)
+    int Lm;                 // M or M / 3 (radix-3 first step of the row transforms)
 };
 
 // ================================================================================================
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
 #define BH_FFT_FWD(...)                                                     \
     {                                                                       \
         if (r3) {                                                           \
-            radix3_step<false>(buf, L_, logW, W_, tw3, tid);                \
+            radix3_step<false, 2>(buf, L_, logW, W_, tw3, tid);                \
             __syncthreads();                                                \
         }                                                                   \
         fft_lds<false, __VA_ARGS__>(buf, L_, logN, logW, W_, tw, tid, N_);  \
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
     {                                                                       \
         fft_lds<true, __VA_ARGS__>(buf, L_, logN, logW, W_, tw, tid, N_);   \
         if (r3) {                                                           \
-            radix3_step<true>(buf, L_, logW, W_, tw3, tid);                 \
+            radix3_step<true, 2>(buf, L_, logW, W_, tw3, tid);                 \
             __syncthreads();                                                \
         }                                                                   \
     }
@@ -673,6 +679,7 @@ struct XParams {
     const cf* tw;         // twiddles for length M
     const cf* untangle;   // w_X^{brev(p)}, p < M
     const cf* twy;        // w_Y^y, y < Y/2
+    const cf* tw3;        // radix-3 twiddles of the row transform (2 Lm entries) when M = 3 Lm
     int ntw;
     ConvDims d;
     float eps;
@@ -703,8 +710,11 @@ __device__ __forceinline__ int opaque(int v) {
 }
 
 // untangle in place after the packed length-M FFT: pairs (p, mirror(p)); u = 0 handles DC + Nyquist and p = 1
-template <bool INV>
-__device__ __forceinline__ void untangle_lds(cf* buf, const cf* ut, int M, int tid) {
+// R3: M = 3 L and the spectrum sits in thirds (frequency 3 j + t in third t at the bit-reversed j).  Third 0 mirrors into
+// itself exactly like a length-L power-of-two transform (frequency M - 3 j = 3 (L - j)); thirds 1 and 2 mirror into each
+// other with complemented positions (M - (3 j + 1) = 3 (L - 1 - j) + 2, and brev(L - 1 - j) = L - 1 - brev(j)).
+template <bool INV, bool R3 = false>
+__device__ __forceinline__ void untangle_lds(cf* buf, const cf* ut, int M, int tid, int L = 0) {
     for (int idx = tid; idx < (M >> 1) * FC_XR; idx += FC_XNT) {
         const int c = idx % FC_XR;
         const int u = idx / FC_XR;
@@ -719,9 +729,16 @@ __device__ __forceinline__ void untangle_lds(cf* buf, const cf* ut, int M, int t
             }
             buf[FC_XPITCH + c] = cconj(buf[FC_XPITCH + c]);  // k = M/2: w^k = -i
         } else {
-            const int top = 31 - __clz(u);
-            const int pp = (2 << top) + (u - (1 << top));
-            const int pm = 3 * (2 << top) - 1 - pp;
+            int pp, pm;
+            if (R3 && u >= (L >> 1)) {
+                const int r = u - (L >> 1);  // < L
+                pp = L + r;
+                pm = 3 * L - 1 - r;
+            } else {
+                const int top = 31 - __clz(u);
+                pp = (2 << top) + (u - (1 << top));
+                pm = 3 * (2 << top) - 1 - pp;
+            }
             const cf a = buf[(size_t)pp * FC_XPITCH + c], b = buf[(size_t)pm * FC_XPITCH + c];
             const cf E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));   // (a + conj b)/2
             const cf Dm = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));  // (a - conj b)/2
@@ -742,13 +759,20 @@ __device__ __forceinline__ void untangle_lds(cf* buf, const cf* ut, int M, int t
 
 // Forward tail shared by x_fwd_kernel and the fused inverse->forward kernel: the tile's 16 packed rows are in
 // LDS (buf[n][c], natural order); FFT, untangle, Y radix-2 step across the row pairs, store the spectrum rows.
-template <int ROUNDS>
+template <int ROUNDS, bool R3 = false>
 __device__ __forceinline__ void x_forward_from_lds(cf* buf, const cf* tw, const cf* ut, const XParams& p,
-                                                   const ConvDims& d, long t, int tid, int q, int rr, int RPR) {
+                                                   const ConvDims& d, long t, int tid, int q, int rr, int RPR,
+                                                   bool active = true) {
     const int M = d.M;
     constexpr int HALF = ROUNDS / 2;
-    fft_lds<false, 2, 1, FC_R16, false, FC_XNT>(buf, M, d.logM, FC_LOGXR, FC_XPITCH, tw, tid);
-    untangle_lds<false>(buf, ut, M, tid);
+    if (R3) {
+        radix3_step<false, 1, FC_XNT>(buf, d.Lm, FC_LOGXR, FC_XPITCH, ut + M, tid);
+        __syncthreads();
+        fft_lds<false, 2, 1, FC_R16, false, FC_XNT>(buf, d.Lm, d.logM, FC_LOGXR, FC_XPITCH, tw, tid, M);
+    } else {
+        fft_lds<false, 2, 1, FC_R16, false, FC_XNT>(buf, M, d.logM, FC_LOGXR, FC_XPITCH, tw, tid);
+    }
+    untangle_lds<false, R3>(buf, ut, M, tid, d.Lm);
     __syncthreads();
 
     // Y radix-2 step across each row pair, then store the spectrum rows
@@ -759,6 +783,7 @@ __device__ __forceinline__ void x_forward_from_lds(cf* buf, const cf* tw, const 
         // this thread's rounds u and u + HALF are exactly a pair (y, y + Y/2): two columns per lane, 16-B stores
 #pragma unroll
         for (int u = 0; u < (HALF > 0 ? HALF : 1); ++u) {
+            if (R3 && !active) break;
             const int c = rr + u * RPR;  // < FC_XH
             const int y = FC_XH * g + c;
             const cf w = p.twy[y];
@@ -800,7 +825,7 @@ __device__ __forceinline__ void x_forward_from_lds(cf* buf, const cf* tw, const 
     }
 }
 
-template <int ROUNDS>
+template <int ROUNDS, bool R3 = false>
 __global__ __launch_bounds__(FC_XNT) void x_fwd_kernel(XParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ConvDims d = p.d;
@@ -811,11 +836,16 @@ __global__ __launch_bounds__(FC_XNT) void x_fwd_kernel(XParams p) {
     const int tid = threadIdx.x;
     for (int i = tid; i < p.ntw; i += FC_XNT) tw[i] = p.tw[i];
     for (int i = tid; i < M; i += FC_XNT) ut[i] = p.untangle[i];
+    if (R3)
+        for (int i = tid; i < 2 * d.Lm; i += FC_XNT) ut[M + i] = p.tw3[i];  // radix-3 twiddles ride behind the untangle table
 
     const int QPR = M >> 1;                 // float4 per real row
-    const int RPR = FC_XNT / QPR;            // rows per round (QPR <= 512)
+    // rows per round (QPR <= 512).  M = 3 L: the largest power of two that fits; the threads left over repeat the work of
+    // the last row group (same addresses, same values)
+    const int RPR = R3 ? (1 << (31 - __clz(FC_XNT / QPR))) : FC_XNT / QPR;
     const int q = tid % QPR;
-    const int rr = tid / QPR;
+    const int rr = R3 ? min(tid / QPR, RPR - 1) : tid / QPR;
+    const bool active = !R3 || tid / QPR < RPR;  // left-over threads only take part in the transforms
     const int gpz = d.Y / FC_XR;
     const long ntiles = (long)d.Z * gpz;
 
@@ -836,7 +866,7 @@ __global__ __launch_bounds__(FC_XNT) void x_fwd_kernel(XParams p) {
 #pragma unroll
         for (int u = 0; u < ROUNDS; ++u) {
             const int c = rr + u * RPR;
-            if (c < FC_XR) {
+            if (c < FC_XR && active) {
                 if (p.out) {  // Richardson-Lucy start: e0 = max(d, 0) is stored and transformed in one pass
                     v[u].x = fmaxf(v[u].x, 0.0f);
                     v[u].y = fmaxf(v[u].y, 0.0f);
@@ -852,12 +882,12 @@ __global__ __launch_bounds__(FC_XNT) void x_fwd_kernel(XParams p) {
         const long tn = t + gridDim.x;
         if (tn < ntiles) load_tile(tn);
 
-        x_forward_from_lds<ROUNDS>(buf, tw, ut, p, d, t, tid, q, rr, RPR);
+        x_forward_from_lds<ROUNDS, R3>(buf, tw, ut, p, d, t, tid, q, rr, RPR, active);
         __syncthreads();
     }
 }
 
-template <int EPI, int ROUNDS, bool FUSE>
+template <int EPI, int ROUNDS, bool FUSE, bool R3 = false>
 __global__ __launch_bounds__(FC_XNT) void x_inv_kernel(XParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ConvDims d = p.d;
@@ -868,11 +898,14 @@ __global__ __launch_bounds__(FC_XNT) void x_inv_kernel(XParams p) {
     const int tid = threadIdx.x;
     for (int i = tid; i < p.ntw; i += FC_XNT) tw[i] = p.tw[i];
     for (int i = tid; i < M; i += FC_XNT) ut[i] = p.untangle[i];
+    if (R3)
+        for (int i = tid; i < 2 * d.Lm; i += FC_XNT) ut[M + i] = p.tw3[i];
 
     const int QPR = M >> 1;
-    const int RPR = FC_XNT / QPR;
+    const int RPR = R3 ? (1 << (31 - __clz(FC_XNT / QPR))) : FC_XNT / QPR;  // see x_fwd_kernel
     const int q = tid % QPR;
-    const int rr = tid / QPR;
+    const int rr = R3 ? min(tid / QPR, RPR - 1) : tid / QPR;
+    const bool active = !R3 || tid / QPR < RPR;  // left-over threads only take part in the transforms
     const int gpz = d.Y / FC_XR;
     const long ntiles = (long)d.Z * gpz;
     constexpr int HALF = ROUNDS / 2;
@@ -903,6 +936,7 @@ __global__ __launch_bounds__(FC_XNT) void x_inv_kernel(XParams p) {
             // undo the Y radix-2 step in registers, write X[p] into LDS (transposed)
 #pragma unroll
             for (int u = 0; u < (HALF > 0 ? HALF : 1); ++u) {
+                if (R3 && !active) break;
                 const int c = rr + u * RPR;  // < FC_XH
                 const cf w = p.twy[FC_XH * g + c];
                 const float4 A = v[u], B = v[(u + HALF) % ROUNDS];
@@ -952,16 +986,22 @@ __global__ __launch_bounds__(FC_XNT) void x_inv_kernel(XParams p) {
         } else if (FAST && tn < ntiles) {
             load_tile(tn);
         }
-        untangle_lds<true>(buf, ut, M, tid);
+        untangle_lds<true, R3>(buf, ut, M, tid, d.Lm);
         __syncthreads();
-        fft_lds<true, 1, 1, FC_R16, false, FC_XNT>(buf, M, d.logM, FC_LOGXR, FC_XPITCH, tw, tid);
+        if (R3) {
+            fft_lds<true, 1, 1, FC_R16, false, FC_XNT>(buf, d.Lm, d.logM, FC_LOGXR, FC_XPITCH, tw, tid, M);
+            radix3_step<true, 1, FC_XNT>(buf, d.Lm, FC_LOGXR, FC_XPITCH, ut + M, tid);
+            __syncthreads();
+        } else {
+            fft_lds<true, 1, 1, FC_R16, false, FC_XNT>(buf, M, d.logM, FC_LOGXR, FC_XPITCH, tw, tid);
+        }
         if (!FUSE && EPI != XE_STORE) load_aux();
         // natural order now: z[j] = x[2j] + i x[2j+1]; apply the fused epilogue to the real rows
 #pragma unroll
         for (int u = 0; u < ROUNDS; ++u) {
             const int rro = opaque(rr);
             const int c = min(rro + u * RPR, FC_XR - 1);
-            const bool mine = rro + u * RPR < FC_XR;
+            const bool mine = rro + u * RPR < FC_XR && active;
             const cf e0 = buf[(size_t)(2 * q) * FC_XPITCH + c], e1 = buf[(size_t)(2 * q + 1) * FC_XPITCH + c];
             float4 r = make_float4(e0.x, e0.y, e1.x, e1.y);
             if (EPI == XE_RATIO) {
@@ -990,7 +1030,7 @@ __global__ __launch_bounds__(FC_XNT) void x_inv_kernel(XParams p) {
         __syncthreads();
         if (FUSE) {
             if (FAST && tn < ntiles) load_tile(tn);  // next tile's spectrum behind the forward FFT
-            x_forward_from_lds<ROUNDS>(buf, tw, ut, p, d, t, tid, q, rr, RPR);
+            x_forward_from_lds<ROUNDS, R3>(buf, tw, ut, p, d, t, tid, q, rr, RPR, active);
             __syncthreads();
         }
     }
@@ -1006,6 +1046,7 @@ struct ConvPlan {
     int Wy = 0, Wz = 0;
     int Lyh = 0, Lz = 0;                      // power-of-two part of Y/2 and Z (== them, or a third of them)
     cf *tw3_y = nullptr, *tw3_z = nullptr;    // radix-3 twiddles where the axis is 3 * 2^k
+    cf* tw3_x = nullptr;                      // same for the rows (M = 3 Lm)
 };
 
 static int ilog2(long v) {
@@ -1020,15 +1061,16 @@ static int ilog2(long v) {
 bool fftconv_supported_ex(int64_t Z, int64_t Y, int64_t X, bool radix3) {
     auto pow2 = [](int64_t v) { return v > 0 && (v & (v - 1)) == 0; };
     auto ok = [&](int64_t v) { return pow2(v) || (radix3 && v % 3 == 0 && pow2(v / 3)); };
-    if (!ok(Z) || !ok(Y) || !pow2(X)) return false;
+    if (!ok(Z) || !ok(Y) || !ok(X)) return false;
     if (X < 64 || X > 2048) return false;          // M = X/2 in [32, 1024]: (M+1)*17*8 + tables <= 160 KiB
+    if (!pow2(X) && X < 192) return false;         // rows of 3 * 2^k: thirds of at least 32 complex points
     if (Y < 2 * 16 || Y / 2 > 2048) return false;   // Y/2 rows x >= 8 columns per tile, whole groups of FC_XR rows
     if (Z < 4 || Z > 2048) return false;
     if ((Y % FC_XR) != 0) return false;
     if (!pow2(Z) && Z < 24) return false;   // radix-3 columns: at least 3 x 8 rows
     if (!pow2(Y) && Y < 96) return false;
-    const int M = (int)X / 2;
-    const size_t xlds = (size_t)(M + 1) * FC_XPITCH * 8 + (size_t)twiddle_count(M) * 8 + (size_t)M * 8;
+    const int M = (int)X / 2, Lm = pow2(X) ? M : M / 3;
+    const size_t xlds = (size_t)(M + 1) * FC_XPITCH * 8 + (size_t)twiddle_count(Lm) * 8 + (size_t)M * 8 + (Lm != M ? (size_t)2 * Lm * 8 : 0);
     return xlds <= 160 * 1024;
 }
 
@@ -1060,13 +1102,14 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     auto pow2part = [](int64_t n) { return (int)((n & (n - 1)) == 0 ? n : n / 3); };
     pl.Lyh = pow2part(Y / 2);
     pl.Lz = pow2part(Z);
-    pl.d.logM = ilog2(X / 2);
+    pl.d.Lm = pow2part(X / 2);
+    pl.d.logM = ilog2(pl.d.Lm);
     pl.d.logYh = ilog2(pl.Lyh);
     pl.d.logZ = ilog2(pl.Lz);
     pl.d.Lyh = pl.Lyh;
     pl.d.Lz = pl.Lz;
     std::vector<cf> h;
-    make_twiddles(pl.d.M, h);
+    make_twiddles(pl.d.Lm, h);
     pl.ntw_x = (int)h.size();
     BH_TRY(upload(h, &pl.tw_x));
     make_twiddles(pl.Lyh, h);
@@ -1087,11 +1130,15 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     };
     BH_TRY(radix3_twiddles((int)Y / 2, pl.Lyh, &pl.tw3_y));
     BH_TRY(radix3_twiddles((int)Z, pl.Lz, &pl.tw3_z));
+    BH_TRY(radix3_twiddles(pl.d.M, pl.d.Lm, &pl.tw3_x));
     h.resize(pl.d.M);
     for (int pp = 0; pp < pl.d.M; ++pp) {
+        // frequency stored at position pp: bit-reversed within the (single, or one of three) length-Lm transform(s)
+        const int third = pp / pl.d.Lm, r = pp % pl.d.Lm;
         int k = 0;
         for (int b = 0; b < pl.d.logM; ++b)
-            if (pp & (1 << b)) k |= 1 << (pl.d.logM - 1 - b);
+            if (r & (1 << b)) k |= 1 << (pl.d.logM - 1 - b);
+        if (pl.d.Lm != pl.d.M) k = 3 * k + third;
         const double a = -2.0 * M_PI * k / (double)X;
         h[pp] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
@@ -1197,10 +1244,12 @@ static int launch_x(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, cons
     p.tw = pl.tw_x;
     p.untangle = pl.untangle;
     p.twy = pl.twy;
+    p.tw3 = pl.tw3_x;
     p.ntw = pl.ntw_x;
     p.d = pl.d;
     p.eps = eps;
-    const size_t lds = (size_t)(pl.d.M + 1) * FC_XPITCH * 8 + (size_t)pl.ntw_x * 8 + (size_t)pl.d.M * 8;
+    const bool r3 = pl.d.Lm != pl.d.M;
+    const size_t lds = (size_t)(pl.d.M + 1) * FC_XPITCH * 8 + (size_t)pl.ntw_x * 8 + (size_t)pl.d.M * 8 + (r3 ? (size_t)2 * pl.d.Lm * 8 : 0);
     const long ntiles = (long)pl.d.Z * (pl.d.Y / FC_XR);
     const int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / FC_XNT, (160 * 1024) / (lds + 1024)));
     const int grid = (int)std::min<long>(ntiles, (long)ctx->num_cus * wgs_per_cu);
@@ -1212,20 +1261,30 @@ static int launch_x(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, cons
         return BH_OK;
     };
     const int QPR = pl.d.M / 2;
-    const int rounds = (int)ceil_div(FC_XR, std::max(1, FC_XNT / QPR));
-#define BH_X_DISPATCH(R)                                                  \
-    if (!inverse) return run(x_fwd_kernel<R>);                            \
-    switch (epi) {                                                        \
-        case XE_STORE: return run(x_inv_kernel<XE_STORE, R, false>);      \
-        case XE_RATIO: return fuse_fwd ? run(x_inv_kernel<XE_RATIO, R, true>) : run(x_inv_kernel<XE_RATIO, R, false>); \
-        default: return fuse_fwd ? run(x_inv_kernel<XE_UPDATE, R, true>) : run(x_inv_kernel<XE_UPDATE, R, false>);     \
+    int rpr = std::max(1, FC_XNT / QPR);
+    if (r3) {  // rows per round: the largest power of two that fits (kernel: RPR)
+        int b = 1;
+        while (2 * b <= rpr) b *= 2;
+        rpr = b;
     }
+    const int rounds = (int)ceil_div(FC_XR, rpr);
+#define BH_X_DISPATCH_(R, R3)                                                 \
+    if (!inverse) return run(x_fwd_kernel<R, R3>);                            \
+    switch (epi) {                                                            \
+        case XE_STORE: return run(x_inv_kernel<XE_STORE, R, false, R3>);      \
+        case XE_RATIO: return fuse_fwd ? run(x_inv_kernel<XE_RATIO, R, true, R3>) : run(x_inv_kernel<XE_RATIO, R, false, R3>); \
+        default: return fuse_fwd ? run(x_inv_kernel<XE_UPDATE, R, true, R3>) : run(x_inv_kernel<XE_UPDATE, R, false, R3>);     \
+    }
+#define BH_X_DISPATCH(R)                    \
+    if (r3) { BH_X_DISPATCH_(R, true) }     \
+    else { BH_X_DISPATCH_(R, false) }
     if (rounds <= 1) { BH_X_DISPATCH(1) }
     if (rounds <= 2) { BH_X_DISPATCH(2) }
     if (rounds <= 4) { BH_X_DISPATCH(4) }
     if (rounds <= 8) { BH_X_DISPATCH(8) }
     BH_X_DISPATCH(16)
 #undef BH_X_DISPATCH
+#undef BH_X_DISPATCH_
 }
 
 // OTF (scrambled order, scaled by 2/V so that forward -> multiply -> inverse is a normalised convolution)
@@ -1273,7 +1332,11 @@ __global__ __launch_bounds__(256) void tikhonov_filter_rows_kernel(const float* 
                 const float h = src[kx];
                 f = (h / (h * h + reg)) * scale;
             }
-            const int ps = kx < d.M ? (int)(__brev((unsigned)kx) >> (32 - d.logM)) : kx;
+            int ps = kx;  // Nyquist and pad columns keep their place
+            if (kx < d.M) {
+                const int jx = d.Lm == d.M ? kx : kx / 3, tx = d.Lm == d.M ? 0 : kx - 3 * jx;
+                ps = tx * d.Lm + (int)(__brev((unsigned)jx) >> (32 - d.logM));
+            }
             rowbuf[ps] = f;
         }
         __syncthreads();

@@ -220,10 +220,13 @@ def test_richardson_lucy_awkward_sizes_pad_fold(gpu, shape, pshape, monkeypatch)
 
 
 @pytest.mark.parametrize("shape,pshape", [((48, 96, 64), (5, 7, 3)), ((24, 32, 128), (3, 3, 9)), ((64, 192, 64), (9, 5, 5)),
-                                          ((96, 64, 256), (7, 3, 3))])
+                                          ((96, 64, 256), (7, 3, 3)),
+                                          ((16, 32, 192), (5, 5, 9)), ((8, 32, 384), (3, 5, 7)), ((24, 96, 768), (5, 3, 11)),
+                                          ((4, 32, 1536), (1, 3, 17))])   # the last four: rows of 3 * 2^k
 def test_richardson_lucy_radix3_columns_fused(gpu, shape, pshape, monkeypatch):
-    """z and / or y of 3 * 2^k: the fused 8-pass iteration runs at the volume's own shape, the column passes starting with a
-    radix-3 step (csrc/fftconv.hip radix3_step); oracle parity and agreement with the library-FFT path."""
+    """Axes of 3 * 2^k: the fused 8-pass iteration runs at the volume's own shape, the transforms of those axes starting with a
+    radix-3 step (csrc/fftconv.hip radix3_step; for rows the real-transform untangle pairs thirds 1 and 2 with each other);
+    oracle parity and agreement with the library-FFT path."""
     from biahub_amd.deconvolve import richardson_lucy, richardson_lucy_plan
 
     assert richardson_lucy_plan(pshape, shape) == (shape, "engine")
@@ -422,7 +425,8 @@ def test_richardson_lucy_fused_engine_vs_oracle(gpu, shape, pshape, monkeypatch)
 
 
 @pytest.mark.parametrize("shape", [(16, 32, 64), (8, 64, 128), (32, 128, 256), (128, 32, 1024),
-                                   (48, 96, 64), (24, 64, 128), (64, 192, 64)])   # the last three: radix-3 columns
+                                   (48, 96, 64), (24, 64, 128), (64, 192, 64),     # radix-3 columns
+                                   (16, 32, 192), (8, 96, 384), (8, 32, 1536)])    # radix-3 rows
 def test_tikhonov_fused_engine_vs_oracle(gpu, shape, monkeypatch):
     from biahub_amd.deconvolve import compute_tranfser_function, deconvolve
 
@@ -530,14 +534,15 @@ def test_phase_cross_corr_golden_and_oracle(gpu):
             assert np.array_equal(got, want), (roll, norm, got, want)
             assert rel_err(corr, wcorr) <= FFT_TOL, (roll, norm)
     # z / y of 3 * 2^k: the engine's column passes start with a radix-3 step; the coefficient order changes, the answers do not
-    r3 = rng.random((48, 96, 64), dtype=np.float32)
-    for roll in ((0, 0, 0), (7, -40, 21), (-24, 48, -32)):
-        mov = np.roll(r3, roll, axis=(0, 1, 2)) + 0.05 * rng.random(r3.shape, dtype=np.float32)
-        for norm in (None, "magnitude", "classic"):
-            want, wcorr = O.phase_cross_corr(r3, mov, norm)
-            got, corr = phase_cross_corr(r3, mov, normalization=norm)
-            assert np.array_equal(got, want), (roll, norm, got, want)
-            assert rel_err(corr, wcorr) <= FFT_TOL, (roll, norm)
+    for shape3, rolls in (((48, 96, 64), ((0, 0, 0), (7, -40, 21), (-24, 48, -32))), ((16, 32, 192), ((3, -9, 77), (-8, 16, -96)))):
+        r3 = rng.random(shape3, dtype=np.float32)
+        for roll in rolls:
+            mov = np.roll(r3, roll, axis=(0, 1, 2)) + 0.05 * rng.random(r3.shape, dtype=np.float32)
+            for norm in (None, "magnitude", "classic"):
+                want, wcorr = O.phase_cross_corr(r3, mov, norm)
+                got, corr = phase_cross_corr(r3, mov, normalization=norm)
+                assert np.array_equal(got, want), (roll, norm, got, want)
+                assert rel_err(corr, wcorr) <= FFT_TOL, (roll, norm)
     with pytest.raises(ValueError):
         phase_cross_corr(ref, ref[:-1], normalization=None)
     with pytest.raises(ValueError):
