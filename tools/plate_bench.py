@@ -26,6 +26,8 @@ ap.add_argument("--T", type=int, default=4)
 ap.add_argument("--C", type=int, default=2)
 ap.add_argument("--shape", type=int, nargs=3, default=[256, 1024, 1024])
 ap.add_argument("--deconv", choices=["rl", "tikhonov"], default="rl")
+ap.add_argument("--order", choices=["deconv-first", "deskew-first"], default="deconv-first",
+                help="deskew-first deconvolves the deskewed (awkward-shaped) volume: fused engine at a padded box (DESIGN.md 2.3)")
 args = ap.parse_args()
 
 rank, local_rank, world = parallel.world_info()
@@ -67,9 +69,13 @@ def one_position(pos):
             # the same scene drifting by (0, -2t, 3t) voxels, camera counts as uint16
             raw = (torch.roll(base, (0, -2 * t, 3 * t), (0, 1, 2)) + 20 * c).round_().to(torch.uint16)
             flat = timed("flat_field", lambda: flat_field_device(raw))
-            dec = timed("deconvolve", lambda: richardson_lucy(flat, psf, 10, 1e-6) if args.deconv == "rl"
-                        else tikhonov_zyx(flat, tf, 1e-3))
-            dsk = timed("deskew", lambda: fast_deskew_zyx(dec, **DK))
+            if args.order == "deconv-first":
+                dec = timed("deconvolve", lambda: richardson_lucy(flat, psf, 10, 1e-6) if args.deconv == "rl"
+                            else tikhonov_zyx(flat, tf, 1e-3))
+                dsk = timed("deskew", lambda: fast_deskew_zyx(dec, **DK))
+            else:
+                dec = timed("deskew", lambda: fast_deskew_zyx(flat, **DK))
+                dsk = timed("deconvolve", lambda: richardson_lucy(dec, psf, 10, 1e-6))
             if t == 0:
                 ref[c] = flat
                 m = np.eye(4)
@@ -93,7 +99,8 @@ torch.cuda.synchronize(dev); parallel.barrier()
 dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
 rows = parallel.gather_stats(st, dev)
 if rank == 0:
-    out = {"workload": f"{args.positions} positions x T={args.T} x C={args.C} x {shape}: flat-field -> {args.deconv} deconvolve -> deskew -> PCC drift -> stabilize",
+    chain = f"{args.deconv} deconvolve -> deskew" if args.order == "deconv-first" else "deskew -> rl deconvolve (deskewed shape)"
+    out = {"workload": f"{args.positions} positions x T={args.T} x C={args.C} x {shape}: flat-field -> {chain} -> PCC drift -> stabilize",
            "n_gpus": world, "seconds": dt, "voxels_per_s_resident": sum(r.voxels for r in rows) / dt,
            "positions_done": sum(r.n_done for r in rows), "positions_failed": sum(r.n_failed for r in rows),
            "stage_seconds_rank0": {k: round(v, 4) for k, v in stage.items()}}
