@@ -51,6 +51,7 @@ SIGNATURES = {
     "bh_deskew": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _f64, _f64, _int, _int, _int, _f32, _vp,
                          C.POINTER(_f32)]),
     "bh_overhang_fill": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _f32, _int, C.POINTER(_f32)]),
+    "bh_overhang_fill_connectivity": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _f32, _int, _int, C.POINTER(_f32)]),
     "bh_transfer_function": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "bh_ctx_fft_plans_replaced": (_int, [_vp, C.POINTER(_int)]),
     "bh_richardson_lucy_plan": (_int, [_i64, _i64, _i64, _i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_int)]),

@@ -427,7 +427,7 @@ static int launch_deskew(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g, b
 }
 
 int fill_overhang_impl(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X, int fill_mode,
-                       float fill_value, int iterations, float* mean_out, int fused_partials);
+                       float fill_value, int iterations, float* mean_out, int fused_partials, int connectivity);
 int fill_mask_buffers(bh_ctx* ctx, int64_t rows, int64_t X, uint32_t** m0, int* W32);
 
 }  // namespace bh
@@ -492,7 +492,7 @@ int bh_deskew(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, i
     }
     if (do_fill) {
         // the deskew kernel already produced the zero mask and the block sums (and skipped storing zeros)
-        BH_TRY(bh::fill_overhang_impl(ctx, out, os[0], os[1], os[2], fill_mode, fill_value, 3, mean_out, nblocks));
+        BH_TRY(bh::fill_overhang_impl(ctx, out, os[0], os[1], os[2], fill_mode, fill_value, 3, mean_out, nblocks, 26));
     } else if (mean_out) {
         *mean_out = 0.0f;
     }

@@ -90,6 +90,38 @@ __global__ void dilate_outer_kernel(const uint32_t* __restrict__ src, uint32_t* 
     }
 }
 
+// `r` iterations of the 6-connected (cross) structuring element = the L1 ball of radius r: a voxel is set when a set voxel
+// lies within |dz| + |dy| + |dx| <= r (SciPy binary_dilation's default structure and border_value 0, which the legacy
+// _fill_overhang_with_mean uses, biahub/deskew.py:277-336).  Per (dz, dy) the row (z + dz, y + dy) is dilated along x by
+// the remaining radius inside its words.  Not separable, ~2 r^2 row reads per word: the legacy path is not a hot one.
+__global__ void dilate_cross_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int64_t nwords, int W32,
+                                    int Y, int Z, int r) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int wi = (int)(i % W32);
+        const int64_t row = i / W32;
+        const int y = (int)(row % Y), z = (int)(row / Y);
+        uint32_t o = 0u;
+        for (int dz = -r; dz <= r; ++dz) {
+            if (z + dz < 0 || z + dz >= Z) continue;
+            const int ry = r - (dz < 0 ? -dz : dz);
+            for (int dy = -ry; dy <= ry; ++dy) {
+                if (y + dy < 0 || y + dy >= Y) continue;
+                const int rx = ry - (dy < 0 ? -dy : dy);
+                const uint32_t* p = src + ((int64_t)(z + dz) * Y + (y + dy)) * W32 + wi;
+                const uint32_t w = p[0];
+                o |= w;
+                if (rx > 0) {
+                    const uint32_t l = wi > 0 ? p[-1] : 0u;
+                    const uint32_t h = wi + 1 < W32 ? p[1] : 0u;
+                    for (int s = 1; s <= rx; ++s) o |= (w << s) | (l >> (32 - s)) | (w >> s) | (h << (32 - s));
+                }
+            }
+        }
+        dst[i] = o;
+    }
+}
+
 // shell sum: voxels in the dilated mask that are not exact zeros; also counts masked voxels
 __global__ __launch_bounds__(256) void shell_kernel(const float* __restrict__ data, const uint32_t* __restrict__ m0,
                                                     const uint32_t* __restrict__ md, double* __restrict__ psum,
@@ -211,7 +243,7 @@ int fill_mask_buffers(bh_ctx* ctx, int64_t rows, int64_t X, uint32_t** m0, int* 
 // fused_partials > 0: the zero mask ("fill_m0") and that many block sums ("fill_pall") were already written by
 // the deskew kernel, which also skipped storing exact zeros; otherwise both come from mask0_kernel here.
 int fill_overhang_impl(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X, int fill_mode, float fill_value,
-                       int iterations, float* mean_out, int fused_partials) {
+                       int iterations, float* mean_out, int fused_partials, int connectivity) {
     BH_REQUIRE(iterations >= 0 && iterations < 32, "dilation_iterations must be in [0,31], got %d", iterations);
     BH_REQUIRE(X < (1ll << 31) && Y < (1ll << 31) && Z < (1ll << 31), "volume too large");
     ScopedTimer timer(ctx, T_FILL);
@@ -237,7 +269,10 @@ int fill_overhang_impl(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X
     const int tb = 256;
     const int gb = (int)std::min<int64_t>(ceil_div(nwords, tb), (int64_t)ctx->num_cus * 16);
     const uint32_t* md = m0;
-    if (iterations > 0) {
+    if (iterations > 0 && connectivity == 6) {
+        hipLaunchKernelGGL(dilate_cross_kernel, dim3(gb), dim3(tb), 0, s, m0, mA, nwords, W32, (int)Y, (int)Z, iterations);
+        md = mA;
+    } else if (iterations > 0) {
         hipLaunchKernelGGL(dilate_x_kernel, dim3(gb), dim3(tb), 0, s, m0, mA, nwords, W32, iterations);
         hipLaunchKernelGGL(dilate_outer_kernel, dim3(gb), dim3(tb), 0, s, mA, mB, nwords, (int64_t)W32, (int)Y,
                            iterations);
@@ -267,5 +302,15 @@ extern "C" int bh_overhang_fill(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, 
     BH_REQUIRE(Z > 0 && Y > 0 && X > 0, "invalid shape");
     BH_REQUIRE(fill_mode == BH_FILL_CONSTANT || fill_mode == BH_FILL_MEAN, "fill_mode must be CONSTANT or MEAN");
     BH_CHECK_HIP(hipSetDevice(ctx->device));
-    return bh::fill_overhang_impl(ctx, data, Z, Y, X, fill_mode, fill_value, dilation_iterations, mean_out, 0);
+    return bh::fill_overhang_impl(ctx, data, Z, Y, X, fill_mode, fill_value, dilation_iterations, mean_out, 0, 26);
+}
+
+extern "C" int bh_overhang_fill_connectivity(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X, int fill_mode,
+                                             float fill_value, int dilation_iterations, int connectivity, float* mean_out) {
+    BH_REQUIRE(ctx != nullptr && data != nullptr, "NULL argument");
+    BH_REQUIRE(Z > 0 && Y > 0 && X > 0, "invalid shape");
+    BH_REQUIRE(fill_mode == BH_FILL_CONSTANT || fill_mode == BH_FILL_MEAN, "fill_mode must be CONSTANT or MEAN");
+    BH_REQUIRE(connectivity == 6 || connectivity == 26, "connectivity must be 6 or 26, got %d", connectivity);
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    return bh::fill_overhang_impl(ctx, data, Z, Y, X, fill_mode, fill_value, dilation_iterations, mean_out, 0, connectivity);
 }

@@ -139,18 +139,21 @@ def deskew_zyx(
 ) -> np.ndarray:
     """numpy-in / numpy-out deskew with the legacy signature (biahub/deskew.py:371-453).
 
-    Runs the production kernel (``fast_deskew_zyx`` semantics).  The reference's legacy body
-    (MONAI 3-D trilinear + 6-connected SciPy dilation) differs from its own production path on
-    the last averaged slab when ``Y % N != 0`` and in the fill connectivity; this entry keeps the
-    signature, shapes and the ``ValueError`` for overhang-only data.
+    Runs the production resampling kernel (``fast_deskew_zyx`` semantics) and then, for ``overhang_fill="mean"`` with
+    ``keep_overhang``, the legacy fill (``_fill_overhang_with_mean``: 6-connected SciPy dilation, :445-450).  The
+    reference's legacy resampler (MONAI 3-D trilinear, absent here) differs from its own production path on the last
+    averaged slab when ``Y % N != 0``; this entry keeps the signature, shapes, fill semantics and the ``ValueError``
+    for overhang-only data.
     """
     if overhang_fill not in ("zero", "mean"):
         raise ValueError(f'overhang_fill must be "zero" or "mean", got {overhang_fill!r}')
     raw = np.asarray(raw_data)
     get_deskewed_data_shape(raw.shape, ls_angle_deg, px_to_scan_ratio, keep_overhang)  # raises first
-    fill = "mean" if overhang_fill == "mean" else 0
-    return _fast_deskew_czyx(raw[None], device=device, ls_angle_deg=ls_angle_deg, px_to_scan_ratio=px_to_scan_ratio,
-                             keep_overhang=keep_overhang, average_n_slices=average_n_slices, overhang_fill=fill)[0]
+    out = _fast_deskew_czyx(raw[None], device=device, ls_angle_deg=ls_angle_deg, px_to_scan_ratio=px_to_scan_ratio,
+                            keep_overhang=keep_overhang, average_n_slices=average_n_slices, overhang_fill=0)[0]
+    if keep_overhang and overhang_fill == "mean":
+        out = _fill_overhang_with_mean(out, device=device)
+    return out
 
 
 def _deskew_czyx(data, **kwargs):
@@ -158,10 +161,12 @@ def _deskew_czyx(data, **kwargs):
     return deskew_zyx(data[0], **kwargs)[None]
 
 
-def fill_overhang(data: torch.Tensor, fill_value: float | None = None, dilation_iterations: int = 3) -> torch.Tensor:
+def fill_overhang(data: torch.Tensor, fill_value: float | None = None, dilation_iterations: int = 3,
+                  connectivity: int = 26) -> torch.Tensor:
     """Replace zero-padded overhang (biahub/deskew.py:339-368 ``_fill_overhang_torch``).
 
-    Returns a new tensor; ``fill_value=None`` uses the mean of the un-masked voxels.
+    Returns a new tensor; ``fill_value=None`` uses the mean of the un-masked voxels.  ``connectivity`` 26 is the
+    production dilation (max_pool3d), 6 the SciPy cross of the legacy ``_fill_overhang_with_mean``.
     """
     t, code, dev = as_device_volume(data)
     if code != _lib.DT_F32:
@@ -171,7 +176,21 @@ def fill_overhang(data: torch.Tensor, fill_value: float | None = None, dilation_
     ctx = get_context(dev)
     mode = _lib.FILL_MEAN if fill_value is None else _lib.FILL_CONSTANT
     with torch.cuda.device(dev):
-        _lib.check(ctx.lib.bh_overhang_fill(ctx.handle, ptr(out), Z, Y, X, mode,
-                                            0.0 if fill_value is None else float(fill_value),
-                                            int(dilation_iterations), None))
+        _lib.check(ctx.lib.bh_overhang_fill_connectivity(ctx.handle, ptr(out), Z, Y, X, mode,
+                                                         0.0 if fill_value is None else float(fill_value),
+                                                         int(dilation_iterations), int(connectivity), None))
     return out
+
+
+def _fill_overhang_with_mean(data: np.ndarray, dilation_iterations: int = 3, debug_plot_path=None,
+                             device="cuda") -> np.ndarray:
+    """Legacy overhang fill, numpy in / numpy out (biahub/deskew.py:277-336): exact zeros, grown by
+    ``dilation_iterations`` steps of SciPy's default (6-connected) structuring element, become the mean of the rest.
+    ``debug_plot_path`` is accepted and ignored (no plotting here)."""
+    a = np.asarray(data)
+    if a.ndim != 3:
+        raise ValueError(f"expected a 3-D volume, got shape {a.shape}")
+    if dilation_iterations < 1:  # SciPy reads iterations < 1 as "until the mask stops changing": everything, mean of nothing
+        raise ValueError("dilation_iterations must be at least 1")
+    t, _, _ = as_device_volume(a.astype(np.float32, copy=False), resolve_device(device))
+    return to_host(fill_overhang(t, None, dilation_iterations, connectivity=6)).astype(a.dtype, copy=False)

@@ -167,6 +167,11 @@ int bh_deskew(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, i
 /* Stand-alone overhang fill on an already deskewed float32 volume, in place. */
 int bh_overhang_fill(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X, int fill_mode,
                      float fill_value, int dilation_iterations, float* mean_out);
+/* Same with the structuring element chosen: connectivity 26 (the production path above, torch max_pool3d) or 6 (SciPy's
+ * default cross, what the legacy biahub/deskew.py:277-336 _fill_overhang_with_mean dilates with: `iterations` steps = the
+ * L1 ball of that radius). */
+int bh_overhang_fill_connectivity(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X, int fill_mode,
+                                  float fill_value, int dilation_iterations, int connectivity, float* mean_out);
 
 /* ---- deconvolution ----------------------------------------------------------------- */
 /* tf_full: float32 (Z,Y,X) = |FFT(zero-padded psf)| / max, full spectrum like the reference. */

@@ -17,6 +17,7 @@ Fixtures written:
   transfer_function.npz   compute_tranfser_function (odd/even psf x odd/even volume)
   transform_scipy.npz     core.transform.Transform.apply (SciPy), orders 0/1
   phase_cross_corr.npz    estimate_stabilization.phase_cross_corr (three normalisations)
+  legacy_fill.npz         deskew._fill_overhang_with_mean (legacy 6-connected SciPy dilation)
   concatenate.json        biahub.concatenate slicing/channel-layout helpers, ConcatenateSettings validation
   helpers.json            settings dumps, fingerprints, estimate_resources, output paths,
                           sbatch parsing, matrix builders
@@ -157,6 +158,28 @@ def binning_vectors():
     print("binning.npz written")
 
 
+def legacy_fill_vectors():
+    """biahub.deskew._fill_overhang_with_mean (legacy path, SciPy 6-connected dilation) -> legacy_fill.npz."""
+    from biahub.deskew import _fill_overhang_with_mean
+
+    rng = np.random.default_rng(31)
+    out = {}
+    for j, (shape, it) in enumerate((((12, 20, 70), 3), ((9, 33, 41), 2), ((20, 16, 130), 3), ((6, 6, 6), 1), ((10, 12, 14), 5))):
+        v = (rng.random(shape) * 200 + 50).astype(np.float32)
+        # overhang-like wedges of exact zeros at both ends of x, plus isolated zeros inside the signal
+        for z in range(shape[0]):
+            w = int(shape[2] * 0.3 * z / max(1, shape[0] - 1))
+            v[z, :, :w] = 0
+            v[shape[0] - 1 - z, :, shape[2] - w:] = 0
+        idx = tuple(rng.integers(0, n, 5) for n in shape)
+        v[idx] = 0
+        out[f"in{j}"] = v
+        out[f"it{j}"] = np.array(it)
+        out[f"out{j}"] = _fill_overhang_with_mean(v, dilation_iterations=it)
+    np.savez_compressed(HERE / "legacy_fill.npz", **out)
+    print("legacy_fill.npz written")
+
+
 def concatenate_vectors():
     """biahub.concatenate helpers + ConcatenateSettings validation -> concatenate.json.  The one reference function that
     opens stores (get_channel_combiner_metadata) is pointed at biahub_amd's reader through the module attribute it looks
@@ -239,6 +262,10 @@ def concatenate_vectors():
 
 
 def main():
+    if sys.argv[1:] == ["legacy_fill"]:
+        load_reference()
+        legacy_fill_vectors()
+        return 0
     if sys.argv[1:] == ["concatenate"]:
         load_reference()
         concatenate_vectors()

@@ -244,6 +244,35 @@ def test_richardson_lucy_radix3_columns_fused(gpu, shape, pshape, monkeypatch):
     assert rel_err(got, lib) <= FFT_TOL
 
 
+def test_legacy_fill_overhang_with_mean(gpu):
+    """deskew._fill_overhang_with_mean (legacy path: exact zeros grown by SciPy's 6-connected structuring element) against
+    the reference's outputs: the same voxels are filled (bit-exact mask), the mean agrees to float32 rounding."""
+    from biahub_amd.deskew import _fill_overhang_with_mean, fill_overhang
+
+    z = np.load(GOLDEN / "legacy_fill.npz")
+    for j in range(5):
+        vol, it, want = z[f"in{j}"], int(z[f"it{j}"]), z[f"out{j}"]
+        got = _fill_overhang_with_mean(vol, dilation_iterations=it)
+        changed_w, changed_g = want != vol, got != vol
+        assert np.array_equal(changed_w, changed_g), j                      # same dilated mask
+        assert np.array_equal(got[~changed_g], vol[~changed_g])
+        fill_w, fill_g = want[changed_w], got[changed_g]
+        assert np.all(fill_g == fill_g[0]) and abs(float(fill_g[0]) - float(fill_w[0])) <= 2e-6 * abs(float(fill_w[0])), j
+        # the production structuring element (26-connected) masks more: the two are different on purpose
+        prod = fill_overhang(torch.from_numpy(vol).to(gpu), None, it).cpu().numpy()
+        assert (prod != vol).sum() >= changed_g.sum()
+    with pytest.raises(ValueError):
+        _fill_overhang_with_mean(z["in0"], dilation_iterations=0)
+    # the legacy entry point composes the production resampler with the legacy fill (biahub/deskew.py:445-450)
+    from biahub_amd.deskew import deskew_zyx
+
+    raw = O.synthetic_volume((20, 14, 9), seed=3, n_blobs=4) + 50
+    zero = deskew_zyx(raw, 36.17, 0.371, True, average_n_slices=2, overhang_fill="zero")
+    mean = deskew_zyx(raw, 36.17, 0.371, True, average_n_slices=2, overhang_fill="mean")
+    assert np.array_equal(zero, O.fast_deskew_zyx(raw, 36.17, 0.371, True, 2, 0).astype(np.float32)) or rel_err(zero, O.fast_deskew_zyx(raw, 36.17, 0.371, True, 2, 0)) <= 1e-5
+    assert rel_err(mean, O.fill_overhang_with_mean(zero, 3)) <= 1e-6
+
+
 # ----------------------------------------------------------------------------- affine
 def test_affine_reference_tests(gpu):
     """tests/test_affine.py:26-59 of the reference, verbatim expectations."""

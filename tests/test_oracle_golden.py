@@ -187,3 +187,12 @@ def test_binning_golden():
         kw = json.loads(str(z[f"kw{j}"]))
         got = O.binning_czyx(z[f"in{j}"], tuple(kw["binning_factor_zyx"]), kw["mode"])
         assert got.dtype == z[f"out{j}"].dtype and np.array_equal(got, z[f"out{j}"]), j
+
+
+def test_legacy_fill_overhang_with_mean_matches_reference():
+    """oracle fill_overhang_with_mean (SciPy 6-connected dilation) against the reference's _fill_overhang_with_mean."""
+    z = np.load(GOLDEN / "legacy_fill.npz")
+    for j in range(5):
+        got = O.fill_overhang_with_mean(z[f"in{j}"], int(z[f"it{j}"]))
+        assert np.array_equal(got, z[f"out{j}"]), j
+
