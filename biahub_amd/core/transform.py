@@ -64,6 +64,28 @@ class Transform:
         m[:-1, -1] = offset
         return cls(m, "translation")
 
+    @classmethod
+    def from_skimage(cls, skimage_transform, ndim: int = 3) -> "Transform":
+        """From a scikit-image geometric transform (anything with a ``.params`` homogeneous matrix), core/transform.py:
+        169-227: the type comes from the class name; a 2-D transform asked for in 3-D acts in the YX plane, Z untouched."""
+        params = np.asarray(skimage_transform.params)
+        name = type(skimage_transform).__name__.lower()
+        kind = next((k for k in ("euclidean", "similarity", "affine") if k in name), "affine")
+        if params.shape == (3, 3):
+            if ndim == 2:
+                return cls(params, transform_type=kind)
+            if ndim == 3:
+                m = np.eye(4, dtype=np.float64)
+                m[1:3, 1:3] = params[:2, :2]
+                m[1:3, 3] = params[:2, 2]
+                return cls(m, transform_type=kind)
+            return None  # the reference falls through for other ndim
+        if params.shape == (4, 4):
+            if ndim == 3:
+                return cls(params, transform_type=kind)
+            raise ValueError("Cannot convert 3D skimage transform to 2D")
+        raise ValueError(f"Unexpected skimage transform shape: {params.shape}")
+
     # -- algebra (core/transform.py:231-298) ----------------------------------------------
     def invert(self) -> "Transform":
         return Transform(np.linalg.inv(self._matrix), self._transform_type)
@@ -149,7 +171,10 @@ class Transform:
         return cls(np.array(data["matrix"]), data.get("transform_type", "affine"))
 
     def __repr__(self) -> str:
-        return f"Transform(ndim={self._ndim}, type={self._transform_type})"
+        return f"Transform(ndim={self._ndim}, type='{self._transform_type}', translation={self.translation.round(3).tolist()})"
+
+    def __str__(self) -> str:
+        return f"Transform({self._transform_type}, {self._ndim}D)\n" + np.array2string(self._matrix, precision=4, suppress_small=True)
 
     def __eq__(self, other) -> bool:
         return isinstance(other, Transform) and np.allclose(self._matrix, other._matrix)
