@@ -43,6 +43,9 @@ SIGNATURES = {
     "bh_flat_field": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, C.POINTER(_f64)]),
     "bh_bin_reduce": (_int, [_vp, _vp, _int, _i64, _i64, _i64, C.POINTER(_int), _int, _vp, C.POINTER(_f32)]),
     "bh_bin_finish": (_int, [_vp, _vp, _i64, _int, _f32, _f32, _f32, _int, _vp]),
+    "bh_valid_mask": (_int, [_vp, _vp, _int, _i64, _vp, C.POINTER(C.c_uint64)]),
+    "bh_bits_and": (_int, [_vp, _vp, _vp, _i64]),
+    "bh_bits_unpack": (_int, [_vp, _vp, _i64, _vp]),
     "bh_blosc_unfilter": (_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _int]),
     "bh_blosc_filter": (_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _int]),
     "bh_host_blosc_unfilter": (_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _int]),

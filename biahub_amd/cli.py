@@ -599,6 +599,23 @@ def concatenate_cli(config_filepath, output_dirpath, sbatch_filepath, cluster, m
     parallel.barrier()
 
 
+@cli.command("estimate-crop")
+@_config
+@click.option("--output-filepath", "-o", required=True, type=click.Path(path_type=Path), help="Path to the output YAML config")
+@click.option("--lf-mask-radius", type=float, default=0.95,
+              help="Radius of the circular mask, as a fraction of the image width, applied to the phase channel.")
+@click.option("--sbatch-filepath", "-sb", default=None, type=click.Path(exists=True), help="Accepted for compatibility.")
+@click.option("--local", "-l", is_flag=True, default=False, help="Accepted for compatibility: this build always runs in-process.")
+def estimate_crop_cli(config_filepath, output_filepath, lf_mask_radius, sbatch_filepath, local):
+    """Estimate the crop in which both the phase and the fluorescence volumes carry data, and write it into a copy of the
+    concatenate configuration (reference: ``biahub estimate-crop``, biahub/estimate_crop.py:285-320)."""
+    from .estimate_crop import estimate_crop
+
+    if sbatch_filepath:
+        sbatch_to_submitit(sbatch_filepath)
+    estimate_crop(config_filepath, output_filepath, lf_mask_radius=lf_mask_radius)
+
+
 @cli.command("flip")
 @click.option("--input-position-dirpaths", "-i", multiple=True, required=True, callback=_positions)
 @click.option("-x", is_flag=True, help="Flip along x.")

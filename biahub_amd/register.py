@@ -124,16 +124,16 @@ def find_lir(registered_zyx: np.ndarray, plot: bool = False) -> tuple:
     """Largest interior cuboid of a registered mask, the reference's heuristic (register.py:284-342): LIR of the
     mid-Z YX plane, then the Z extent common to six probe ZY / ZX slices through that rectangle."""
     reg = np.asarray(registered_zyx, dtype=bool)
-    x, y, width, height = largest_interior_rectangle(reg[reg.shape[0] // 2])
+    x, y, width, height = (int(v) for v in largest_interior_rectangle(reg[reg.shape[0] // 2]))
     x_start, x_stop, y_start, y_stop = x, x + width, y, y + height
     x_slice, y_slice = slice(x_start, x_stop), slice(y_start, y_stop)
     spans = []
     for _x in (x_start, x_start + (x_stop - x_start) // 2, x_stop - 1):
         _, z, _, depth = largest_interior_rectangle(reg[:, y_slice, _x])
-        spans.append((z, z + depth))
+        spans.append((int(z), int(z + depth)))
     for _y in (y_start, y_start + (y_stop - y_start) // 2, y_stop - 1):
         _, z, _, depth = largest_interior_rectangle(reg[:, _y, x_slice])
-        spans.append((z, z + depth))
+        spans.append((int(z), int(z + depth)))
     spans = np.asarray(spans)
     return slice(int(spans[:, 0].max()), int(spans[:, 1].min())), y_slice, x_slice
 

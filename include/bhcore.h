@@ -11,6 +11,8 @@
  *                          <- biahub/flat_field.py:101-120 flat_field_zyx, :56-99 _median_tiled (np.median, axis 0)
  *   bh_bin_reduce, bh_bin_finish
  *                          <- biahub/process_data.py:29-105 binning_czyx
+ *   bh_valid_mask, bh_bits_and, bh_bits_unpack
+ *                          <- biahub/estimate_crop.py:58-94 estimate_crop_one_position (masks, counts, their AND)
  *   bh_blosc_unfilter, bh_blosc_filter
  *                          <- (upstream of the reference) the chunk compressor of the OME-Zarr stores iohub 0.3.11 reads and
  *                             writes for biahub/deskew.py:608-640,738-749: numcodecs 0.15.1 Blosc (uv.lock:3160-3161) =
@@ -131,6 +133,15 @@ int bh_bin_reduce(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t 
  * ndarray.astype; out_dtype is one of the BH_DT_* codes. */
 int bh_bin_finish(bh_ctx* ctx, const float* v, int64_t n, int apply, float sub, float mul, float div, int out_dtype,
                   void* out);
+
+/* ---- validity masks (crop estimation, biahub/estimate_crop.py:58-94) -------------------- */
+/* bits: ceil(n / 64) * 2 words on the device; voxel i -> bit i % 32 of word i / 32, set when the voxel is neither 0 nor
+ * NaN; count = number of set bits (synchronises the stream). */
+int bh_valid_mask(bh_ctx* ctx, const void* vol, int dtype, int64_t n, uint32_t* bits, uint64_t* count);
+/* acc &= src, word-wise */
+int bh_bits_and(bh_ctx* ctx, uint32_t* acc, const uint32_t* src, int64_t nwords);
+/* out[i] = bit i of bits (one byte per voxel) */
+int bh_bits_unpack(bh_ctx* ctx, const uint32_t* bits, int64_t n, uint8_t* out);
 
 /* ---- chunk codec: the byte permutations of the Blosc-1 container ---------------------- */
 #define BH_BLOSC_NOSHUFFLE 0

@@ -17,6 +17,7 @@ Fixtures written:
   transfer_function.npz   compute_tranfser_function (odd/even psf x odd/even volume)
   transform_scipy.npz     core.transform.Transform.apply (SciPy), orders 0/1
   phase_cross_corr.npz    estimate_stabilization.phase_cross_corr (three normalisations)
+  estimate_crop.npz       estimate_crop.estimate_crop_one_position on in-memory arrays (LIR from biahub_amd's restatement)
   legacy_fill.npz         deskew._fill_overhang_with_mean (legacy 6-connected SciPy dilation)
   concatenate.json        biahub.concatenate slicing/channel-layout helpers, ConcatenateSettings validation
   helpers.json            settings dumps, fingerprints, estimate_resources, output paths,
@@ -158,6 +159,80 @@ def binning_vectors():
     print("binning.npz written")
 
 
+def estimate_crop_vectors():
+    """biahub.estimate_crop.estimate_crop_one_position -> estimate_crop.npz.  The reference reads stores through iohub/dask
+    and takes the largest interior rectangle from a library this image lacks: it is pointed at in-memory arrays (an ndarray
+    subclass with .compute()) and at biahub_amd.register's restatement of `lir`, so the fixture pins everything but that."""
+    import biahub.estimate_crop as rc
+    import biahub.register as rr
+    from biahub_amd.register import largest_interior_rectangle
+
+    class Lazy(np.ndarray):
+        def compute(self):
+            return np.asarray(self)
+
+    class _Lir:
+        @staticmethod
+        def lir(mask):
+            return np.array(largest_interior_rectangle(mask))
+
+    rr.lir = _Lir
+    rc.da.isnan = lambda a: np.isnan(a).view(Lazy)
+    store = {}
+
+    class _Data:
+        def __init__(self, a):
+            self._a = a
+
+        def dask_array(self):
+            return self._a.view(Lazy)
+
+    class _Pos:
+        def __init__(self, path):
+            self.data = _Data(store[str(path)])
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    rc.open_ome_zarr = _Pos
+    rng = np.random.default_rng(17)
+
+    def dataset(T, C, shape, box, dtype, nan=False):
+        a = np.zeros((T, C) + shape, dtype=dtype)
+        (z0, z1), (y0, y1), (x0, x1) = box
+        a[:, :, z0:z1, y0:y1, x0:x1] = (rng.random((T, C, z1 - z0, y1 - y0, x1 - x0)) * 100 + 1).astype(dtype)
+        if nan:
+            a[:, :, z0:z0 + 1, y0:y1, x0:x1] = np.nan
+        return a
+
+    cases = []
+    # same shapes would hit the reference's undefined `_max_zyx_dims` when a mask radius is given, so every case with a
+    # radius has different shapes; equal shapes are covered without radius
+    lf = dataset(3, 2, (10, 30, 34), ((1, 9), (3, 27), (4, 31)), np.float32)
+    ls = dataset(3, 1, (10, 30, 34), ((2, 10), (0, 25), (6, 34)), np.float32, nan=True)
+    ls[1] = 0  # an empty time point: its count is far from the median and it is left out
+    cases.append((lf, ls, None))
+    lf2 = dataset(2, 1, (8, 40, 40), ((0, 8), (0, 40), (0, 40)), np.float32)
+    ls2 = dataset(2, 2, (9, 38, 44), ((1, 8), (2, 36), (5, 40)), np.uint16)
+    cases.append((lf2, ls2, 0.9))
+    cases.append((lf2, ls2, None))
+    lf3 = dataset(2, 1, (6, 24, 36), ((0, 6), (0, 24), (0, 36)), np.uint16)
+    ls3 = dataset(2, 1, (7, 26, 36), ((0, 7), (1, 25), (2, 33)), np.uint16)
+    cases.append((lf3, ls3, 0.8))
+    out = {}
+    for j, (a, b, radius) in enumerate(cases):
+        store["p/A/1/0"], store["q/A/1/0"] = a, b
+        res = rc.estimate_crop_one_position(Path("p/A/1/0"), Path("q/A/1/0"), lf_mask_radius=radius, output_dir=None)
+        out[f"lf{j}"], out[f"ls{j}"] = a, b
+        out[f"radius{j}"] = np.array(np.nan if radius is None else radius)
+        out[f"crop{j}"] = np.array(res)
+    np.savez_compressed(HERE / "estimate_crop.npz", **out)
+    print("estimate_crop.npz written", [out[f"crop{j}"].tolist() for j in range(len(cases))])
+
+
 def legacy_fill_vectors():
     """biahub.deskew._fill_overhang_with_mean (legacy path, SciPy 6-connected dilation) -> legacy_fill.npz."""
     from biahub.deskew import _fill_overhang_with_mean
@@ -262,6 +337,10 @@ def concatenate_vectors():
 
 
 def main():
+    if sys.argv[1:] == ["estimate_crop"]:
+        load_reference()
+        estimate_crop_vectors()
+        return 0
     if sys.argv[1:] == ["legacy_fill"]:
         load_reference()
         legacy_fill_vectors()

@@ -273,6 +273,87 @@ def test_legacy_fill_overhang_with_mean(gpu):
     assert rel_err(mean, O.fill_overhang_with_mean(zero, 3)) <= 1e-6
 
 
+def test_valid_mask_kernels_bit_exact(gpu):
+    """bh_valid_mask / bh_bits_and / bh_bits_unpack against NumPy: (v != 0) & ~isnan(v), popcount, AND."""
+    from biahub_amd.estimate_crop import _unpack, valid_mask_device
+    from biahub_amd.device import get_context, ptr
+
+    rng = np.random.default_rng(8)
+    ctx = get_context(gpu)
+    for dt, n in ((np.float32, 100_003), (np.uint16, 64 * 500), (np.uint8, 77), (np.int16, 4099), (np.float64, 1000)):
+        a = (rng.random(n) * 10 - 3).astype(dt)
+        a[rng.random(n) < 0.3] = 0
+        if np.dtype(dt).kind == "f":
+            a[rng.random(n) < 0.1] = np.nan
+            a[5] = -0.0
+        want = (a != 0) & ~np.isnan(a) if np.dtype(dt).kind == "f" else a != 0
+        bits, count = valid_mask_device(a, gpu)
+        assert count == int(want.sum()), dt
+        assert np.array_equal(_unpack(bits, (n,), gpu).cpu().numpy().astype(bool), want), dt
+        other = rng.random(n) < 0.5
+        obits, _ = valid_mask_device(other.astype(np.uint8), gpu)
+        _lib_and = ctx.lib.bh_bits_and(ctx.handle, ptr(bits), ptr(obits), bits.numel())
+        assert _lib_and == 0
+        assert np.array_equal(_unpack(bits, (n,), gpu).cpu().numpy().astype(bool), want & other), dt
+
+
+def test_estimate_crop_golden_and_cli(gpu, tmp_path):
+    """estimate_crop_one_position on stores holding the fixture's arrays gives the reference's crops; the command merges
+    positions (largest start, smallest stop) into the concatenate configuration it writes."""
+    import yaml
+    from click.testing import CliRunner
+
+    from biahub_amd import io
+    from biahub_amd.cli import cli
+    from biahub_amd.estimate_crop import estimate_crop_one_position, standardize_ranges
+
+    z = np.load(GOLDEN / "estimate_crop.npz")
+    crops = []
+    for j in range(4):
+        radius = None if np.isnan(z[f"radius{j}"]) else float(z[f"radius{j}"])
+        for name, arr in (("lf", z[f"lf{j}"]), ("ls", z[f"ls{j}"])):
+            dt = np.float32 if arr.dtype.kind == "f" else arr.dtype
+            io.create_empty_plate(tmp_path / f"{name}{j}.zarr", [("A", "1", "0")], [f"c{k}" for k in range(arr.shape[1])], arr.shape,
+                                  dtype=dt, compressor="blosc")
+            pos = io.open_ome_zarr(tmp_path / f"{name}{j}.zarr/A/1/0")
+            for t in range(arr.shape[0]):
+                for c in range(arr.shape[1]):
+                    pos.data[t, c] = arr[t, c]
+        got = estimate_crop_one_position(tmp_path / f"lf{j}.zarr/A/1/0", tmp_path / f"ls{j}.zarr/A/1/0", lf_mask_radius=radius)
+        assert np.array_equal(np.array(got), z[f"crop{j}"]), (j, got)
+        crops.append(got)
+    assert standardize_ranges([crops[1], crops[2]]).tolist() == [[1, 8, 7], [8, 33, 32]]
+    # the command: two positions per dataset (cases 1 and 2 share their arrays, case 2 has no radius -> run with one radius)
+    for name in ("lf", "ls"):
+        arr = z[f"{name}1"]
+        io.create_empty_plate(tmp_path / f"{name}.zarr", [("A", "1", "0"), ("B", "1", "0")], [f"c{k}" for k in range(arr.shape[1])],
+                              arr.shape, dtype=np.float32 if arr.dtype.kind == "f" else arr.dtype)
+        for key, shift in (("A/1/0", 0), ("B/1/0", 3)):
+            pos = io.open_ome_zarr(tmp_path / f"{name}.zarr" / key)
+            for t in range(arr.shape[0]):
+                for c in range(arr.shape[1]):
+                    v = arr[t, c].copy()
+                    if name == "lf" and shift:
+                        v[:2, :, :] = 0  # the second position's phase volume starts two planes later
+                    pos.data[t, c] = v
+    cfg = tmp_path / "concat.yml"
+    cfg.write_text(yaml.safe_dump({"concat_data_paths": ["lf.zarr/*/*/*", "ls.zarr/*/*/*"], "channel_names": ["all", "all"]}))
+    out = tmp_path / "out" / "concat_cropped.yml"
+    out.parent.mkdir()
+    r = CliRunner().invoke(cli, ["estimate-crop", "-c", str(cfg), "-o", str(out), "--lf-mask-radius", "0.9"])
+    assert r.exit_code == 0, (r.output, r.exception)
+    res = yaml.safe_load(out.read_text())
+    a = O.estimate_crop_arrays(z["lf1"], z["ls1"], 0.9, __import__("biahub_amd.register", fromlist=["find_lir"]).find_lir)
+    lf_b = z["lf1"].copy()
+    lf_b[:, :, :2] = 0
+    b = O.estimate_crop_arrays(lf_b, z["ls1"], 0.9, __import__("biahub_amd.register", fromlist=["find_lir"]).find_lir)
+    assert b[0][0] == 2 and a[0][0] == 1
+    want = standardize_ranges([a, b])
+    assert (res["Z_slice"], res["Y_slice"], res["X_slice"]) == (want[:, 0].tolist(), want[:, 1].tolist(), want[:, 2].tolist())
+    assert res["concat_data_paths"] == ["lf.zarr/*/*/*", "ls.zarr/*/*/*"] and (out.parent / "crop_slices.csv").exists()
+    assert not (out.parent / "crop_estimates").exists()
+
+
 # ----------------------------------------------------------------------------- affine
 def test_affine_reference_tests(gpu):
     """tests/test_affine.py:26-59 of the reference, verbatim expectations."""

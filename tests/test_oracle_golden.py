@@ -222,3 +222,14 @@ def test_transform_from_skimage_and_text():
     with pytest.raises(ValueError, match="Unexpected skimage transform shape"):
         Transform.from_skimage(Odd(), ndim=3)
 
+
+def test_estimate_crop_oracle_matches_reference():
+    """oracle estimate_crop_arrays against the reference's estimate_crop_one_position (fixture made with the same LIR)."""
+    from biahub_amd.register import find_lir
+
+    z = np.load(GOLDEN / "estimate_crop.npz")
+    for j in range(4):
+        radius = None if np.isnan(z[f"radius{j}"]) else float(z[f"radius{j}"])
+        got = O.estimate_crop_arrays(z[f"lf{j}"], z[f"ls{j}"], radius, find_lir)
+        assert np.array_equal(np.array(got), z[f"crop{j}"]), (j, got)
+
