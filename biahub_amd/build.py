@@ -27,7 +27,7 @@ def needs_build() -> bool:
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.hpp", INCLUDE / "bhcore.h"]
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.hpp", CSRC / "fftconv_xpass.inc", INCLUDE / "bhcore.h"]
     return any(d.stat().st_mtime > t for d in deps)
 
 

@@ -40,14 +40,8 @@ constexpr int FC_TILE = 16384;     // complex elements per column tile (128 KiB)
 #ifndef BH_FC_XNT
 #define BH_FC_XNT BH_FC_NT
 #endif
-constexpr int FC_XR = BH_FC_XR;    // rows per X-pass tile (FC_XH row pairs y, y + Y/2); a power of two
-constexpr int FC_XH = FC_XR / 2;
-constexpr int FC_LOGXR = FC_XR == 16 ? 4 : (FC_XR == 8 ? 3 : (FC_XR == 4 ? 2 : 1));
-constexpr int FC_LOGXH = FC_LOGXR - 1;
-constexpr int FC_XPITCH = FC_XR + 1;
 constexpr int FC_XNT = BH_FC_XNT;  // threads per workgroup of the X passes
 static_assert(FC_XNT >= 512 && FC_XNT <= 1024, "an X-pass thread owns one complex pair of a row: X/4 <= 512 threads per row");
-static_assert(FC_XR == 2 || FC_XR == 4 || FC_XR == 8 || FC_XR == 16, "FC_XR must be a power of two");
 #ifndef BH_FC_R16
 #define BH_FC_R16 0
 #endif
@@ -685,360 +679,6 @@ struct XParams {
     float eps;
 };
 
-// tile = (z, group g): rows c < XH -> y = XH g + c ; rows c >= XH -> y = XH g + (c - XH) + Y/2   (XH = FC_XH).
-// row0 = z * Y + XH g is computed ONCE per tile (a 64-bit division per row load costs more than the FFT's index math).
-__device__ __forceinline__ long x_tile_row0(const ConvDims& d, long tile) {
-    const int gpz = d.Y / FC_XR;  // groups per z
-    const int ti = (int)tile;     // host guarantees < 2^31 tiles
-    const int z = ti / gpz;
-    const int g = ti - z * gpz;
-    return (long)z * d.Y + FC_XH * g;
-}
-__device__ __forceinline__ long x_row_index(const ConvDims& d, long row0, int c) {
-    return row0 + (c & (FC_XH - 1)) + ((c >> FC_LOGXH) ? d.Y / 2 : 0);
-}
-// 32-bit element offset of (tile row c, column col) from the tile's first row, for a row pitch `pitch`
-// ((Y/2 + 8) * pitch < 2^31 for every supported shape)
-__device__ __forceinline__ unsigned x_row_off(const ConvDims& d, int c, int pitch, int col) {
-    return (unsigned)(((c & (FC_XH - 1)) + ((c >> FC_LOGXH) ? d.Y / 2 : 0)) * pitch + col);
-}
-// opaque copy of a per-thread value: address math built on it stays inside the tile loop instead of being
-// hoisted into (scarce) registers for the whole kernel
-__device__ __forceinline__ int opaque(int v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
-// untangle in place after the packed length-M FFT: pairs (p, mirror(p)); u = 0 handles DC + Nyquist and p = 1
-// R3: M = 3 L and the spectrum sits in thirds (frequency 3 j + t in third t at the bit-reversed j).  Third 0 mirrors into
-// itself exactly like a length-L power-of-two transform (frequency M - 3 j = 3 (L - j)); thirds 1 and 2 mirror into each
-// other with complemented positions (M - (3 j + 1) = 3 (L - 1 - j) + 2, and brev(L - 1 - j) = L - 1 - brev(j)).
-template <bool INV, bool R3 = false>
-__device__ __forceinline__ void untangle_lds(cf* buf, const cf* ut, int M, int tid, int L = 0) {
-    for (int idx = tid; idx < (M >> 1) * FC_XR; idx += FC_XNT) {
-        const int c = idx % FC_XR;
-        const int u = idx / FC_XR;
-        if (u == 0) {
-            if (!INV) {
-                const cf z0 = buf[c];
-                buf[c] = make_float2(z0.x + z0.y, 0.0f);                          // X[0]
-                buf[(size_t)M * FC_XPITCH + c] = make_float2(z0.x - z0.y, 0.0f);  // X[M] (Nyquist)
-            } else {
-                const float x0 = buf[c].x, xm = buf[(size_t)M * FC_XPITCH + c].x;
-                buf[c] = make_float2(0.5f * (x0 + xm), 0.5f * (x0 - xm));
-            }
-            buf[FC_XPITCH + c] = cconj(buf[FC_XPITCH + c]);  // k = M/2: w^k = -i
-        } else {
-            int pp, pm;
-            if (R3 && u >= (L >> 1)) {
-                const int r = u - (L >> 1);  // < L
-                pp = L + r;
-                pm = 3 * L - 1 - r;
-            } else {
-                const int top = 31 - __clz(u);
-                pp = (2 << top) + (u - (1 << top));
-                pm = 3 * (2 << top) - 1 - pp;
-            }
-            const cf a = buf[(size_t)pp * FC_XPITCH + c], b = buf[(size_t)pm * FC_XPITCH + c];
-            const cf E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));   // (a + conj b)/2
-            const cf Dm = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));  // (a - conj b)/2
-            if (!INV) {
-                // X[k] = E + w^k O, O = -i (a - conj b)/2 ; X[M-k] = conj(E - w^k O)
-                const cf wO = cmul(ut[pp], mul_mi(Dm));
-                buf[(size_t)pp * FC_XPITCH + c] = cadd(E, wO);
-                buf[(size_t)pm * FC_XPITCH + c] = cconj(csub(E, wO));
-            } else {
-                // Zf[k] = E + i O, O = (X[k] - conj X[M-k])/2 conj(w^k) ; Zf[M-k] = conj(E - i O)
-                const cf iO = mul_pi(cmulc(Dm, ut[pp]));
-                buf[(size_t)pp * FC_XPITCH + c] = cadd(E, iO);
-                buf[(size_t)pm * FC_XPITCH + c] = cconj(csub(E, iO));
-            }
-        }
-    }
-}
-
-// Forward tail shared by x_fwd_kernel and the fused inverse->forward kernel: the tile's 16 packed rows are in
-// LDS (buf[n][c], natural order); FFT, untangle, Y radix-2 step across the row pairs, store the spectrum rows.
-template <int ROUNDS, bool R3 = false>
-__device__ __forceinline__ void x_forward_from_lds(cf* buf, const cf* tw, const cf* ut, const XParams& p,
-                                                   const ConvDims& d, long t, int tid, int q, int rr, int RPR,
-                                                   bool active = true) {
-    const int M = d.M;
-    constexpr int HALF = ROUNDS / 2;
-    if (R3) {
-        radix3_step<false, 1, FC_XNT>(buf, d.Lm, FC_LOGXR, FC_XPITCH, ut + M, tid);
-        __syncthreads();
-        fft_lds<false, 2, 1, FC_R16, false, FC_XNT>(buf, d.Lm, d.logM, FC_LOGXR, FC_XPITCH, tw, tid, M);
-    } else {
-        fft_lds<false, 2, 1, FC_R16, false, FC_XNT>(buf, M, d.logM, FC_LOGXR, FC_XPITCH, tw, tid);
-    }
-    untangle_lds<false, R3>(buf, ut, M, tid, d.Lm);
-    __syncthreads();
-
-    // Y radix-2 step across each row pair, then store the spectrum rows
-    const int gpz = d.Y / FC_XR;
-    const int z = (int)t / gpz;
-    const int g = (int)t - z * gpz;
-    if (ROUNDS >= 2) {
-        // this thread's rounds u and u + HALF are exactly a pair (y, y + Y/2): two columns per lane, 16-B stores
-#pragma unroll
-        for (int u = 0; u < (HALF > 0 ? HALF : 1); ++u) {
-            if (R3 && !active) break;
-            const int c = rr + u * RPR;  // < FC_XH
-            const int y = FC_XH * g + c;
-            const cf w = p.twy[y];
-            const cf xa0 = buf[(size_t)(2 * q) * FC_XPITCH + c], xb0 = buf[(size_t)(2 * q) * FC_XPITCH + c + FC_XH];
-            const cf xa1 = buf[(size_t)(2 * q + 1) * FC_XPITCH + c], xb1 = buf[(size_t)(2 * q + 1) * FC_XPITCH + c + FC_XH];
-            const cf A0 = cadd(xa0, xb0), A1 = cadd(xa1, xb1);
-            const cf B0 = cmul(csub(xa0, xb0), w), B1 = cmul(csub(xa1, xb1), w);
-            cf* rowA = p.S + ((long)z * d.Y + y) * d.XP + 2 * q;
-            cf* rowB = rowA + (long)(d.Y / 2) * d.XP;
-            *reinterpret_cast<float4*>(rowA) = make_float4(A0.x, A0.y, A1.x, A1.y);
-            *reinterpret_cast<float4*>(rowB) = make_float4(B0.x, B0.y, B1.x, B1.y);
-        }
-        if (tid < FC_XH * 16) {  // Nyquist column + zero pad columns
-            const int rp = tid >> 4, col = M + (tid & 15);
-            const int y = FC_XH * g + rp;
-            cf A = make_float2(0.f, 0.f), B = A;
-            if (col == M) {
-                const cf xa = buf[(size_t)M * FC_XPITCH + rp], xb = buf[(size_t)M * FC_XPITCH + rp + FC_XH];
-                A = cadd(xa, xb);
-                B = cmul(csub(xa, xb), p.twy[y]);
-            }
-            p.S[((long)z * d.Y + y) * d.XP + col] = A;
-            p.S[((long)z * d.Y + y + d.Y / 2) * d.XP + col] = B;
-        }
-    } else {
-        for (int idx = tid; idx < FC_XH * d.XP; idx += FC_XNT) {
-            const int pcol = idx % d.XP;
-            const int rp = idx / d.XP;
-            const int y = FC_XH * g + rp;
-            cf A = make_float2(0.f, 0.f), B = A;
-            if (pcol <= M) {
-                const cf xa = buf[(size_t)pcol * FC_XPITCH + rp], xb = buf[(size_t)pcol * FC_XPITCH + rp + FC_XH];
-                A = cadd(xa, xb);
-                B = cmul(csub(xa, xb), p.twy[y]);
-            }
-            p.S[((long)z * d.Y + y) * d.XP + pcol] = A;
-            p.S[((long)z * d.Y + y + d.Y / 2) * d.XP + pcol] = B;
-        }
-    }
-}
-
-template <int ROUNDS, bool R3 = false>
-__global__ __launch_bounds__(FC_XNT) void x_fwd_kernel(XParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const ConvDims d = p.d;
-    const int M = d.M;
-    cf* buf = reinterpret_cast<cf*>(smem);                                  // [(M + 1)][17]
-    cf* tw = buf + (size_t)(M + 1) * FC_XPITCH;
-    cf* ut = tw + p.ntw;                                                    // [M]
-    const int tid = threadIdx.x;
-    for (int i = tid; i < p.ntw; i += FC_XNT) tw[i] = p.tw[i];
-    for (int i = tid; i < M; i += FC_XNT) ut[i] = p.untangle[i];
-    if (R3)
-        for (int i = tid; i < 2 * d.Lm; i += FC_XNT) ut[M + i] = p.tw3[i];  // radix-3 twiddles ride behind the untangle table
-
-    const int QPR = M >> 1;                 // float4 per real row
-    // rows per round (QPR <= 512).  M = 3 L: the largest power of two that fits; the threads left over repeat the work of
-    // the last row group (same addresses, same values)
-    const int RPR = R3 ? (1 << (31 - __clz(FC_XNT / QPR))) : FC_XNT / QPR;
-    const int q = tid % QPR;
-    const int rr = R3 ? min(tid / QPR, RPR - 1) : tid / QPR;
-    const bool active = !R3 || tid / QPR < RPR;  // left-over threads only take part in the transforms
-    const int gpz = d.Y / FC_XR;
-    const long ntiles = (long)d.Z * gpz;
-
-    float4 v[ROUNDS];
-    auto load_tile = [&](long t) {
-        const float* base = p.in + x_tile_row0(d, t) * d.X;
-        const int rro = opaque(rr);
-#pragma unroll
-        for (int u = 0; u < ROUNDS; ++u) {
-            const int c = min(rro + u * RPR, FC_XR - 1);
-            v[u] = *reinterpret_cast<const float4*>(base + x_row_off(d, c, d.X, 4 * q));
-        }
-    };
-    long t = blockIdx.x;
-    if (t < ntiles) load_tile(t);
-    for (; t < ntiles; t += gridDim.x) {
-        float* obase = p.out ? p.out + x_tile_row0(d, t) * d.X : nullptr;
-#pragma unroll
-        for (int u = 0; u < ROUNDS; ++u) {
-            const int c = rr + u * RPR;
-            if (c < FC_XR && active) {
-                if (p.out) {  // Richardson-Lucy start: e0 = max(d, 0) is stored and transformed in one pass
-                    v[u].x = fmaxf(v[u].x, 0.0f);
-                    v[u].y = fmaxf(v[u].y, 0.0f);
-                    v[u].z = fmaxf(v[u].z, 0.0f);
-                    v[u].w = fmaxf(v[u].w, 0.0f);
-                    *reinterpret_cast<float4*>(obase + x_row_off(d, c, d.X, 4 * q)) = v[u];
-                }
-                buf[(size_t)(2 * q) * FC_XPITCH + c] = make_float2(v[u].x, v[u].y);
-                buf[(size_t)(2 * q + 1) * FC_XPITCH + c] = make_float2(v[u].z, v[u].w);
-            }
-        }
-        __syncthreads();
-        const long tn = t + gridDim.x;
-        if (tn < ntiles) load_tile(tn);
-
-        x_forward_from_lds<ROUNDS, R3>(buf, tw, ut, p, d, t, tid, q, rr, RPR, active);
-        __syncthreads();
-    }
-}
-
-template <int EPI, int ROUNDS, bool FUSE, bool R3 = false>
-__global__ __launch_bounds__(FC_XNT) void x_inv_kernel(XParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const ConvDims d = p.d;
-    const int M = d.M;
-    cf* buf = reinterpret_cast<cf*>(smem);  // [(M + 1)][17]
-    cf* tw = buf + (size_t)(M + 1) * FC_XPITCH;
-    cf* ut = tw + p.ntw;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < p.ntw; i += FC_XNT) tw[i] = p.tw[i];
-    for (int i = tid; i < M; i += FC_XNT) ut[i] = p.untangle[i];
-    if (R3)
-        for (int i = tid; i < 2 * d.Lm; i += FC_XNT) ut[M + i] = p.tw3[i];
-
-    const int QPR = M >> 1;
-    const int RPR = R3 ? (1 << (31 - __clz(FC_XNT / QPR))) : FC_XNT / QPR;  // see x_fwd_kernel
-    const int q = tid % QPR;
-    const int rr = R3 ? min(tid / QPR, RPR - 1) : tid / QPR;
-    const bool active = !R3 || tid / QPR < RPR;  // left-over threads only take part in the transforms
-    const int gpz = d.Y / FC_XR;
-    const long ntiles = (long)d.Z * gpz;
-    constexpr int HALF = ROUNDS / 2;
-    constexpr bool FAST = ROUNDS >= 2;
-
-    // prefetch registers: the tile's spectrum rows (two columns per lane) + its Nyquist column
-    float4 v[ROUNDS];
-    cf nyA = make_float2(0.f, 0.f), nyB = nyA;
-    auto load_tile = [&](long t) {
-        const cf* base = p.S + x_tile_row0(d, t) * d.XP;
-        const int rro = opaque(rr);
-#pragma unroll
-        for (int u = 0; u < ROUNDS; ++u) {
-            const int c = min(rro + u * RPR, FC_XR - 1);
-            v[u] = *reinterpret_cast<const float4*>(base + x_row_off(d, c, d.XP, 2 * q));
-        }
-        const int rp = opaque(tid) & (FC_XH - 1);  // every thread loads (16 distinct addresses per tile: cache hits), 8 use it
-        nyA = base[x_row_off(d, rp, d.XP, M)];
-        nyB = base[x_row_off(d, rp + FC_XH, d.XP, M)];
-    };
-    long t = blockIdx.x;
-    if (FAST && t < ntiles) load_tile(t);
-    for (; t < ntiles; t += gridDim.x) {
-        const int z = (int)t / gpz;
-        const int g = (int)t - z * gpz;
-        const long trow0 = (long)z * d.Y + FC_XH * g;
-        if (FAST) {
-            // undo the Y radix-2 step in registers, write X[p] into LDS (transposed)
-#pragma unroll
-            for (int u = 0; u < (HALF > 0 ? HALF : 1); ++u) {
-                if (R3 && !active) break;
-                const int c = rr + u * RPR;  // < FC_XH
-                const cf w = p.twy[FC_XH * g + c];
-                const float4 A = v[u], B = v[(u + HALF) % ROUNDS];
-                const cf ub0 = cmulc(make_float2(B.x, B.y), w), ub1 = cmulc(make_float2(B.z, B.w), w);
-                const cf a0 = make_float2(A.x, A.y), a1 = make_float2(A.z, A.w);
-                buf[(size_t)(2 * q) * FC_XPITCH + c] = cadd(a0, ub0);
-                buf[(size_t)(2 * q) * FC_XPITCH + c + FC_XH] = csub(a0, ub0);
-                buf[(size_t)(2 * q + 1) * FC_XPITCH + c] = cadd(a1, ub1);
-                buf[(size_t)(2 * q + 1) * FC_XPITCH + c + FC_XH] = csub(a1, ub1);
-            }
-            if (tid < FC_XH) {
-                const cf ub = cmulc(nyB, p.twy[FC_XH * g + tid]);
-                buf[(size_t)M * FC_XPITCH + tid] = cadd(nyA, ub);
-                buf[(size_t)M * FC_XPITCH + tid + FC_XH] = csub(nyA, ub);
-            }
-        } else {
-            for (int idx = tid; idx < FC_XH * (M + 1); idx += FC_XNT) {
-                const int pcol = idx % (M + 1);
-                const int rp = idx / (M + 1);
-                const int y = FC_XH * g + rp;
-                const cf A = p.S[((long)z * d.Y + y) * d.XP + pcol];
-                const cf B = p.S[((long)z * d.Y + y + d.Y / 2) * d.XP + pcol];
-                const cf ub = cmulc(B, p.twy[y]);
-                buf[(size_t)pcol * FC_XPITCH + rp] = cadd(A, ub);
-                buf[(size_t)pcol * FC_XPITCH + rp + FC_XH] = csub(A, ub);
-            }
-        }
-        __syncthreads();
-        const long tn = t + gridDim.x;
-        // register budget: the next tile's spectrum (v) and this tile's d / est rows (aux) are never both live
-        // across an FFT.  Fused kernel: aux rides behind the inverse FFT, v behind the forward FFT.
-        // Plain kernel: v rides behind the inverse FFT, aux is fetched at the epilogue.
-        float4 aux[ROUNDS];
-        auto load_aux = [&]() {
-#pragma unroll
-            for (int u = 0; u < ROUNDS; ++u) {
-                const int c = min(opaque(rr) + u * RPR, FC_XR - 1);
-                aux[u] = *reinterpret_cast<const float4*>(p.aux + trow0 * d.X + x_row_off(d, c, d.X, 4 * q));
-            }
-        };
-        // (Running the last inverse radix-4 step, the epilogue and the first forward radix-4 step on their common four legs
-        // in registers — two LDS round trips and two barriers fewer — was built and measured 0.7 ms per iteration SLOWER:
-        // the leg-ordered aux / est accesses are 8-B instead of 16-B per lane.  The same fusion does pay in the Z pass,
-        // where the unit-twiddle steps around the OTF product need no extra global traffic: BH_MID in col_pass_kernel.)
-        if (FUSE) {
-            if (EPI != XE_STORE) load_aux();
-        } else if (FAST && tn < ntiles) {
-            load_tile(tn);
-        }
-        untangle_lds<true, R3>(buf, ut, M, tid, d.Lm);
-        __syncthreads();
-        if (R3) {
-            fft_lds<true, 1, 1, FC_R16, false, FC_XNT>(buf, d.Lm, d.logM, FC_LOGXR, FC_XPITCH, tw, tid, M);
-            radix3_step<true, 1, FC_XNT>(buf, d.Lm, FC_LOGXR, FC_XPITCH, ut + M, tid);
-            __syncthreads();
-        } else {
-            fft_lds<true, 1, 1, FC_R16, false, FC_XNT>(buf, M, d.logM, FC_LOGXR, FC_XPITCH, tw, tid);
-        }
-        if (!FUSE && EPI != XE_STORE) load_aux();
-        // natural order now: z[j] = x[2j] + i x[2j+1]; apply the fused epilogue to the real rows
-#pragma unroll
-        for (int u = 0; u < ROUNDS; ++u) {
-            const int rro = opaque(rr);
-            const int c = min(rro + u * RPR, FC_XR - 1);
-            const bool mine = rro + u * RPR < FC_XR && active;
-            const cf e0 = buf[(size_t)(2 * q) * FC_XPITCH + c], e1 = buf[(size_t)(2 * q + 1) * FC_XPITCH + c];
-            float4 r = make_float4(e0.x, e0.y, e1.x, e1.y);
-            if (EPI == XE_RATIO) {
-                const float4 dd = aux[u];
-                r.x = dd.x / fmaxf(r.x, p.eps);
-                r.y = dd.y / fmaxf(r.y, p.eps);
-                r.z = dd.z / fmaxf(r.z, p.eps);
-                r.w = dd.w / fmaxf(r.w, p.eps);
-            } else if (EPI == XE_UPDATE) {
-                const float4 e = aux[u];
-                r.x = fmaxf(e.x * r.x, 0.0f);
-                r.y = fmaxf(e.y * r.y, 0.0f);
-                r.z = fmaxf(e.z * r.z, 0.0f);
-                r.w = fmaxf(e.w * r.w, 0.0f);
-            }
-            // the ratio of a fused pass never leaves the chip; everything else is written out
-            if (mine && !(FUSE && EPI == XE_RATIO))
-                *reinterpret_cast<float4*>(p.out + trow0 * d.X + x_row_off(d, c, d.X, 4 * q)) = r;
-            // fused: the rows feed the next convolution's forward X pass straight from LDS (no HBM round trip);
-            // each thread overwrites exactly the two packed elements it just read
-            if (FUSE && mine) {
-                buf[(size_t)(2 * q) * FC_XPITCH + c] = make_float2(r.x, r.y);
-                buf[(size_t)(2 * q + 1) * FC_XPITCH + c] = make_float2(r.z, r.w);
-            }
-        }
-        __syncthreads();
-        if (FUSE) {
-            if (FAST && tn < ntiles) load_tile(tn);  // next tile's spectrum behind the forward FFT
-            x_forward_from_lds<ROUNDS, R3>(buf, tw, ut, p, d, t, tid, q, rr, RPR, active);
-            __syncthreads();
-        }
-    }
-}
-
-// ================================================================================================
-// host side
-// ================================================================================================
 struct ConvPlan {
     ConvDims d;
     cf *tw_x = nullptr, *tw_y = nullptr, *tw_z = nullptr, *untangle = nullptr, *twy = nullptr;
@@ -1047,13 +687,34 @@ struct ConvPlan {
     int Lyh = 0, Lz = 0;                      // power-of-two part of Y/2 and Z (== them, or a third of them)
     cf *tw3_y = nullptr, *tw3_z = nullptr;    // radix-3 twiddles where the axis is 3 * 2^k
     cf* tw3_x = nullptr;                      // same for the rows (M = 3 Lm)
+    int xr = BH_FC_XR;                        // rows per X-pass tile: which instantiation of the X passes runs
 };
+
+// The X passes exist for two tile heights: 16 rows (M = X/2 up to 1024) and 8 rows (M up to 1536: a 3072-voxel row, for which
+// 16 rows of LDS do not fit).  Same spectrum layout either way — the tile height only groups rows.
+namespace xr16 {
+#define BH_XP_XR BH_FC_XR
+#include "fftconv_xpass.inc"
+#undef BH_XP_XR
+}  // namespace xr16
+namespace xr8 {
+#define BH_XP_XR 8
+#include "fftconv_xpass.inc"
+#undef BH_XP_XR
+}  // namespace xr8
+
+// ================================================================================================
+// host side
+// ================================================================================================
 
 static int ilog2(long v) {
     int l = 0;
     while ((1l << l) < v) ++l;
     return l;
 }
+
+// rows per X-pass tile for a row length: the configured height while its LDS tile fits, 8 rows beyond M = 1024
+static int x_tile_rows(int64_t X) { return X / 2 > 1024 ? 8 : BH_FC_XR; }
 
 // Shapes the engine runs: X a power of two; Y and Z powers of two or — `radix3` — three times one (the column passes then
 // start with a radix-3 step).  Callers whose spectral arithmetic knows the scrambled coefficient order (Tikhonov's filter
@@ -1062,15 +723,17 @@ bool fftconv_supported_ex(int64_t Z, int64_t Y, int64_t X, bool radix3) {
     auto pow2 = [](int64_t v) { return v > 0 && (v & (v - 1)) == 0; };
     auto ok = [&](int64_t v) { return pow2(v) || (radix3 && v % 3 == 0 && pow2(v / 3)); };
     if (!ok(Z) || !ok(Y) || !ok(X)) return false;
-    if (X < 64 || X > 2048) return false;          // M = X/2 in [32, 1024]: (M+1)*17*8 + tables <= 160 KiB
+    if (X < 64 || X > 3072) return false;          // M = X/2 in [32, 1536]: (M+1)*(rows+1)*8 + tables <= 160 KiB
     if (!pow2(X) && X < 192) return false;         // rows of 3 * 2^k: thirds of at least 32 complex points
-    if (Y < 2 * 16 || Y / 2 > 2048) return false;   // Y/2 rows x >= 8 columns per tile, whole groups of FC_XR rows
+    if (X / 2 > 2 * FC_XNT) return false;          // an X-pass thread owns two complex columns of a row
+    if (Y < 2 * 16 || Y / 2 > 2048) return false;   // Y/2 rows x >= 8 columns per tile, whole groups of tile rows
     if (Z < 4 || Z > 2048) return false;
-    if ((Y % FC_XR) != 0) return false;
+    const int xr = x_tile_rows(X);
+    if ((Y % xr) != 0) return false;
     if (!pow2(Z) && Z < 24) return false;   // radix-3 columns: at least 3 x 8 rows
     if (!pow2(Y) && Y < 96) return false;
     const int M = (int)X / 2, Lm = pow2(X) ? M : M / 3;
-    const size_t xlds = (size_t)(M + 1) * FC_XPITCH * 8 + (size_t)twiddle_count(Lm) * 8 + (size_t)M * 8 + (Lm != M ? (size_t)2 * Lm * 8 : 0);
+    const size_t xlds = (size_t)(M + 1) * (xr + 1) * 8 + (size_t)twiddle_count(Lm) * 8 + (size_t)M * 8 + (Lm != M ? (size_t)2 * Lm * 8 : 0);
     return xlds <= 160 * 1024;
 }
 
@@ -1102,6 +765,7 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     auto pow2part = [](int64_t n) { return (int)((n & (n - 1)) == 0 ? n : n / 3); };
     pl.Lyh = pow2part(Y / 2);
     pl.Lz = pow2part(Z);
+    pl.xr = x_tile_rows(X);
     pl.d.Lm = pow2part(X / 2);
     pl.d.logM = ilog2(pl.d.Lm);
     pl.d.logYh = ilog2(pl.Lyh);
@@ -1236,55 +900,8 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
 
 static int launch_x(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, const float* in, cf* S, float* out,
                     const float* aux, float eps, bool fuse_fwd = false) {
-    XParams p;
-    p.in = in;
-    p.S = S;
-    p.out = out;
-    p.aux = aux;
-    p.tw = pl.tw_x;
-    p.untangle = pl.untangle;
-    p.twy = pl.twy;
-    p.tw3 = pl.tw3_x;
-    p.ntw = pl.ntw_x;
-    p.d = pl.d;
-    p.eps = eps;
-    const bool r3 = pl.d.Lm != pl.d.M;
-    const size_t lds = (size_t)(pl.d.M + 1) * FC_XPITCH * 8 + (size_t)pl.ntw_x * 8 + (size_t)pl.d.M * 8 + (r3 ? (size_t)2 * pl.d.Lm * 8 : 0);
-    const long ntiles = (long)pl.d.Z * (pl.d.Y / FC_XR);
-    const int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / FC_XNT, (160 * 1024) / (lds + 1024)));
-    const int grid = (int)std::min<long>(ntiles, (long)ctx->num_cus * wgs_per_cu);
-    auto run = [&](auto kern) -> int {
-        BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(FC_XNT), lds, ctx->stream, p);
-        BH_CHECK_HIP(hipGetLastError());
-        return BH_OK;
-    };
-    const int QPR = pl.d.M / 2;
-    int rpr = std::max(1, FC_XNT / QPR);
-    if (r3) {  // rows per round: the largest power of two that fits (kernel: RPR)
-        int b = 1;
-        while (2 * b <= rpr) b *= 2;
-        rpr = b;
-    }
-    const int rounds = (int)ceil_div(FC_XR, rpr);
-#define BH_X_DISPATCH_(R, R3)                                                 \
-    if (!inverse) return run(x_fwd_kernel<R, R3>);                            \
-    switch (epi) {                                                            \
-        case XE_STORE: return run(x_inv_kernel<XE_STORE, R, false, R3>);      \
-        case XE_RATIO: return fuse_fwd ? run(x_inv_kernel<XE_RATIO, R, true, R3>) : run(x_inv_kernel<XE_RATIO, R, false, R3>); \
-        default: return fuse_fwd ? run(x_inv_kernel<XE_UPDATE, R, true, R3>) : run(x_inv_kernel<XE_UPDATE, R, false, R3>);     \
-    }
-#define BH_X_DISPATCH(R)                    \
-    if (r3) { BH_X_DISPATCH_(R, true) }     \
-    else { BH_X_DISPATCH_(R, false) }
-    if (rounds <= 1) { BH_X_DISPATCH(1) }
-    if (rounds <= 2) { BH_X_DISPATCH(2) }
-    if (rounds <= 4) { BH_X_DISPATCH(4) }
-    if (rounds <= 8) { BH_X_DISPATCH(8) }
-    BH_X_DISPATCH(16)
-#undef BH_X_DISPATCH
-#undef BH_X_DISPATCH_
+    return pl.xr == 8 ? xr8::launch_x(ctx, pl, inverse, epi, in, S, out, aux, eps, fuse_fwd)
+                      : xr16::launch_x(ctx, pl, inverse, epi, in, S, out, aux, eps, fuse_fwd);
 }
 
 // OTF (scrambled order, scaled by 2/V so that forward -> multiply -> inverse is a normalised convolution)

@@ -156,7 +156,8 @@ def test_richardson_lucy_plan_boxes(monkeypatch):
     assert plan((33, 17, 17), (342, 1024, 1517)) == ((384, 1024, 1536), "engine-padded")       # 342 + 32 <= 3 * 128, 1517 + 16 <= 3 * 512
     assert plan((33, 17, 17), (384, 1024, 1536)) == ((384, 1024, 1536), "engine")              # 3 * 2^k on z and x
     assert plan((33, 17, 17), (1068, 256, 1664)) == ((1536, 256, 2048), "engine-padded")       # a mantis position
-    assert plan((33, 17, 17), (683, 2048, 3034)) == ((720, 2048, 3072), "library")             # x beyond the engine's 2048
+    assert plan((33, 17, 17), (683, 2048, 3034)) == ((768, 2048, 3072), "engine-padded")       # deskewed config 2: 8-row X passes
+    assert plan((33, 17, 17), (683, 2048, 3100)) == ((720, 2048, 3125), "library")             # x beyond the engine's 3072
     assert plan((5, 5, 5), (15, 42, 50)) == ((15, 42, 50), "library")                          # 7-smooth and small
     monkeypatch.setenv("BH_RL_ENGINE_PAD", "0")
     assert plan((33, 17, 17), (342, 1024, 1517)) == ((375, 1024, 1536), "library")

@@ -190,6 +190,7 @@ def test_richardson_lucy_vs_oracle(gpu, shape, pshape):
     ((40, 70, 64), (9, 9, 3)),      # X stays, Z -> 48 = 3 * 16 (radix-3 columns), Y -> 96 (columns of 48 = 3 * 16)
     ((80, 150, 64), (5, 5, 5)),     # Z -> 96 (odd log2 of the power-of-two part), Y -> 192
     ((170, 64, 64), (9, 3, 3)),     # Z -> 192 = 3 * 64
+    ((6, 40, 2300), (3, 3, 9)),     # X -> 3072: rows beyond 2048 voxels run the 8-row X passes
 ])
 def test_richardson_lucy_awkward_sizes_pad_fold(gpu, shape, pshape, monkeypatch):
     """Axes with a large prime factor are zero-padded to a 7-smooth FFT size and the wrapped part of the linear
@@ -222,7 +223,8 @@ def test_richardson_lucy_awkward_sizes_pad_fold(gpu, shape, pshape, monkeypatch)
 @pytest.mark.parametrize("shape,pshape", [((48, 96, 64), (5, 7, 3)), ((24, 32, 128), (3, 3, 9)), ((64, 192, 64), (9, 5, 5)),
                                           ((96, 64, 256), (7, 3, 3)),
                                           ((16, 32, 192), (5, 5, 9)), ((8, 32, 384), (3, 5, 7)), ((24, 96, 768), (5, 3, 11)),
-                                          ((4, 32, 1536), (1, 3, 17))])   # the last four: rows of 3 * 2^k
+                                          ((4, 32, 1536), (1, 3, 17)),    # the last four: rows of 3 * 2^k
+                                          ((4, 32, 3072), (1, 3, 9))])    # 3072-voxel rows: the 8-row instantiation of the X passes
 def test_richardson_lucy_radix3_columns_fused(gpu, shape, pshape, monkeypatch):
     """Axes of 3 * 2^k: the fused 8-pass iteration runs at the volume's own shape, the transforms of those axes starting with a
     radix-3 step (csrc/fftconv.hip radix3_step; for rows the real-transform untangle pairs thirds 1 and 2 with each other);
