@@ -42,7 +42,8 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     def compile_one(src: str) -> Path:
         obj = objdir / (src + ".o")
         srcp = CSRC / src
-        hdr_t = max((CSRC / "common.hpp").stat().st_mtime, (INCLUDE / "bhcore.h").stat().st_mtime)
+        hdr_t = max((CSRC / "common.hpp").stat().st_mtime, (INCLUDE / "bhcore.h").stat().st_mtime,
+                    (CSRC / "fftconv_xpass.inc").stat().st_mtime if src == "fftconv.hip" else 0.0)
         if not force and obj.exists() and obj.stat().st_mtime > max(srcp.stat().st_mtime, hdr_t):
             return obj
         cmd = [_hipcc(), *flags, "-c", str(srcp), "-o", str(obj)]

@@ -40,8 +40,10 @@ constexpr int FC_TILE = 16384;     // complex elements per column tile (128 KiB)
 #ifndef BH_FC_XNT
 #define BH_FC_XNT BH_FC_NT
 #endif
-constexpr int FC_XNT = BH_FC_XNT;  // threads per workgroup of the X passes
-static_assert(FC_XNT >= 512 && FC_XNT <= 1024, "an X-pass thread owns one complex pair of a row: X/4 <= 512 threads per row");
+#ifndef BH_FC_XNT8
+#define BH_FC_XNT8 768  // threads per workgroup of the 8-row X passes (rows of 3072 voxels: one thread per float4 of a row;
+                        // 1.40 s against 1.44 s with 1024 threads for R-L x10 at the box (768,2048,3072))
+#endif
 #ifndef BH_FC_R16
 #define BH_FC_R16 0
 #endif
@@ -694,13 +696,17 @@ struct ConvPlan {
 // 16 rows of LDS do not fit).  Same spectrum layout either way — the tile height only groups rows.
 namespace xr16 {
 #define BH_XP_XR BH_FC_XR
+#define BH_XP_XNT BH_FC_XNT
 #include "fftconv_xpass.inc"
 #undef BH_XP_XR
+#undef BH_XP_XNT
 }  // namespace xr16
 namespace xr8 {
 #define BH_XP_XR 8
+#define BH_XP_XNT BH_FC_XNT8
 #include "fftconv_xpass.inc"
 #undef BH_XP_XR
+#undef BH_XP_XNT
 }  // namespace xr8
 
 // ================================================================================================
@@ -725,7 +731,7 @@ bool fftconv_supported_ex(int64_t Z, int64_t Y, int64_t X, bool radix3) {
     if (!ok(Z) || !ok(Y) || !ok(X)) return false;
     if (X < 64 || X > 3072) return false;          // M = X/2 in [32, 1536]: (M+1)*(rows+1)*8 + tables <= 160 KiB
     if (!pow2(X) && X < 192) return false;         // rows of 3 * 2^k: thirds of at least 32 complex points
-    if (X / 2 > 2 * FC_XNT) return false;          // an X-pass thread owns two complex columns of a row
+    if (X / 4 > (X / 2 > 1024 ? BH_FC_XNT8 : BH_FC_XNT)) return false;  // an X-pass thread owns two complex columns of a row
     if (Y < 2 * 16 || Y / 2 > 2048) return false;   // Y/2 rows x >= 8 columns per tile, whole groups of tile rows
     if (Z < 4 || Z > 2048) return false;
     const int xr = x_tile_rows(X);
