@@ -568,17 +568,22 @@ static bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
 static bool engine_pad_box(const int64_t N[3], const int64_t K[3], int64_t P[3]) {
     const bool radix3 = getenv("BH_FC_NORADIX3") == nullptr;
     for (int a = 0; a < 3; ++a) {
-        // axes the engine transforms as they are wrap by themselves: powers of two and 3 * 2^k
+        // axes the engine transforms as they are wrap by themselves: powers of two, 3 * 2^k and 5 * 2^k
         auto alone = [&](int64_t n) { return fftconv_supported_ex(a == 0 ? n : 64, a == 1 ? n : 64, a == 2 ? n : 64, true); };
-        if (is_pow2(N[a]) || (radix3 && N[a] % 3 == 0 && is_pow2(N[a] / 3) && alone(N[a]))) {
+        const bool odd_native = (N[a] % 3 == 0 && is_pow2(N[a] / 3)) || (N[a] % 5 == 0 && is_pow2(N[a] / 5));
+        if (is_pow2(N[a]) || (radix3 && odd_native && alone(N[a]))) {
             P[a] = N[a];
             continue;
         }
         const int64_t need = N[a] + K[a] - 1;
         P[a] = 1;
         while (P[a] < need) P[a] *= 2;
-        // 3 * 2^k (radix-3 first step of that axis' transform) when it is enough
-        if (radix3 && P[a] >= 8 && 3 * (P[a] / 4) >= need && alone(3 * (P[a] / 4))) P[a] = 3 * (P[a] / 4);
+        // 5 * 2^k or 3 * 2^k (odd first step of that axis' transform) when that is enough
+        if (radix3 && P[a] >= 16) {
+            const int64_t p5 = 5 * (P[a] / 8), p3 = 3 * (P[a] / 4);
+            if (p5 >= need && alone(p5)) P[a] = p5;
+            else if (p3 >= need && alone(p3)) P[a] = p3;
+        }
         if (K[a] - 1 >= N[a]) return false;  // the wrap below assumes margins shorter than the axis
     }
     return fftconv_supported_ex(P[0], P[1], P[2], true);

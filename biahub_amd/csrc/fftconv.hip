@@ -331,6 +331,56 @@ __device__ __forceinline__ void radix3_step(cf* buf, int L, int logW, int P, con
     }
 }
 
+// Radix-5 step, same conventions: rows (m, m + L, .., m + 4L) <-> the five length-L sequences y_k[m] = (sum_j x[m + jL] w5^jk) w_N^(k m)
+// in rows [k L, (k + 1) L); t5[4 m + k - 1] = w_N^(k m), k = 1..4.
+template <bool INV, int CPT = 2, int NT = FC_NT>
+__device__ __forceinline__ void radix5_step(cf* buf, int L, int logW, int P, const cf* t5, int tid) {
+    const int lw = logW - (CPT == 2 ? 1 : 0);
+    const int total = L << lw;
+    const size_t LP = (size_t)L * P;
+    const float C1 = 0.30901699437494742f, C2 = -0.80901699437494742f;  // cos(2 pi / 5), cos(4 pi / 5)
+    const float S1 = 0.95105651629515357f, S2 = 0.58778525229247313f;   // sin(2 pi / 5), sin(4 pi / 5)
+    for (int idx = tid; idx < total; idx += NT) {
+        const int c = (idx & ((1 << lw) - 1)) * CPT;
+        const int m = idx >> lw;
+        cf* p0 = buf + (size_t)m * P + c;
+        const CV<CPT> x0 = CV<CPT>::ld(p0);
+        CV<CPT> x1 = CV<CPT>::ld(p0 + LP), x2 = CV<CPT>::ld(p0 + 2 * LP), x3 = CV<CPT>::ld(p0 + 3 * LP), x4 = CV<CPT>::ld(p0 + 4 * LP);
+        const cf w1 = t5[4 * m], w2 = t5[4 * m + 1], w3 = t5[4 * m + 2], w4 = t5[4 * m + 3];
+        if (INV) {
+            x1 = vmulc<CPT>(x1, w1);
+            x2 = vmulc<CPT>(x2, w2);
+            x3 = vmulc<CPT>(x3, w3);
+            x4 = vmulc<CPT>(x4, w4);
+        }
+        const CV<CPT> t1 = vadd<CPT>(x1, x4), t2 = vadd<CPT>(x2, x3), t3 = vsub<CPT>(x1, x4), t4 = vsub<CPT>(x2, x3);
+        const CV<CPT> a1 = vadd<CPT>(x0, vadd<CPT>(vscale<CPT>(t1, C1), vscale<CPT>(t2, C2)));
+        const CV<CPT> a2 = vadd<CPT>(x0, vadd<CPT>(vscale<CPT>(t1, C2), vscale<CPT>(t2, C1)));
+        const CV<CPT> b1 = vadd<CPT>(vscale<CPT>(t3, S1), vscale<CPT>(t4, S2));
+        const CV<CPT> b2 = vsub<CPT>(vscale<CPT>(t3, S2), vscale<CPT>(t4, S1));
+        const CV<CPT> r1 = INV ? vmul_pi<CPT>(b1) : vmul_mi<CPT>(b1), r2 = INV ? vmul_pi<CPT>(b2) : vmul_mi<CPT>(b2);
+        vadd<CPT>(x0, vadd<CPT>(t1, t2)).st(p0);
+        if (!INV) {
+            vmul<CPT>(vadd<CPT>(a1, r1), w1).st(p0 + LP);
+            vmul<CPT>(vadd<CPT>(a2, r2), w2).st(p0 + 2 * LP);
+            vmul<CPT>(vsub<CPT>(a2, r2), w3).st(p0 + 3 * LP);
+            vmul<CPT>(vsub<CPT>(a1, r1), w4).st(p0 + 4 * LP);
+        } else {
+            vadd<CPT>(a1, r1).st(p0 + LP);
+            vadd<CPT>(a2, r2).st(p0 + 2 * LP);
+            vsub<CPT>(a2, r2).st(p0 + 3 * LP);
+            vsub<CPT>(a1, r1).st(p0 + 4 * LP);
+        }
+    }
+}
+
+// the odd first (forward) / last (inverse) step of an axis of rdx * 2^k, rdx = 3 or 5
+template <bool INV, int CPT, int NT, int RDX>
+__device__ __forceinline__ void odd_step(cf* buf, int L, int logW, int P, const cf* t, int tid) {
+    if (RDX == 3) radix3_step<INV, CPT, NT>(buf, L, logW, P, t, tid);
+    if (RDX == 5) radix5_step<INV, CPT, NT>(buf, L, logW, P, t, tid);
+}
+
 // R16: pair consecutive radix-4 steps into radix-16 steps (one column per thread); a leftover radix-4 step and
 // the radix-2 step of an odd log2(N) use <BPT, CPT>.
 // SKIP2: leave out the h = 2 radix-4 step (last forward / first inverse; its twiddles are all 1) — the convolution
@@ -451,23 +501,25 @@ struct ColParams {
 // float4[] in scratch memory here even with every index constant).  BH_FOR8 applies a macro to all of them.
 #define BH_FOR8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
-template <int MODE, int ROUNDS>
+// RDX: 1 for power-of-two columns, 3 / 5 for columns of 3 * 2^k / 5 * 2^k rows (their own instantiations: the odd step's
+// registers would otherwise push the power-of-two kernels into scratch)
+template <int MODE, int ROUNDS, int RDX = 1>
 __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* buf = reinterpret_cast<cf*>(smem);                         // [N][W]
     cf* tw = reinterpret_cast<cf*>(smem + (size_t)p.N * p.W * 8);  // twiddles
     const int tid = threadIdx.x;
     for (int i = tid; i < p.ntw; i += FC_NT) tw[i] = p.tw[i];
-    const int L_ = p.L;
-    const bool r3 = L_ != p.N;
+    const int L_ = RDX == 1 ? p.N : p.L;
+    constexpr bool r3 = RDX != 1;
     cf* tw3 = tw + p.ntw;
     if (r3)
-        for (int i = tid; i < 2 * L_; i += FC_NT) tw3[i] = p.tw3[i];
+        for (int i = tid; i < (RDX - 1) * L_; i += FC_NT) tw3[i] = p.tw3[i];
     // column transform = [radix-3 step] + power-of-two transform of the 1 or 3 length-L sequences
 #define BH_FFT_FWD(...)                                                     \
     {                                                                       \
         if (r3) {                                                           \
-            radix3_step<false, 2>(buf, L_, logW, W_, tw3, tid);                \
+            odd_step<false, 2, FC_NT, RDX>(buf, L_, logW, W_, tw3, tid);                \
             __syncthreads();                                                \
         }                                                                   \
         fft_lds<false, __VA_ARGS__>(buf, L_, logN, logW, W_, tw, tid, N_);  \
@@ -476,7 +528,7 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
     {                                                                       \
         fft_lds<true, __VA_ARGS__>(buf, L_, logN, logW, W_, tw, tid, N_);   \
         if (r3) {                                                           \
-            radix3_step<true, 2>(buf, L_, logW, W_, tw3, tid);                 \
+            odd_step<true, 2, FC_NT, RDX>(buf, L_, logW, W_, tw3, tid);                 \
             __syncthreads();                                                \
         }                                                                   \
     }
@@ -727,19 +779,19 @@ static int x_tile_rows(int64_t X) { return X / 2 > 1024 ? 8 : BH_FC_XR; }
 // staging) ask without `radix3`; order-agnostic ones (Richardson-Lucy at a padded box) may ask with it.
 bool fftconv_supported_ex(int64_t Z, int64_t Y, int64_t X, bool radix3) {
     auto pow2 = [](int64_t v) { return v > 0 && (v & (v - 1)) == 0; };
-    auto ok = [&](int64_t v) { return pow2(v) || (radix3 && v % 3 == 0 && pow2(v / 3)); };
+    auto ok = [&](int64_t v) { return pow2(v) || (radix3 && ((v % 3 == 0 && pow2(v / 3)) || (v % 5 == 0 && pow2(v / 5)))); };
     if (!ok(Z) || !ok(Y) || !ok(X)) return false;
     if (X < 64 || X > 3072) return false;          // M = X/2 in [32, 1536]: (M+1)*(rows+1)*8 + tables <= 160 KiB
-    if (!pow2(X) && X < 192) return false;         // rows of 3 * 2^k: thirds of at least 32 complex points
+    if (!pow2(X) && X / 2 / (X % 3 == 0 ? 3 : 5) < 32) return false;  // rows of 3 * 2^k / 5 * 2^k: parts of at least 32 complex points
     if (X / 4 > (X / 2 > 1024 ? BH_FC_XNT8 : BH_FC_XNT)) return false;  // an X-pass thread owns two complex columns of a row
     if (Y < 2 * 16 || Y / 2 > 2048) return false;   // Y/2 rows x >= 8 columns per tile, whole groups of tile rows
     if (Z < 4 || Z > 2048) return false;
     const int xr = x_tile_rows(X);
     if ((Y % xr) != 0) return false;
-    if (!pow2(Z) && Z < 24) return false;   // radix-3 columns: at least 3 x 8 rows
-    if (!pow2(Y) && Y < 96) return false;
-    const int M = (int)X / 2, Lm = pow2(X) ? M : M / 3;
-    const size_t xlds = (size_t)(M + 1) * (xr + 1) * 8 + (size_t)twiddle_count(Lm) * 8 + (size_t)M * 8 + (Lm != M ? (size_t)2 * Lm * 8 : 0);
+    if (!pow2(Z) && Z / (Z % 3 == 0 ? 3 : 5) < 8) return false;        // odd-radix columns: parts of at least 8 rows
+    if (!pow2(Y) && Y / 2 / (Y % 3 == 0 ? 3 : 5) < 16) return false;
+    const int M = (int)X / 2, Lm = pow2(X) ? M : (X % 3 == 0 ? M / 3 : M / 5);
+    const size_t xlds = (size_t)(M + 1) * (xr + 1) * 8 + (size_t)twiddle_count(Lm) * 8 + (size_t)M * 8 + (Lm != M ? (size_t)(M / Lm - 1) * Lm * 8 : 0);
     return xlds <= 160 * 1024;
 }
 
@@ -768,7 +820,7 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     pl.d.X = (int)X;
     pl.d.M = (int)X / 2;
     pl.d.XP = (int)X / 2 + 16;
-    auto pow2part = [](int64_t n) { return (int)((n & (n - 1)) == 0 ? n : n / 3); };
+    auto pow2part = [](int64_t n) { return (int)((n & (n - 1)) == 0 ? n : (n % 3 == 0 ? n / 3 : n / 5)); };
     pl.Lyh = pow2part(Y / 2);
     pl.Lz = pow2part(Z);
     pl.xr = x_tile_rows(X);
@@ -788,13 +840,14 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     make_twiddles(pl.Lz, h);
     pl.ntw_z = (int)h.size();
     BH_TRY(upload(h, &pl.tw_z));
-    auto radix3_twiddles = [&](int n, int L, cf** dptr) -> int {  // [w_n^m, w_n^2m], m < L = n / 3
+    auto radix3_twiddles = [&](int n, int L, cf** dptr) -> int {  // [w_n^(k m), k = 1 .. r - 1], m < L = n / r, r = 3 or 5
         if (L == n) return BH_OK;
-        h.resize(2 * (size_t)L);
+        const int r = n / L;
+        h.resize((size_t)(r - 1) * L);
         for (int m = 0; m < L; ++m)
-            for (int k = 1; k <= 2; ++k) {
+            for (int k = 1; k < r; ++k) {
                 const double a = -2.0 * M_PI * (double)m * k / (double)n;
-                h[2 * m + k - 1] = make_float2((float)std::cos(a), (float)std::sin(a));
+                h[(size_t)(r - 1) * m + k - 1] = make_float2((float)std::cos(a), (float)std::sin(a));
             }
         return upload(h, dptr);
     };
@@ -808,7 +861,7 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
         int k = 0;
         for (int b = 0; b < pl.d.logM; ++b)
             if (r & (1 << b)) k |= 1 << (pl.d.logM - 1 - b);
-        if (pl.d.Lm != pl.d.M) k = 3 * k + third;
+        if (pl.d.Lm != pl.d.M) k = (pl.d.M / pl.d.Lm) * k + third;
         const double a = -2.0 * M_PI * k / (double)X;
         h[pp] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
@@ -875,7 +928,7 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
     p.ncoltiles = (int)ceil_div(pl.d.XP, p.W);
     BH_REQUIRE((long)p.N * p.W <= FC_TILE && (long)p.N * (p.W / 2) <= 16l * FC_NT && (FC_NT % (p.W / 2)) == 0,
                "internal: column tile %dx%d unsupported", p.N, p.W);
-    const size_t lds = (size_t)p.N * p.W * 8 + (size_t)p.ntw * 8 + (p.L != p.N ? (size_t)2 * p.L * 8 : 0);
+    const size_t lds = (size_t)p.N * p.W * 8 + (size_t)p.ntw * 8 + (p.L != p.N ? (size_t)(p.N / p.L - 1) * p.L * 8 : 0);
     const long ntiles = (long)p.nouter * p.ncoltiles;
     const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
     auto run = [&](auto kern) -> int {
@@ -887,21 +940,26 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
     };
     const long per_round = (long)(FC_NT / (p.W / 2));
     const int rounds = (int)ceil_div(p.N, per_round);
-#define BH_COL_DISPATCH(R)                                            \
-    switch (mode) {                                                   \
-        case COL_FWD: return run(col_pass_kernel<COL_FWD, R>);        \
-        case COL_INV: return run(col_pass_kernel<COL_INV, R>);        \
-        case COL_FWD_SCALE: return run(col_pass_kernel<COL_FWD_SCALE, R>); \
-        case COL_CONV: return run(col_pass_kernel<COL_CONV, R>);      \
-        case COL_FILTER: return run(col_pass_kernel<COL_FILTER, R>);  \
-        default: return run(col_pass_kernel<COL_CORR, R>);            \
+#define BH_COL_DISPATCH_(R, RDX)                                           \
+    switch (mode) {                                                        \
+        case COL_FWD: return run(col_pass_kernel<COL_FWD, R, RDX>);        \
+        case COL_INV: return run(col_pass_kernel<COL_INV, R, RDX>);        \
+        case COL_FWD_SCALE: return run(col_pass_kernel<COL_FWD_SCALE, R, RDX>); \
+        case COL_CONV: return run(col_pass_kernel<COL_CONV, R, RDX>);      \
+        case COL_FILTER: return run(col_pass_kernel<COL_FILTER, R, RDX>);  \
+        default: return run(col_pass_kernel<COL_CORR, R, RDX>);            \
     }
+#define BH_COL_DISPATCH(R)                                 \
+    if (p.N / p.L == 3) { BH_COL_DISPATCH_(R, 3) }         \
+    else if (p.N / p.L == 5) { BH_COL_DISPATCH_(R, 5) }    \
+    else { BH_COL_DISPATCH_(R, 1) }
     if (rounds <= 1) { BH_COL_DISPATCH(1) }
     if (rounds <= 2) { BH_COL_DISPATCH(2) }
     if (rounds <= 4) { BH_COL_DISPATCH(4) }
     if (rounds <= 8) { BH_COL_DISPATCH(8) }
     BH_COL_DISPATCH(16)
 #undef BH_COL_DISPATCH
+#undef BH_COL_DISPATCH_
 }
 
 static int launch_x(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, const float* in, cf* S, float* out,
@@ -943,11 +1001,11 @@ __global__ __launch_bounds__(256) void tikhonov_filter_rows_kernel(const float* 
         // stored position -> frequency: a 3 * 2^k column holds X[3 j + t] in third t at the bit-reversed j
         const int tz = zs / d.Lz, rz = zs - tz * d.Lz;
         const int jz = (int)(__brev((unsigned)rz) >> (32 - d.logZ));
-        const int kz = d.Lz == d.Z ? jz : 3 * jz + tz;
+        const int kz = (d.Z / d.Lz) * jz + tz;  // Z / Lz = 1, 3 or 5: frequency r j + t sits in part t at the bit-reversed j
         const int half = ys / Yh, r = ys - half * Yh;
         const int ty = r / d.Lyh, ry = r - ty * d.Lyh;
         const int jy = (int)(__brev((unsigned)ry) >> (32 - d.logYh));
-        const int ky = 2 * (d.Lyh == Yh ? jy : 3 * jy + ty) + half;
+        const int ky = 2 * ((Yh / d.Lyh) * jy + ty) + half;
         const float* src = tf + ((long)kz * d.Y + ky) * d.X;
         for (int kx = threadIdx.x; kx < d.XP; kx += 256) {
             float f = 0.0f;
@@ -957,7 +1015,7 @@ __global__ __launch_bounds__(256) void tikhonov_filter_rows_kernel(const float* 
             }
             int ps = kx;  // Nyquist and pad columns keep their place
             if (kx < d.M) {
-                const int jx = d.Lm == d.M ? kx : kx / 3, tx = d.Lm == d.M ? 0 : kx - 3 * jx;
+                const int rx = d.M / d.Lm, jx = kx / rx, tx = kx - rx * jx;
                 ps = tx * d.Lm + (int)(__brev((unsigned)jx) >> (32 - d.logM));
             }
             rowbuf[ps] = f;

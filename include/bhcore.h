@@ -195,8 +195,8 @@ int bh_tikhonov(bh_ctx* ctx, const float* in, const float* tf_full, int64_t Z, i
                 double regularization_strength, float* out);
 
 /* Host-only: the transform box and back-end bh_richardson_lucy picks for a shape.  BH_RL_ENGINE: the fused FFT engine at
- * the volume's own (power-of-two) shape; BH_RL_ENGINE_PADDED: the engine at a larger box (axes of 2^k or, for z and y,
- * 3 * 2^k) that carries the volume wrap-extended by K - 1; BH_RL_LIBRARY: hipFFT at the shape itself or, for axes with a
+ * the volume's own (power-of-two) shape; BH_RL_ENGINE_PADDED: the engine at a larger box (axes of 2^k, 3 * 2^k or
+ * 5 * 2^k) that carries the volume wrap-extended by K - 1; BH_RL_LIBRARY: hipFFT at the shape itself or, for axes with a
  * prime factor above 7, at a 7-smooth pad-and-fold box.  All three compute the circular Richardson-Lucy at size (Z,Y,X). */
 #define BH_RL_ENGINE 0
 #define BH_RL_ENGINE_PADDED 1

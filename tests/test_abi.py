@@ -155,7 +155,7 @@ def test_richardson_lucy_plan_boxes(monkeypatch):
     assert plan((33, 17, 17), (384, 1024, 1024)) == ((384, 1024, 1024), "engine")
     assert plan((33, 17, 17), (342, 1024, 1517)) == ((384, 1024, 1536), "engine-padded")       # 342 + 32 <= 3 * 128, 1517 + 16 <= 3 * 512
     assert plan((33, 17, 17), (384, 1024, 1536)) == ((384, 1024, 1536), "engine")              # 3 * 2^k on z and x
-    assert plan((33, 17, 17), (1068, 256, 1664)) == ((1536, 256, 2048), "engine-padded")       # a mantis position
+    assert plan((33, 17, 17), (1068, 256, 1664)) == ((1280, 256, 2048), "engine-padded")       # a mantis position: z -> 5 * 256
     assert plan((33, 17, 17), (683, 2048, 3034)) == ((768, 2048, 3072), "engine-padded")       # deskewed config 2: 8-row X passes
     assert plan((33, 17, 17), (683, 2048, 3100)) == ((720, 2048, 3125), "library")             # x beyond the engine's 3072
     assert plan((5, 5, 5), (15, 42, 50)) == ((15, 42, 50), "library")                          # 7-smooth and small
@@ -163,7 +163,8 @@ def test_richardson_lucy_plan_boxes(monkeypatch):
     assert plan((33, 17, 17), (342, 1024, 1517)) == ((375, 1024, 1536), "library")
     monkeypatch.setenv("BH_RL_ENGINE_PAD", "1")
     assert plan((7, 5, 9), (21, 64, 150)) == ((32, 64, 192), "engine-padded")
-    assert plan((9, 9, 3), (40, 70, 64)) == ((48, 96, 64), "engine-padded")
+    assert plan((9, 9, 3), (40, 70, 64)) == ((40, 96, 64), "engine-padded")                    # z = 5 * 8 runs as it is
+    assert plan((5, 5, 5), (70, 150, 300)) == ((80, 160, 320), "engine-padded")
     assert plan((5, 3, 11), (19, 40, 134)) == ((24, 64, 192), "engine-padded")
     monkeypatch.setenv("BH_FC_NORADIX3", "1")
     assert plan((5, 3, 11), (19, 40, 134)) == ((32, 64, 256), "engine-padded")

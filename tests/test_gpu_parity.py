@@ -191,6 +191,7 @@ def test_richardson_lucy_vs_oracle(gpu, shape, pshape):
     ((80, 150, 64), (5, 5, 5)),     # Z -> 96 (odd log2 of the power-of-two part), Y -> 192
     ((170, 64, 64), (9, 3, 3)),     # Z -> 192 = 3 * 64
     ((6, 40, 2300), (3, 3, 9)),     # X -> 3072: rows beyond 2048 voxels run the 8-row X passes
+    ((70, 150, 300), (5, 5, 5)),    # -> (80, 160, 320): radix-5 first steps on all three axes
 ])
 def test_richardson_lucy_awkward_sizes_pad_fold(gpu, shape, pshape, monkeypatch):
     """Axes with a large prime factor are zero-padded to a 7-smooth FFT size and the wrapped part of the linear
@@ -224,7 +225,9 @@ def test_richardson_lucy_awkward_sizes_pad_fold(gpu, shape, pshape, monkeypatch)
                                           ((96, 64, 256), (7, 3, 3)),
                                           ((16, 32, 192), (5, 5, 9)), ((8, 32, 384), (3, 5, 7)), ((24, 96, 768), (5, 3, 11)),
                                           ((4, 32, 1536), (1, 3, 17)),    # the last four: rows of 3 * 2^k
-                                          ((4, 32, 3072), (1, 3, 9))])    # 3072-voxel rows: the 8-row instantiation of the X passes
+                                          ((4, 32, 3072), (1, 3, 9)),     # 3072-voxel rows: the 8-row instantiation of the X passes
+                                          ((40, 160, 64), (5, 5, 3)), ((16, 32, 320), (3, 3, 5)), ((80, 32, 640), (3, 3, 7)),
+                                          ((8, 32, 2560), (3, 3, 3))])    # radix-5 first steps: columns, rows, 8-row rows
 def test_richardson_lucy_radix3_columns_fused(gpu, shape, pshape, monkeypatch):
     """Axes of 3 * 2^k: the fused 8-pass iteration runs at the volume's own shape, the transforms of those axes starting with a
     radix-3 step (csrc/fftconv.hip radix3_step; for rows the real-transform untangle pairs thirds 1 and 2 with each other);
@@ -538,7 +541,8 @@ def test_richardson_lucy_fused_engine_vs_oracle(gpu, shape, pshape, monkeypatch)
 
 @pytest.mark.parametrize("shape", [(16, 32, 64), (8, 64, 128), (32, 128, 256), (128, 32, 1024),
                                    (48, 96, 64), (24, 64, 128), (64, 192, 64),     # radix-3 columns
-                                   (16, 32, 192), (8, 96, 384), (8, 32, 1536)])    # radix-3 rows
+                                   (16, 32, 192), (8, 96, 384), (8, 32, 1536),     # radix-3 rows
+                                   (40, 160, 64), (16, 32, 320), (8, 32, 2560)])   # radix-5 columns / rows
 def test_tikhonov_fused_engine_vs_oracle(gpu, shape, monkeypatch):
     from biahub_amd.deconvolve import compute_tranfser_function, deconvolve
 
@@ -646,7 +650,8 @@ def test_phase_cross_corr_golden_and_oracle(gpu):
             assert np.array_equal(got, want), (roll, norm, got, want)
             assert rel_err(corr, wcorr) <= FFT_TOL, (roll, norm)
     # z / y of 3 * 2^k: the engine's column passes start with a radix-3 step; the coefficient order changes, the answers do not
-    for shape3, rolls in (((48, 96, 64), ((0, 0, 0), (7, -40, 21), (-24, 48, -32))), ((16, 32, 192), ((3, -9, 77), (-8, 16, -96)))):
+    for shape3, rolls in (((48, 96, 64), ((0, 0, 0), (7, -40, 21), (-24, 48, -32))), ((16, 32, 192), ((3, -9, 77), (-8, 16, -96))),
+                          ((40, 160, 320), ((-20, 80, 160), (9, -70, 33)))):
         r3 = rng.random(shape3, dtype=np.float32)
         for roll in rolls:
             mov = np.roll(r3, roll, axis=(0, 1, 2)) + 0.05 * rng.random(r3.shape, dtype=np.float32)
