@@ -32,11 +32,11 @@ def valid_mask_device(vol, device="cuda"):
         t = vol.to(dev).contiguous()
         code = {torch.uint8: _lib.DT_U8, torch.uint16: _lib.DT_U16, torch.int16: _lib.DT_I16, torch.float32: _lib.DT_F32}.get(t.dtype)
         if code is None:
-            t, code = t.to(torch.float32), _lib.DT_F32
+            t, code = ((t != 0) & ~torch.isnan(t) if t.is_floating_point() else t != 0).to(torch.uint8), _lib.DT_U8
     else:
         a = np.ascontiguousarray(vol)
-        if a.dtype not in _NP_TO_DT:
-            a = a.astype(np.float32)
+        if a.dtype not in _NP_TO_DT:  # e.g. float64: a cast could flush tiny values to zero, so the predicate runs on the host
+            a = ((a != 0) & ~np.isnan(a)).astype(np.uint8) if a.dtype.kind == "f" else (a != 0).astype(np.uint8)
         t, code = upload(a, dev)
     n = t.numel()
     bits = torch.empty(((n + 63) // 64) * 2, dtype=torch.int32, device=dev)
