@@ -326,24 +326,41 @@ __global__ __launch_bounds__(256) void fold_update_rewrap_kernel(const float* __
         else if (qy >= f.N[1] - f.lo[1]) ty[ny++] = qy - f.N[1] + f.off[1];
         const float* erow = est_old + ((int64_t)tz[0] * f.P[1] + ty[0]) * f.P[2] + f.off[2];
         float* drow = est_new + row * f.P[2];
-        for (int x = blockIdx.x * 256 + threadIdx.x; x < f.P[2]; x += gridDim.x * 256) {
-            int qx = x - f.off[2];
-            float v = 0.0f;
-            if (in_zy && qx >= -f.lo[2] && qx < f.N[2] + f.hi[2]) {
-                qx += qx < 0 ? f.N[2] : (qx >= f.N[2] ? -f.N[2] : 0);
-                int tx[2] = {qx + f.off[2], 0};
-                int nx = 1;
-                if (qx < f.hi[2]) tx[nx++] = qx + f.N[2] + f.off[2];
-                else if (qx >= f.N[2] - f.lo[2]) tx[nx++] = qx - f.N[2] + f.off[2];
-                float acc = 0.0f;
-                for (int a = 0; a < nz; ++a)
-                    for (int b = 0; b < ny; ++b) {
-                        const float* crow = corr + ((int64_t)tz[a] * f.P[1] + ty[b]) * f.P[2];
-                        for (int c = 0; c < nx; ++c) acc += crow[tx[c]];
-                    }
-                v = fmaxf(erow[qx] * acc, 0.0f);
+        // four voxels per thread (the box's rows are multiples of 4 long); a group whose voxels are all their own volume
+        // voxel, away from the x tails, on a row without z / y tails reads and writes whole float4s at its own position
+        const bool plain_row = in_zy && nz == 1 && ny == 1;
+        const float* crow0 = corr + ((int64_t)tz[0] * f.P[1] + ty[0]) * f.P[2];
+        for (int x = 4 * (blockIdx.x * 256 + threadIdx.x); x < f.P[2]; x += 4 * gridDim.x * 256) {
+            const int q0 = x - f.off[2];
+            if (plain_row && q0 >= f.hi[2] && q0 + 3 < f.N[2] - f.lo[2]) {
+                const float4 e = *reinterpret_cast<const float4*>(erow + q0);
+                const float4 c = *reinterpret_cast<const float4*>(crow0 + x);
+                *reinterpret_cast<float4*>(drow + x) = make_float4(fmaxf(e.x * c.x, 0.0f), fmaxf(e.y * c.y, 0.0f),
+                                                                    fmaxf(e.z * c.z, 0.0f), fmaxf(e.w * c.w, 0.0f));
+                continue;
             }
-            drow[x] = v;
+            float out4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int qx = q0 + k;
+                float v = 0.0f;
+                if (in_zy && qx >= -f.lo[2] && qx < f.N[2] + f.hi[2]) {
+                    qx += qx < 0 ? f.N[2] : (qx >= f.N[2] ? -f.N[2] : 0);
+                    int tx[2] = {qx + f.off[2], 0};
+                    int nx = 1;
+                    if (qx < f.hi[2]) tx[nx++] = qx + f.N[2] + f.off[2];
+                    else if (qx >= f.N[2] - f.lo[2]) tx[nx++] = qx - f.N[2] + f.off[2];
+                    float acc = 0.0f;
+                    for (int a = 0; a < nz; ++a)
+                        for (int b = 0; b < ny; ++b) {
+                            const float* crow = corr + ((int64_t)tz[a] * f.P[1] + ty[b]) * f.P[2];
+                            for (int c = 0; c < nx; ++c) acc += crow[tx[c]];
+                        }
+                    v = fmaxf(erow[qx] * acc, 0.0f);
+                }
+                out4[k] = v;
+            }
+            *reinterpret_cast<float4*>(drow + x) = make_float4(out4[0], out4[1], out4[2], out4[3]);
         }
     }
 }
