@@ -10,17 +10,24 @@ pytestmark = pytest.mark.gpu
 
 
 def test_fuzz_fused_engine_vs_oracle(gpu):
-    """Fused FFT engine on random power-of-two shapes and PSF extents (even, odd, 1) against the NumPy oracle:
-    R-L, Tikhonov, phase cross-correlation."""
-    from biahub_amd.deconvolve import richardson_lucy, tikhonov_zyx, transfer_function_device
+    """Fused FFT engine on random shapes it takes as they are — axes of 2^k, 3 * 2^k and 5 * 2^k — and PSF extents (even, odd,
+    1) against the NumPy oracle: R-L, Tikhonov, phase cross-correlation."""
+    from biahub_amd.deconvolve import richardson_lucy, richardson_lucy_plan, tikhonov_zyx, transfer_function_device
     from biahub_amd.estimate_stabilization import phase_cross_corr_device
 
     rng = np.random.default_rng(123)
     done = 0
-    while done < 14:
+    odd = 0
+    while done < 20:
         Z, Y, X = int(2 ** rng.integers(2, 7)), int(2 ** rng.integers(5, 9)), int(2 ** rng.integers(6, 11))
+        if done >= 10:  # the second half: an odd first step (3 or 5) on one to three axes
+            fz, fy, fx = (int(rng.choice([1, 3, 5])) for _ in range(3))
+            Z, Y, X = max(8, Z) * fz // (2 if fz > 1 else 1), max(64, Y) * fy // (2 if fy > 1 else 1), max(128, X) * fx // (4 if fx > 1 else 1)
         if Z * Y * X > 2**22:
             continue
+        if richardson_lucy_plan((1, 1, 1), (Z, Y, X))[1] != "engine":
+            continue
+        odd += any(n & (n - 1) for n in (Z, Y, X))
         done += 1
         pshape = tuple(int(min(rng.integers(1, 12), n)) for n in (Z, Y, X))
         volh = (rng.random((Z, Y, X)) * 300).astype(np.float32)
@@ -37,6 +44,7 @@ def test_fuzz_fused_engine_vs_oracle(gpu):
         sh, corr = phase_cross_corr_device(vol, torch.from_numpy(movh).to(gpu), "magnitude")
         wsh, wcorr = O.phase_cross_corr(volh, movh, "magnitude")
         assert np.array_equal(sh, wsh) and rel_err(corr.cpu().numpy(), wcorr) <= 1e-4, ((Z, Y, X), roll)
+    assert odd >= 6
 
 
 def test_fuzz_richardson_lucy_backends_vs_oracle(gpu, monkeypatch):
