@@ -48,6 +48,10 @@ constexpr int FC_TILE = 16384;     // complex elements per column tile (128 KiB)
 #define BH_FC_R16 0
 #endif
 constexpr bool FC_R16 = BH_FC_R16 != 0;
+#ifndef BH_FC_XR16
+#define BH_FC_XR16 BH_FC_R16  // the same choice for the row transforms of the X passes alone
+#endif
+constexpr bool FC_XR16 = BH_FC_XR16 != 0;
 
 __device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
