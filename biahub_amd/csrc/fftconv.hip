@@ -1030,14 +1030,68 @@ __global__ __launch_bounds__(256) void tikhonov_filter_rows_kernel(const float* 
     }
 }
 
+// z-slab variants: the X passes and the Y column pass work plane by plane, so a range of planes is the same launch on
+// offset pointers with Z shrunk (the Z pass needs every plane and is never slabbed)
+static int launch_x_slab(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, const float* in, cf* S, float* out,
+                         const float* aux, float eps, bool fuse_fwd, int z0, int nz) {
+    ConvPlan q = pl;
+    q.d.Z = nz;
+    const long rows = (long)z0 * pl.d.Y;
+    return launch_x(ctx, q, inverse, epi, in ? in + rows * pl.d.X : nullptr, S + rows * pl.d.XP, out ? out + rows * pl.d.X : nullptr,
+                    aux ? aux + rows * pl.d.X : nullptr, eps, fuse_fwd);
+}
+static int launch_col_y_slab(bh_ctx* ctx, const ConvPlan& pl, int mode, cf* S, int z0, int nz) {
+    ConvPlan q = pl;
+    q.d.Z = nz;
+    return launch_col(ctx, q, mode, false, S + (long)z0 * pl.d.Y * pl.d.XP, nullptr, 1.f);
+}
+
+// Planes per slab for the MALL hand-off below (0 = off): BH_FC_SLAB_MB megabytes of spectrum, default off.
+static int slab_planes(const ConvPlan& pl) {
+    static const int mb = getenv("BH_FC_SLAB_MB") ? atoi(getenv("BH_FC_SLAB_MB")) : 0;
+    if (mb <= 0) return 0;
+    const double plane = (double)pl.d.Y * pl.d.XP * sizeof(cf);
+    const int n = (int)((double)mb * 1048576.0 / plane);
+    return n >= 1 && n < pl.d.Z ? n : 0;
+}
+
 // Richardson-Lucy iterations with the X passes of consecutive convolutions fused:
 //   S = Xfwd(est);  repeat { Y, Z*OTF, Yinv ; [Xinv -> d/max(.,eps) -> Xfwd] ; Y, Z*conj(OTF), Yinv ;
 //                            [Xinv -> est = max(est*.,0) (stored) -> Xfwd] }   (last iteration: no trailing Xfwd)
 // 8 passes and 84 B/voxel per iteration instead of 10 passes and 96 B/voxel.
 // `est` is output only: the first pass fills it with max(d, 0).
+// With BH_FC_SLAB_MB set, the Yinv -> X -> Yfwd chain between two Z passes runs slab by slab (a few z planes at a time), so
+// that each kernel finds the planes its predecessor just wrote in the 256-MB memory-side cache instead of HBM.
 int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, const cf* otf, cf* spec, int iterations,
                             float eps, float* est) {
     if (iterations <= 0) return BH_OK;
+    const int slab = slab_planes(pl);
+    if (slab > 0) {
+        const int Z = pl.d.Z;
+        for (int z0 = 0; z0 < Z; z0 += slab) {
+            const int nz = std::min(slab, Z - z0);
+            BH_TRY(launch_x_slab(ctx, pl, false, 0, d, spec, est, nullptr, 0.f, false, z0, nz));
+            BH_TRY(launch_col_y_slab(ctx, pl, COL_FWD, spec, z0, nz));
+        }
+        for (int it = 0; it < iterations; ++it) {
+            const bool last = it + 1 == iterations;
+            BH_TRY(launch_col(ctx, pl, COL_CONV, true, spec, otf, 1.f));
+            for (int z0 = 0; z0 < Z; z0 += slab) {
+                const int nz = std::min(slab, Z - z0);
+                BH_TRY(launch_col_y_slab(ctx, pl, COL_INV, spec, z0, nz));
+                BH_TRY(launch_x_slab(ctx, pl, true, XE_RATIO, nullptr, spec, nullptr, d, eps, true, z0, nz));
+                BH_TRY(launch_col_y_slab(ctx, pl, COL_FWD, spec, z0, nz));
+            }
+            BH_TRY(launch_col(ctx, pl, COL_CORR, true, spec, otf, 1.f));
+            for (int z0 = 0; z0 < Z; z0 += slab) {
+                const int nz = std::min(slab, Z - z0);
+                BH_TRY(launch_col_y_slab(ctx, pl, COL_INV, spec, z0, nz));
+                BH_TRY(launch_x_slab(ctx, pl, true, XE_UPDATE, nullptr, spec, est, est, eps, !last, z0, nz));
+                if (!last) BH_TRY(launch_col_y_slab(ctx, pl, COL_FWD, spec, z0, nz));
+            }
+        }
+        return BH_OK;
+    }
     BH_TRY(launch_x(ctx, pl, false, 0, d, spec, est, nullptr, 0.f));  // est = max(d, 0) written by the same pass
     for (int it = 0; it < iterations; ++it) {
         BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));
