@@ -625,6 +625,31 @@ def test_richardson_lucy_properties_large(gpu, monkeypatch):
     assert float((est - est_ref).abs().max()) <= FFT_TOL * float(est_ref.abs().max())
 
 
+def test_richardson_lucy_properties_large_awkward(gpu, monkeypatch):
+    """The same properties on the deskewed config-3/4 volume (342, 1024, 1517), whose axes fit none of the engine's lengths:
+    it runs at the padded box (384, 1024, 1536) with radix-3 first steps, and agrees with the library pad-and-fold path."""
+    from biahub_amd.deconvolve import richardson_lucy, richardson_lucy_plan
+
+    shape = (342, 1024, 1517)
+    psf_h = O.gaussian_psf((33, 17, 17), (3.0, 1.5, 1.5))
+    assert richardson_lucy_plan(psf_h.shape, shape) == ((384, 1024, 1536), "engine-padded")
+    g = torch.Generator(device=gpu).manual_seed(8)
+    vol = (torch.rand(shape, generator=g, device=gpu) * 300 + 100).round_()
+    vol[0] += 500.0       # structure on the faces: a wrong wrap would show
+    vol[:, :, -1] += 250.0
+    psf = torch.from_numpy(psf_h).to(gpu)
+    est = richardson_lucy(vol, psf, 4, 1e-6)
+    assert float(est.min()) >= 0.0 and bool(torch.isfinite(est).all())
+    flux_in, flux_out = float(vol.double().sum()), float(est.double().sum())
+    assert abs(flux_out - flux_in) / flux_in < 1e-4
+    flat = richardson_lucy(torch.full(shape, 42.0, device=gpu), psf, 3, 1e-6)
+    assert float((flat - 42.0).abs().max()) < 1e-2
+    monkeypatch.setenv("BH_RL_ENGINE_PAD", "0")
+    assert richardson_lucy_plan(psf_h.shape, shape)[1] == "library"
+    est_ref = richardson_lucy(vol, psf, 4, 1e-6)
+    assert float((est - est_ref).abs().max()) <= FFT_TOL * float(est_ref.abs().max())
+
+
 def test_phase_cross_corr_golden_and_oracle(gpu):
     """estimate_stabilization.phase_cross_corr: shifts exact, correlation volume within FFT tolerance."""
     from biahub_amd.estimate_stabilization import phase_cross_corr
