@@ -77,14 +77,28 @@ def _resolve_cluster(cluster: str | None, local: bool = False) -> str:
     return resolved
 
 
+def _create_plate_once(*args, **kwargs):
+    """Rank 0 lays the output plate out, the other ranks wait for it: ``create_empty_plate`` rewrites plate / row / well
+    metadata, which concurrent ranks would race on (the reference creates the plate once, in the submitting process,
+    before any job starts: biahub/deskew.py:668-676)."""
+    rank, _ = parallel.init()
+    if rank == 0:
+        create_empty_plate(*args, **kwargs)
+    parallel.barrier()
+
+
 def _run_positions(step: str, inputs, outputs, make_job, out_parent: Path):
-    """Shard positions over ranks, run them in the foreground, write the job-id log the reference writes."""
+    """Shard positions over ranks (rank r on GPU LOCAL_RANK, bound by ``parallel.init``), run them in the foreground,
+    write the job-id log the reference writes.  Any rank that saw a position fail exits non-zero."""
     rank, world = parallel.init()
     pairs = list(zip(inputs, outputs))
     log_dir = out_parent / "slurm_output"
     if rank == 0:
         log_dir.mkdir(exist_ok=True)
         (log_dir / "submitit_jobs_ids.log").write_text("\n".join(f"{step}-{i}" for i in range(len(pairs))))
+    if world > 1:
+        click.echo(f"[rank {rank}/{world}] {step}: device {parallel.bound_device()}, "
+                   f"{len(parallel.shard_positions(pairs, rank, world))} of {len(pairs)} position(s)", err=True)
 
     def one(pair):
         src, dst = pair
@@ -93,11 +107,14 @@ def _run_positions(step: str, inputs, outputs, make_job, out_parent: Path):
         with open_ome_zarr(dst) as d:
             return float(np.prod(d.data.shape))
 
-    st = parallel.process_positions(pairs, one, rank, world)
+    st = parallel.process_positions(pairs, one, rank, world, label=lambda pair: str(pair[0]))
     parallel.barrier()
     rows = parallel.gather_stats(st)
-    if rank == 0 and sum(r.n_failed for r in rows):
-        raise click.ClickException(f"{sum(r.n_failed for r in rows)} position(s) failed")
+    failed = sum(r.n_failed for r in rows)
+    if st.n_failed:
+        raise click.ClickException(f"{st.n_failed} position(s) failed on rank {rank} (first: {st.first_error})")
+    if rank == 0 and failed:
+        raise click.ClickException(f"{failed} position(s) failed on other ranks")
 
 
 @click.group()
@@ -141,7 +158,7 @@ def deskew_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor
         version = settings.output_ome_zarr_version or ds.version
     out_shape, voxel = get_deskewed_data_shape((Z, Y, X), settings.ls_angle_deg, settings.px_to_scan_ratio,
                                                settings.keep_overhang, settings.average_n_slices, settings.pixel_size_um)
-    create_empty_plate(output_dirpath, [p.parts[-3:] for p in input_position_dirpaths], channel_names,
+    _create_plate_once(output_dirpath, [p.parts[-3:] for p in input_position_dirpaths], channel_names,
                        (T, C) + tuple(out_shape), scale=(1, 1) + tuple(voxel), version=version, compressor=_output_compressor())
     minutes, cpus, gb = estimate_resources((T, C, Z, Y, X), ram_multiplier=8, time_multiplier=0.5, max_num_cpus=16)
     echo_resources(cpus, cpus * gb, minutes)
@@ -193,7 +210,7 @@ def process_with_config_cli(input_position_dirpaths, output_dirpath, sbatch_file
             out_shape = (T, Cn, Z // f[0], Y // f[1], X // f[2])
             new_scale = scale[:2] + [scale[2] * f[0], scale[3] * f[1], scale[4] * f[2]]
             break
-    create_empty_plate(output_dirpath, [p.parts[-3:] for p in input_position_dirpaths], names, out_shape, scale=new_scale,
+    _create_plate_once(output_dirpath, [p.parts[-3:] for p in input_position_dirpaths], names, out_shape, scale=new_scale,
                        dtype=np.float32, version=settings.output_ome_zarr_version or version, compressor=_output_compressor())
     if sbatch_filepath:
         sbatch_to_submitit(sbatch_filepath)
@@ -258,7 +275,7 @@ def flat_field_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, mon
 def _same_shape_plate(inputs, output_dirpath, version_override, dtype=np.float32):
     with open_ome_zarr(inputs[0]) as ds:
         names, shape, scale, version = ds.channel_names, ds.data.shape, ds.scale, version_override or ds.version
-    create_empty_plate(output_dirpath, [p.parts[-3:] for p in inputs], names, shape, scale=scale, version=version,
+    _create_plate_once(output_dirpath, [p.parts[-3:] for p in inputs], names, shape, scale=scale, version=version,
                        dtype=dtype, compressor=_output_compressor())
     return names, shape, scale
 
@@ -286,9 +303,10 @@ def deconvolve_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, mon
     tf_store = Path(output_dirpath).parent / "transfer_function.zarr"
     from .io import create_empty_position
 
-    create_empty_position(tf_store, ["PSF"], (1, 1) + tuple(shape[-3:]), chunks=(1, 1, min(256, shape[-3])) + tuple(shape[-2:]),
-                          scale=scale)
-    open_ome_zarr(tf_store).data[0, 0] = tf
+    if parallel.world_info()[0] == 0:  # one writer for the shared store (every rank keeps its own device copy of tf)
+        create_empty_position(tf_store, ["PSF"], (1, 1) + tuple(shape[-3:]),
+                              chunks=(1, 1, min(256, shape[-3])) + tuple(shape[-2:]), scale=scale)
+        open_ome_zarr(tf_store).data[0, 0] = tf
     outs = get_output_paths(input_position_dirpaths, output_dirpath)
     _run_positions("deconvolve", input_position_dirpaths, outs,
                    lambda s, d: process_single_position(deconvolve, s, d, transfer_function=tf,
@@ -316,28 +334,71 @@ def rl_deconvolve_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, 
 
 @cli.command("stabilize")
 @_common
-@_config
+@click.option("--config-filepaths", "--config-filepath", "-c", "config_filepaths", multiple=True, required=True,
+              type=click.Path(exists=True, path_type=Path),
+              help="YAML configuration file(s): one for all positions, or one per FOV named after it (row_col_fov)")
 @click.option("--local", "-l", is_flag=True, default=False)
-def stabilize_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor, config_filepath, local):
-    """Apply per-timepoint affines to every listed channel (reference: ``biahub stabilize``)."""
+def stabilize_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor, config_filepaths, local):
+    """Apply per-timepoint affines to every channel (reference: ``biahub stabilize``, stabilize.py:93-318: all channels
+    of the input are stabilized — ``stabilization_channels = channel_names`` — over ``time_indices``; the output scale
+    is ``output_voxel_size``; with several config files each FOV takes the one whose name contains ``row_col_fov``)."""
+    from scipy.spatial.transform import Rotation
+
+    from .array_ops import copy_n_paste_czyx
     from .stabilize import apply_stabilization_transform
 
-    settings = yaml_to_model(config_filepath, StabilizationSettings)
-    matrices = [np.asarray(m, dtype=np.float64) for m in settings.affine_transform_zyx_list]
-    names, shape, _ = _same_shape_plate(input_position_dirpaths, output_dirpath, settings.output_ome_zarr_version)
-    T = shape[0]
-    if len(matrices) < T:
-        raise click.ClickException(f"{len(matrices)} transforms for {T} time points")
-    chans = [names.index(c) for c in settings.stabilization_channels]
-    tidx = list(range(T)) if settings.time_indices == "all" else list(np.atleast_1d(settings.time_indices))
+    config_filepaths = list(config_filepaths)
+    settings = yaml_to_model(config_filepaths[0], StabilizationSettings)
+    with open_ome_zarr(input_position_dirpaths[0]) as ds:
+        names, (T, C, Z, Y, X), version = ds.channel_names, ds.data.shape, ds.version
+    stabilization_channels = list(names)  # stabilize.py:150-151
+    # a transform that rotates ~90 degrees about x swaps the output's Y and X extents (stabilize.py:165-181)
+    U, _, Vt = np.linalg.svd(np.asarray(settings.affine_transform_zyx_list[0], dtype=np.float64)[:3, :3])
+    euler = Rotation.from_matrix(U @ Vt).as_euler("xyz", degrees=True)
+    out_zyx = (Z, X, Y) if np.isclose(euler[0], 90, atol=10) else (Z, Y, X)
+    if settings.time_indices == "all":
+        tidx = list(range(T))
+    elif isinstance(settings.time_indices, int):
+        tidx = [settings.time_indices]
+    else:
+        tidx = list(settings.time_indices)
+    _create_plate_once(output_dirpath, [p.parts[-3:] for p in input_position_dirpaths], names,
+                       (len(tidx), len(names)) + out_zyx, scale=list(settings.output_voxel_size),
+                       version=settings.output_ome_zarr_version or version, dtype=np.float32,
+                       compressor=_output_compressor())
+    _, cpus, gb = estimate_resources((T, C, Z, Y, X), ram_multiplier=16, max_num_cpus=16)
+    click.echo(f"Preparing jobs: {{'slurm_job_name': 'stabilize', 'slurm_mem_per_cpu': '{gb}G', "
+               f"'slurm_cpus_per_task': {cpus}}}")
+    if sbatch_filepath:
+        sbatch_to_submitit(sbatch_filepath)
+    _resolve_cluster(None, local=True)
+    otidx = list(range(len(tidx)))  # the output holds len(time_indices) frames, in the order listed
+    full = [slice(0, Z), slice(0, Y), slice(0, X)]
+
+    def job(src, dst):
+        cfg = config_filepaths[0]
+        if len(config_filepaths) > 1:  # per-FOV settings (stabilize.py:262-267)
+            fov = "_".join(Path(src).parts[-3:])
+            hits = [p for p in config_filepaths if fov in p.name]
+            if not hits:
+                raise ValueError(f"no stabilization config among {len(config_filepaths)} files matches FOV {fov}")
+            cfg = hits[0]
+        fov_settings = yaml_to_model(cfg, StabilizationSettings)
+        mats = [np.asarray(m, dtype=np.float64) for m in fov_settings.affine_transform_zyx_list]
+        if tidx and len(mats) <= max(tidx):
+            raise ValueError(f"{cfg}: {len(mats)} transforms, but time index {max(tidx)} is requested")
+        for name in names:
+            c = [[names.index(name)]]
+            if name in stabilization_channels:
+                process_single_position(apply_stabilization_transform, src, dst, input_channel_indices=c,
+                                        output_channel_indices=c, input_time_indices=tidx, output_time_indices=otidx,
+                                        list_of_shifts=mats, output_shape=out_zyx)
+            else:  # unreachable while every channel is stabilized, kept as the reference keeps it (stabilize.py:291-304)
+                process_single_position(copy_n_paste_czyx, src, dst, input_channel_indices=c, output_channel_indices=c,
+                                        input_time_indices=tidx, output_time_indices=otidx, czyx_slicing_params=full)
+
     outs = get_output_paths(input_position_dirpaths, output_dirpath)
-    _run_positions("stabilize", input_position_dirpaths, outs,
-                   lambda s, d: process_single_position(apply_stabilization_transform, s, d,
-                                                        input_channel_indices=[[c] for c in chans],
-                                                        output_channel_indices=[[c] for c in chans],
-                                                        input_time_indices=tidx, output_time_indices=tidx,
-                                                        list_of_shifts=matrices, output_shape=tuple(shape[-3:])),
-                   Path(output_dirpath).parent)
+    _run_positions("stabilize", input_position_dirpaths, outs, job, Path(output_dirpath).parent)
 
 
 @cli.command("register")
@@ -368,7 +429,7 @@ def register_cli(source_position_dirpaths, target_position_dirpaths, config_file
         out_zyx = tuple(s.stop - s.start for s in crop)
         click.echo(f"Cropping to the overlapping volume: {crop}")
     out_names = list(dict.fromkeys(list(settings.source_channel_names) + [settings.target_channel_name]))
-    create_empty_plate(output_dirpath, [p.parts[-3:] for p in source_position_dirpaths], out_names,
+    _create_plate_once(output_dirpath, [p.parts[-3:] for p in source_position_dirpaths], out_names,
                        (T, len(out_names)) + out_zyx, scale=out_scale, compressor=_output_compressor())
     outs = get_output_paths(source_position_dirpaths, output_dirpath)
     tidx = list(range(T)) if settings.time_indices == "all" else list(np.atleast_1d(settings.time_indices))
@@ -592,7 +653,8 @@ def concatenate_cli(config_filepath, output_dirpath, sbatch_filepath, cluster, m
     if init_only:
         return
     log_dir = Path(output_dirpath).parent / "slurm_output"
-    prep = concatenate(settings, output_dirpath, resume=resume, compressor=_output_compressor(), rank=rank, world=world)
+    prep = concatenate(settings, output_dirpath, resume=resume, compressor=_output_compressor(), rank=rank, world=world,
+                       create=False)  # rank 0 laid the plate out above
     if rank == 0:
         log_dir.mkdir(exist_ok=True)
         (log_dir / "submitit_jobs_ids.log").write_text("\n".join(f"concatenate-{i}" for i in range(len(prep["all_data_paths"]))))

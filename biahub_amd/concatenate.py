@@ -127,8 +127,9 @@ def _resolve_time_indices(settings: ConcatenateSettings, all_shapes) -> list[int
     return [settings.time_indices]
 
 
-def prepare_concatenate(settings: ConcatenateSettings, output_dirpath: Path, compressor=None) -> dict:
-    """Resolve the layout, check compatibility and create the output plate (biahub/concatenate.py:284-396)."""
+def prepare_concatenate(settings: ConcatenateSettings, output_dirpath: Path, compressor=None, create: bool = True) -> dict:
+    """Resolve the layout, check compatibility and (``create``) lay out the output plate (biahub/concatenate.py:284-396).
+    Under several ranks only one of them creates: plate / well metadata has one writer."""
     paths, names, in_idx, out_idx, slicing = get_channel_combiner_metadata(
         settings.concat_data_paths, settings.channel_names, [settings.Z_slice, settings.Y_slice, settings.X_slice])
     outputs = get_output_paths(paths, output_dirpath, ensure_unique_positions=settings.ensure_unique_positions)
@@ -158,11 +159,12 @@ def prepare_concatenate(settings: ConcatenateSettings, output_dirpath: Path, com
     if cropped[0] > Z or cropped[1] > Y or cropped[2] > X:
         raise ValueError("The cropped shape is larger than the original shape.")
     chunks = [1] + list(settings.chunks_czyx) if settings.chunks_czyx is not None else None
-    create_empty_plate(output_dirpath, [p.parts[-3:] for p in outputs], names, (len(times), len(names)) + tuple(cropped),
-                       chunks=chunks, scale=(1, 1) + tuple(voxels[0]), dtype=dtype,
-                       version=settings.output_ome_zarr_version or versions[0], compressor=compressor,
-                       shards_ratio=settings.shards_ratio)
-    click.echo(f"Created {output_dirpath} ({len(outputs)} positions)")
+    if create:
+        create_empty_plate(output_dirpath, [p.parts[-3:] for p in outputs], names,
+                           (len(times), len(names)) + tuple(cropped), chunks=chunks, scale=(1, 1) + tuple(voxels[0]),
+                           dtype=dtype, version=settings.output_ome_zarr_version or versions[0], compressor=compressor,
+                           shards_ratio=settings.shards_ratio)
+        click.echo(f"Created {output_dirpath} ({len(outputs)} positions)")
     return {"all_data_paths": paths, "output_position_paths": outputs, "input_channel_idx_list": in_idx,
             "output_channel_idx_list": out_idx, "all_slicing_params": slicing, "input_time_indices": times,
             "shape": (T, C, Z, Y, X), "dtype": dtype}
@@ -176,21 +178,27 @@ def _crop_unit(czyx, zyx_slicing_params, out_dtype=None):
 
 
 def concatenate(settings: ConcatenateSettings, output_dirpath: Path, init_only: bool = False, resume: bool = False,
-                compressor=None, rank: int = 0, world: int = 1) -> dict:
-    """Create the output plate, then crop-copy every source position into it (positions `rank::world` on this process)."""
-    prep = prepare_concatenate(settings, Path(output_dirpath), compressor)
+                compressor=None, rank: int = 0, world: int = 1, create: bool = True) -> dict:
+    """Create the output plate (``create``), then crop-copy the source positions into it.  Work is sharded by *output*
+    position (`rank::world` over the distinct destinations, in first-appearance order): sources that are channel-combined
+    into one position share its resume record and zattrs, so one position has one writer."""
+    prep = prepare_concatenate(settings, Path(output_dirpath), compressor, create=create)
     if init_only:
         return prep
     units = list(zip(prep["all_data_paths"], prep["output_position_paths"], prep["input_channel_idx_list"],
                      prep["output_channel_idx_list"], prep["all_slicing_params"]))
+    by_dst: dict = {}
+    for u in units:
+        by_dst.setdefault(str(u[1]), []).append(u)
     times = prep["input_time_indices"]
-    for src, dst, cin, cout, box in units[rank::world]:
-        existing = open_ome_zarr(dst).zattrs.get("extra_metadata") or {}
-        process_single_position(
-            _crop_unit, input_position_path=src, output_position_path=dst,
-            input_channel_indices=[[c] for c in cin], output_channel_indices=[[c] for c in cout],
-            input_time_indices=times, output_time_indices=list(range(len(times))), resume=resume,
-            resume_token=settings_fingerprint(settings),
-            extra_metadata={**existing, "biahub-concatenate": settings.model_dump()},
-            zyx_slicing_params=box, out_dtype=prep["dtype"])
+    for key in list(by_dst)[rank::world]:
+        for src, dst, cin, cout, box in by_dst[key]:
+            existing = open_ome_zarr(dst).zattrs.get("extra_metadata") or {}
+            process_single_position(
+                _crop_unit, input_position_path=src, output_position_path=dst,
+                input_channel_indices=[[c] for c in cin], output_channel_indices=[[c] for c in cout],
+                input_time_indices=times, output_time_indices=list(range(len(times))), resume=resume,
+                resume_token=settings_fingerprint(settings),
+                extra_metadata={**existing, "biahub-concatenate": settings.model_dump()},
+                zyx_slicing_params=box, out_dtype=prep["dtype"])
     return prep

@@ -196,7 +196,7 @@ def estimate_xyz_stabilization_pcc(input_position_dirpaths, output_folder_path, 
     transforms_out = output_folder_path / "transforms_per_position"
     shifts_out = output_folder_path / "shifts_per_position"
     transforms_out.mkdir(parents=True, exist_ok=True)
-    rank, _, world = parallel.world_info()
+    rank, world = parallel.init()  # binds this rank to GPU LOCAL_RANK before any device call
     for p in parallel.shard_positions(input_position_dirpaths, rank, world):
         estimate_xyz_stabilization_pcc_per_position(p, transforms_out, shifts_out, channel_index,
                                                     phase_cross_corr_settings, verbose=verbose, device=device)

@@ -33,7 +33,8 @@ _AXES = [
 
 
 def _write_json(path: Path, obj) -> None:
-    tmp = path.with_suffix(path.suffix + ".tmp")
+    # unique per writer: ranks / I/O threads that touch the same group must not share (and rename away) one temp file
+    tmp = path.with_suffix(f"{path.suffix}.{os.getpid()}.{threading.get_ident()}.tmp")
     tmp.write_text(json.dumps(obj, indent=1))
     os.replace(tmp, path)
 

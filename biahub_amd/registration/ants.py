@@ -386,7 +386,7 @@ def estimate_tczyx(
     output_folder_path = Path(output_folder_path)
     out = output_folder_path / "xyz_transforms"
     out.mkdir(parents=True, exist_ok=True)
-    rank, _, world = parallel.world_info()
+    rank, world = parallel.init()  # binds this rank to GPU LOCAL_RANK before any device call
     for t in range(rank, T, world):
         estimate_czyx(
             mov_czyx=np.asarray(mov_tczyx[t]), ref_czyx=np.asarray(ref_tczyx[t]), initial_tform=initial,

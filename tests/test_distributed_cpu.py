@@ -56,6 +56,98 @@ def test_two_rank_gloo_sharding():
     assert out[0][5] == out[1][5] and sum(v for _, _, v in out[0][5]) == 9000.0  # identical gathered status
 
 
+def _bind_worker(rank, world, port, q):
+    """Rank r must make GPU r its current device before anything else touches a GPU (device count mocked: 8)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), BH_DIST_BACKEND="gloo")
+    calls = []
+    torch.cuda.device_count = lambda: 8
+    torch.cuda.set_device = lambda d: calls.append(torch.device(d))
+    r, w = parallel.init()  # what every CLI command calls first (cli._create_plate_once / _run_positions)
+    dev = parallel.bound_device()
+    parallel.barrier()  # gloo: must not try to run on the (mocked) GPU
+    rows = parallel.gather_stats(parallel.RankStats(n_done=rank + 1))
+    q.put((rank, str(dev), [str(c) for c in calls], [x.n_done for x in rows]))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_bind_their_own_gpu():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bind_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, dev, calls, done in out:
+        assert dev == f"cuda:{rank}" and calls == [f"cuda:{rank}"]  # bound exactly once, to LOCAL_RANK
+        assert done == [1, 2]
+
+
+def test_bind_device_wraps_and_handles_no_gpu(monkeypatch):
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    seen = []
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: seen.append(str(d)))
+    assert str(parallel.bind_device()) == "cuda:1" and seen == ["cuda:1"]  # more ranks than GPUs wrap around
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
+    assert parallel.bind_device() is None and parallel.bound_device() is None
+    assert parallel._comm_device(None) == "cpu"
+
+
+def _plate_worker(rank, world, port, store, q):
+    """Both ranks run a CLI command's plate set-up at once: rank 0 creates, rank 1 waits; then both update attrs."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), BH_DIST_BACKEND="gloo")
+    from biahub_amd import cli, io
+
+    keys = [(row, str(col), "0") for row in "AB" for col in range(1, 5)]
+    cli._create_plate_once(store, keys, ["ch0", "ch1"], (1, 2, 4, 8, 8))
+    n = 0
+    for k in keys:  # every rank can open every position straight after the barrier
+        with io.open_ome_zarr(os.path.join(store, *k)) as p:
+            n += int(p.data.shape == (1, 2, 4, 8, 8))
+    for i in range(50):  # concurrent metadata writers on one group must not trip over a shared temp name
+        io._write_json(io.Path(store) / f"probe_{rank}.json", {"i": i})
+        io._write_json(io.Path(store) / "shared.json", {"rank": rank, "i": i})
+    q.put((rank, n))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_process_plate_creation(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    store = str(tmp_path / "plate.zarr")
+    procs = [ctx.Process(target=_plate_worker, args=(r, world, port, store, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out == [(0, 8), (1, 8)]
+    import json
+
+    assert json.loads((tmp_path / "plate.zarr" / "shared.json").read_text())["i"] == 49
+    assert not list((tmp_path / "plate.zarr").glob("*.tmp"))
+
+
+def test_process_positions_logs_failures(capsys):
+    def func(pos):
+        if pos == 1:
+            raise RuntimeError("corrupt chunk 3/0/0")
+        return 1.0
+
+    st = parallel.process_positions(range(3), func, 0, 1)
+    assert (st.n_done, st.n_failed) == (2, 1) and st.first_error == "1: RuntimeError: corrupt chunk 3/0/0"
+    err = capsys.readouterr().err
+    assert "position 1 failed" in err and "Traceback" in err and "corrupt chunk 3/0/0" in err
+
+
 def test_single_process_defaults():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         os.environ.pop(k, None)

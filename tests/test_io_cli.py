@@ -266,9 +266,32 @@ def test_cli_steps_end_to_end(gpu, tmp_path):
     stab = tmp_path / "stab.zarr"
     res = r.invoke(cli, ["stabilize", "-i", str(src / "A/1/0"), "-c", str(tmp_path / "stab.yml"), "-o", str(stab), "--local"])
     assert res.exit_code == 0, res.output
-    want = O.apply_affine_transform(data[("A", "1", "0", 1, 1)], np.array(mats[1]), shape[-3:])
-    assert np.abs(io.open_ome_zarr(stab / "A/1/0").data[1, 1] - want).max() <= 1e-5 * want.max()
-    assert not io.open_ome_zarr(stab / "A/1/0").data[1, 0].any()  # ch0 was not listed: left empty
+    sp = io.open_ome_zarr(stab / "A/1/0")
+    for c in (0, 1):  # every channel is stabilized, listed in stabilization_channels or not (stabilize.py:150-151)
+        want = O.apply_affine_transform(data[("A", "1", "0", 1, c)], np.array(mats[1]), shape[-3:])
+        assert np.abs(sp.data[1, c] - want).max() <= 1e-5 * want.max()
+    assert sp.data.dtype == np.float32 and list(sp.scale) == [1.0] * 5  # output_voxel_size is the output scale
+    # a time subset: the output holds len(time_indices) frames and takes output_voxel_size (stabilize.py:183-219)
+    (tmp_path / "stab1.yml").write_text(json.dumps({
+        "stabilization_estimation_channel": "ch0", "stabilization_type": "xyz", "stabilization_channels": ["ch1"],
+        "affine_transform_zyx_list": mats, "time_indices": [1], "output_voxel_size": [1, 1, 0.5, 0.25, 0.25]}))
+    res = r.invoke(cli, ["stabilize", "-i", str(src / "A/1/0"), "-c", str(tmp_path / "stab1.yml"), "-o",
+                         str(tmp_path / "stab1.zarr"), "--local"])
+    assert res.exit_code == 0, res.output
+    sp1 = io.open_ome_zarr(tmp_path / "stab1.zarr" / "A/1/0")
+    assert sp1.data.shape == (1, 2) + shape[-3:] and list(sp1.scale) == [1, 1, 0.5, 0.25, 0.25]
+    assert np.array_equal(sp1.data[0, 0], sp.data[1, 0]) and np.array_equal(sp1.data[0, 1], sp.data[1, 1])
+    # one settings file per FOV: each position takes the file whose name contains row_col_fov (stabilize.py:262-267)
+    (tmp_path / "A_1_0.yml").write_text((tmp_path / "stab.yml").read_text())
+    (tmp_path / "B_2_0.yml").write_text(json.dumps({
+        "stabilization_estimation_channel": "ch0", "stabilization_type": "xyz", "stabilization_channels": ["ch1"],
+        "affine_transform_zyx_list": [np.eye(4).tolist(), np.eye(4).tolist()], "time_indices": "all"}))
+    res = r.invoke(cli, expand_eat_all(["stabilize", "-i", str(src / "A/1/0"), str(src / "B/2/0"), "-c", str(tmp_path / "A_1_0.yml"),
+                         "-c", str(tmp_path / "B_2_0.yml"), "-o", str(tmp_path / "stab2.zarr"), "--local"]))
+    assert res.exit_code == 0, res.output
+    assert np.array_equal(io.open_ome_zarr(tmp_path / "stab2.zarr" / "A/1/0").data[1, 1], sp.data[1, 1])
+    assert np.array_equal(io.open_ome_zarr(tmp_path / "stab2.zarr" / "B/2/0").data[1, 1],
+                          data[("B", "2", "0", 1, 1)].astype(np.float32))  # identity transforms for that FOV
     # register
     (tmp_path / "reg.yml").write_text(json.dumps({
         "source_channel_names": ["ch0"], "target_channel_name": "ch1", "affine_transform_zyx": mats[1],
@@ -473,3 +496,48 @@ def test_cli_process_with_config_binning(gpu, tmp_path):
     cfg.write_text("processing_functions:\n- function: np.mean\n  input_channels: [ch0]\n")
     res = CliRunner().invoke(cli, ["process-with-config", "-i", str(src / "A/1/0"), "-c", str(cfg), "-o", str(out), "--local"])
     assert res.exit_code != 0
+
+
+@pytest.mark.gpu
+def test_cli_two_ranks_under_torchrun(gpu, tmp_path):
+    """The N>1 product path: ``torchrun --nproc-per-node 2 -m biahub_amd deskew`` shards positions over two ranks, each
+    bound to GPU ``LOCAL_RANK % device_count`` by ``parallel.init`` (reference fan-out: biahub/deskew.py:715-749).  On
+    the 1-GPU test box both ranks wrap onto cuda:0, so the status exchange runs over gloo (RCCL refuses two ranks on one
+    device); on an 8-GPU node the same command lands rank r on GPU r over RCCL."""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    src = tmp_path / "in.zarr"
+    keys = [(row, str(col), "0") for row in "AB" for col in (1, 2)]
+    data = make_plate(src, positions=keys, shape=(1, 2, 16, 24, 20))
+    cfg = tmp_path / "deskew.yml"
+    cfg.write_text(DESKEW_YML)
+    out = tmp_path / "deskewed.zarr"
+    env = dict(os.environ, BH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=str(Path(__file__).resolve().parent.parent))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", "-m", "biahub_amd", "deskew", "-i", *[str(src.joinpath(*k)) for k in keys],
+           "-c", str(cfg), "-o", str(out), "--cluster", "debug"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    n = torch.cuda.device_count()
+    for rank in (0, 1):  # each rank reports the GPU it was bound to and its share of the plate
+        assert f"[rank {rank}/2] deskew: device cuda:{rank % n}, 2 of 4 position(s)" in res.stderr, res.stderr
+    assert res.stdout.count("Deskew complete:") == 4
+    for k in keys:
+        got = io.open_ome_zarr(out.joinpath(*k))
+        for c in (0, 1):
+            want = O.fast_deskew_zyx(data[k + (0, c)].astype(np.float32), 36.17, 0.371, True, 3, "mean")
+            assert np.abs(got.data[0, c] - want).max() <= 1e-5 * want.max()
+    # a position that cannot be processed: its traceback is logged, the rank that saw it exits non-zero
+    import shutil
+
+    shutil.rmtree(src / "B" / "2" / "0" / "0" / "0")  # drop the chunk files of one position's t=0
+    (src / "B" / "2" / "0" / "0" / ".zarray").write_text("{ not json")
+    res = subprocess.run(cmd[:-6] + ["-c", str(cfg), "-o", str(tmp_path / "again.zarr"), "--cluster", "debug"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0
