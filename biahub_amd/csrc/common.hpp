@@ -90,9 +90,11 @@ struct bh_ctx {
     std::map<std::string, bh::Scratch> scratch;
     int num_cus = 256;
     int plans_replaced = 0;  // 3-D library plans that failed their self-check and were rebuilt decomposed (context.hip)
-    // Richardson-Lucy OTF cache: the OTF in "fc_otf" belongs to the PSF with this content hash / these shapes
+    // Richardson-Lucy OTF cache: the OTF in "fc_otf" belongs to the PSF kept in "rl_psf_kept" (compared byte for byte on every
+    // call; the hash is informational) / these shapes / this spectrum layout
     bool otf_valid = false;
     unsigned long long otf_hash = 0;
+    int otf_tag = 0;  // spectrum layout of the plan that built it (fftconv_plan_tag)
     int64_t otf_dims[6] = {0, 0, 0, 0, 0, 0};
 };
 

@@ -445,6 +445,7 @@ bool fftconv_supported(int64_t Z, int64_t Y, int64_t X);
 bool fftconv_supported_ex(int64_t Z, int64_t Y, int64_t X, bool radix3);
 int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out);
 size_t fftconv_spectrum_elems(const ConvPlan& pl);
+int fftconv_plan_tag(const ConvPlan& pl);
 int fftconv_make_otf(bh_ctx* ctx, const ConvPlan& pl, const float* padded_psf, cf* otf);
 int fftconv_apply(bh_ctx* ctx, const ConvPlan& pl, const float* in, const cf* otf, bool correlate, cf* spec,
                   int epilogue, const float* aux, float eps, float* out);
@@ -469,22 +470,32 @@ static bool use_fused_engine_any_order(int64_t Z, int64_t Y, int64_t X) {
     return fftconv_supported_ex(Z, Y, X, getenv("BH_FC_NORADIX3") == nullptr);
 }
 
-// order-sensitive 64-bit content hash of a small device array (one block; the PSF is a few thousand floats)
+// order-sensitive 64-bit content hash of a small device array (one block; the PSF is a few thousand floats).  With `kept`
+// (the device copy of the PSF whose OTF is cached) out[1] also says whether the two arrays are equal word for word: a hash
+// match alone never validates the cache.
 __global__ __launch_bounds__(256) void content_hash_kernel(const uint32_t* __restrict__ data, int64_t n,
-                                                           unsigned long long* out) {
+                                                           const uint32_t* __restrict__ kept, unsigned long long* out) {
     __shared__ unsigned long long sh[256];
+    __shared__ int differs;
+    if (threadIdx.x == 0) differs = 0;
+    __syncthreads();
     unsigned long long h = 0xcbf29ce484222325ull ^ (unsigned long long)threadIdx.x;
+    int diff = 0;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
-        h ^= (unsigned long long)data[i] + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+        const uint32_t v = data[i];
+        if (kept && kept[i] != v) diff = 1;
+        h ^= (unsigned long long)v + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
         h *= 0x100000001b3ull;
         h ^= h >> 29;
     }
     sh[threadIdx.x] = h;
+    if (diff) differs = 1;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long t = 0x84222325cbf29ce4ull;
         for (int i = 0; i < 256; ++i) t = (t ^ sh[i]) * 0x100000001b3ull + (t >> 31);
-        *out = t;
+        out[0] = t;
+        out[1] = (kept && !differs) ? 1ull : 0ull;
     }
 }
 
@@ -529,14 +540,22 @@ static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, 
     // The OTF only depends on the PSF and the shapes: a plate reuses one PSF for every position, so keep the OTF
     // across calls and rebuild it only when the PSF's content hash (or a shape) changes.
     unsigned long long* dhash = reinterpret_cast<unsigned long long*>(psum) + 1;
-    unsigned long long hash = 0;
-    hipLaunchKernelGGL(content_hash_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(psf),
-                       pz * py * px, dhash);
-    BH_CHECK_HIP(hipMemcpyAsync(&hash, dhash, sizeof(hash), hipMemcpyDeviceToHost, s));
-    BH_CHECK_HIP(hipStreamSynchronize(s));
+    unsigned long long hv[2] = {0, 0};
     const int64_t dims[6] = {pz, py, px, Z, Y, X};
-    bool hit = ctx->otf_valid && ctx->otf_hash == hash;
-    for (int i = 0; i < 6; ++i) hit = hit && ctx->otf_dims[i] == dims[i];
+    const int tag = fftconv_plan_tag(*pl);  // which spectrum layout the plan's kernels keep: an OTF only fits its own
+    bool same_key = ctx->otf_valid && ctx->otf_tag == tag;
+    for (int i = 0; i < 6; ++i) same_key = same_key && ctx->otf_dims[i] == dims[i];
+    const size_t psf_bytes = (size_t)(pz * py * px) * sizeof(float);
+    uint32_t* kept = nullptr;  // device copy of the PSF the cached OTF was built from
+    BH_TRY(get_scratch(ctx, "rl_psf_kept", psf_bytes, (void**)&kept));
+    // one small kernel + one 16-byte read-back decide the hit: the hash is only a log key, equality of the bytes decides.
+    // (A pointer match would not do instead of the read-back: the adapters upload the PSF anew for every call, and a buffer
+    // that kept its address may have changed its contents.)
+    hipLaunchKernelGGL(content_hash_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(psf),
+                       pz * py * px, same_key ? kept : nullptr, dhash);
+    BH_CHECK_HIP(hipMemcpyAsync(hv, dhash, sizeof(hv), hipMemcpyDeviceToHost, s));
+    BH_CHECK_HIP(hipStreamSynchronize(s));
+    const bool hit = same_key && hv[1] == 1ull;
     if (!hit) {
         ctx->otf_valid = false;
         // the padded PSF is staged in the spectrum buffer's own memory? no: it must survive the forward X pass that
@@ -544,7 +563,9 @@ static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, 
         BH_TRY(get_scratch(ctx, "fft_real", V * sizeof(float), (void**)&real));
         BH_TRY(stage_rl_psf(ctx, psf, pz, py, px, Z, Y, X, real, psum));
         BH_TRY(fftconv_make_otf(ctx, *pl, real, otf));
-        ctx->otf_hash = hash;
+        BH_CHECK_HIP(hipMemcpyAsync(kept, psf, psf_bytes, hipMemcpyDeviceToDevice, s));
+        ctx->otf_hash = hv[0];
+        ctx->otf_tag = tag;
         for (int i = 0; i < 6; ++i) ctx->otf_dims[i] = dims[i];
         ctx->otf_valid = true;
     }

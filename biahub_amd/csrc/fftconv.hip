@@ -746,6 +746,11 @@ struct ConvPlan {
     cf *tw3_y = nullptr, *tw3_z = nullptr;    // radix-3 twiddles where the axis is 3 * 2^k
     cf* tw3_x = nullptr;                      // same for the rows (M = 3 Lm)
     int xr = BH_FC_XR;                        // rows per X-pass tile: which instantiation of the X passes runs
+    // wave-private X passes (fftconv_xw.inc) for rows of 1024 / 2048 voxels: their tables, and the stored column of every
+    // bit-reversed position (they keep the spectrum row in their own column order)
+    bool xw = false;
+    cf* xw_tab = nullptr;
+    int* xw_col = nullptr;
 };
 
 // The X passes exist for two tile heights: 16 rows (M = X/2 up to 1024) and 8 rows (M up to 1536: a 3072-voxel row, for which
@@ -764,6 +769,8 @@ namespace xr8 {
 #undef BH_XP_XR
 #undef BH_XP_XNT
 }  // namespace xr8
+
+#include "fftconv_xw.inc"
 
 // ================================================================================================
 // host side
@@ -812,7 +819,9 @@ static int upload(const std::vector<cf>& h, cf** dptr) {
 
 int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     std::lock_guard<std::mutex> lock(g_plans_mu);
-    auto key = std::make_tuple(ctx->device, Z, Y, X);
+    // BH_FC_XW=0 keeps the tile-based X passes for every shape (A/B switch, read per call: plans of both kinds can coexist)
+    const bool xw_on = !(getenv("BH_FC_XW") && atoi(getenv("BH_FC_XW")) == 0) && (X == 1024 || X == 2048) && ((Y / 2) % 4) == 0;
+    auto key = std::make_tuple(ctx->device * 2 + (xw_on ? 1 : 0), Z, Y, X);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) {
         *out = &it->second;
@@ -885,10 +894,20 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     };
     pl.Wy = tile_w(Y / 2);
     pl.Wz = tile_w(Z);
+    if (xw_on) {
+        std::vector<int> col;
+        if (X == 2048) xw::make_tables<10>(h, col); else xw::make_tables<9>(h, col);
+        BH_TRY(upload(h, &pl.xw_tab));
+        BH_CHECK_HIP(hipMalloc(&pl.xw_col, col.size() * sizeof(int)));
+        BH_CHECK_HIP(hipMemcpy(pl.xw_col, col.data(), col.size() * sizeof(int), hipMemcpyHostToDevice));
+        pl.xw = true;
+    }
     auto ins = g_plans.emplace(key, pl);
     *out = &ins.first->second;
     return BH_OK;
 }
+
+int fftconv_plan_tag(const ConvPlan& pl) { return pl.xw ? 1 : 0; }
 
 size_t fftconv_spectrum_elems(const ConvPlan& pl) {
     return (size_t)pl.d.Z * pl.d.Y * pl.d.XP + 64;  // slack: a ragged last column tile reads past its row
@@ -966,8 +985,51 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
 #undef BH_COL_DISPATCH_
 }
 
+template <int LOGM>
+static int launch_xw_m(bh_ctx* ctx, const xw::Params& p, int mode) {
+    using G = xw::Geo<LOGM>;
+    const long npairs = (long)p.Z * (p.Y / 2);
+    const int grid = (int)std::min<long>(ceil_div(npairs, (long)xw::NW * G::PAIRS), ctx->num_cus);
+    auto run = [&](auto kern) -> int {
+        BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)G::LDS_BYTES));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(xw::NT), G::LDS_BYTES, ctx->stream, p);
+        BH_CHECK_HIP(hipGetLastError());
+        return BH_OK;
+    };
+    switch (mode) {
+        case xw::FWD: return run(xw::xw_kernel<LOGM, xw::FWD>);
+        case xw::INV_STORE: return run(xw::xw_kernel<LOGM, xw::INV_STORE>);
+        case xw::INV_RATIO: return run(xw::xw_kernel<LOGM, xw::INV_RATIO>);
+        case xw::INV_UPDATE: return run(xw::xw_kernel<LOGM, xw::INV_UPDATE>);
+        case xw::FUSED_RATIO: return run(xw::xw_kernel<LOGM, xw::FUSED_RATIO>);
+        default: return run(xw::xw_kernel<LOGM, xw::FUSED_UPDATE>);
+    }
+}
+
+static int launch_xw(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, const float* in, cf* S, float* out,
+                     const float* aux, float eps, bool fuse_fwd) {
+    xw::Params p;
+    p.in = in;
+    p.S = S;
+    p.out = out;
+    p.aux = aux;
+    p.tab = pl.xw_tab;
+    p.twy = pl.twy;
+    p.Z = pl.d.Z;
+    p.Y = pl.d.Y;
+    p.XP = pl.d.XP;
+    p.eps = eps;
+    const int mode = !inverse ? xw::FWD
+                     : epi == XE_STORE ? xw::INV_STORE
+                     : epi == XE_RATIO ? (fuse_fwd ? xw::FUSED_RATIO : xw::INV_RATIO)
+                                       : (fuse_fwd ? xw::FUSED_UPDATE : xw::INV_UPDATE);
+    return pl.d.M == 1024 ? launch_xw_m<10>(ctx, p, mode) : launch_xw_m<9>(ctx, p, mode);
+}
+
 static int launch_x(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, const float* in, cf* S, float* out,
                     const float* aux, float eps, bool fuse_fwd = false) {
+    if (pl.xw) return launch_xw(ctx, pl, inverse, epi, in, S, out, aux, eps, fuse_fwd);
     return pl.xr == 8 ? xr8::launch_x(ctx, pl, inverse, epi, in, S, out, aux, eps, fuse_fwd)
                       : xr16::launch_x(ctx, pl, inverse, epi, in, S, out, aux, eps, fuse_fwd);
 }
@@ -997,7 +1059,8 @@ int fftconv_apply(bh_ctx* ctx, const ConvPlan& pl, const float* in, const cf* ot
 // engine's scrambled half-spectrum layout.  One workgroup per spectrum row: coalesced read of tf[kz][ky][0..M],
 // bit-reversal permutation through LDS, coalesced write of filt[zs][ys][0..XP).
 __global__ __launch_bounds__(256) void tikhonov_filter_rows_kernel(const float* __restrict__ tf, float* __restrict__ filt,
-                                                                   ConvDims d, float reg, float scale) {
+                                                                   ConvDims d, float reg, float scale,
+                                                                   const int* __restrict__ xcol) {
     extern __shared__ float rowbuf[];  // [XP]
     const int Yh = d.Y / 2;
     for (long row = blockIdx.x; row < (long)d.Z * d.Y; row += gridDim.x) {
@@ -1021,6 +1084,7 @@ __global__ __launch_bounds__(256) void tikhonov_filter_rows_kernel(const float* 
             if (kx < d.M) {
                 const int rx = d.M / d.Lm, jx = kx / rx, tx = kx - rx * jx;
                 ps = tx * d.Lm + (int)(__brev((unsigned)jx) >> (32 - d.logM));
+                if (xcol) ps = xcol[ps];  // the wave-private X passes store position ps in column xcol[ps]
             }
             rowbuf[ps] = f;
         }
@@ -1149,7 +1213,7 @@ int fftconv_tikhonov(bh_ctx* ctx, const ConvPlan& pl, const float* in, const flo
     const double V = (double)pl.d.Z * pl.d.Y * pl.d.X;
     const int grid = ctx->num_cus * 8;
     hipLaunchKernelGGL(tikhonov_filter_rows_kernel, dim3(grid), dim3(256), pl.d.XP * sizeof(float), ctx->stream, tf_full,
-                       filt, pl.d, reg, (float)(2.0 / V));
+                       filt, pl.d, reg, (float)(2.0 / V), pl.xw ? pl.xw_col : nullptr);
     BH_CHECK_HIP(hipGetLastError());
     BH_TRY(launch_x(ctx, pl, false, 0, in, spec, nullptr, nullptr, 0.f));
     BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));

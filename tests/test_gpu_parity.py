@@ -1052,3 +1052,44 @@ def test_zarr_device_volume_io(gpu, tmp_path, version, shards_ratio, shuffle):
     assert np.array_equal(arr.read_volume_device(0, 0, gpu).cpu().numpy(), v0)
     f = tmp_path / "p" / "0" / ("c/0/0/0/0/0" if version == "0.5" else "0/0/0/0/0")
     assert f.stat().st_size < 8 * 96 * 160 * 2 * (2 if shards_ratio else 1) // 2      # it really is compressed
+
+
+# ----------------------------------------------------------------------------- wave-private X passes (csrc/fftconv_xw.inc)
+@pytest.mark.parametrize("shape,pshape", [
+    ((8, 32, 2048), (5, 5, 9)),      # M = 1024: one row pair per wavefront, radix 8 x 16 x 8
+    ((4, 64, 1024), (3, 7, 7)),      # M = 512: two row pairs per wavefront, radix 8 x 8 x 8
+    ((24, 96, 1024), (5, 5, 5)),     # Z, Y of 3 * 2^k: radix-3 column passes around the new X passes
+    ((12, 40, 2048), (3, 5, 11)),    # Z, Y too short for the engine as they are: the wrap-padded box (plain inverse with store)
+])
+def test_wave_private_x_passes(gpu, shape, pshape, monkeypatch):
+    """Rows of 1024 / 2048 voxels run the wave-private X passes (register FFT stages + two wave-local LDS exchanges, own
+    column order of the spectrum).  Richardson-Lucy (fused ratio / update kernels, forward, plain inverse), Tikhonov (filter
+    staged through the column map) and phase cross-correlation agree with the oracle and with the tile-based X passes
+    (BH_FC_XW=0) on the same inputs."""
+    from biahub_amd.deconvolve import compute_tranfser_function, deconvolve, richardson_lucy
+    from biahub_amd.estimate_stabilization import phase_cross_corr
+
+    vol = O.synthetic_volume(shape, seed=21, n_blobs=12)
+    vol[:, 0, :] += 400.0
+    vol[:, :, -1] += 250.0           # structure on the faces: wrap-around / column-order mistakes show up
+    psf = O.gaussian_psf(pshape, tuple(max(p / 4.0, 0.8) for p in pshape))
+    psf[0, 0, 0] += 0.02             # asymmetric: convolution and correlation differ
+    v, pt = torch.from_numpy(vol).to(gpu), torch.from_numpy(psf).to(gpu)
+    for it in (1, 4):
+        want = O.richardson_lucy_zyx(vol, psf, iterations=it, eps=1e-6)
+        monkeypatch.delenv("BH_FC_XW", raising=False)
+        new = richardson_lucy(v, pt, it, 1e-6).cpu().numpy()
+        monkeypatch.setenv("BH_FC_XW", "0")
+        old = richardson_lucy(v, pt, it, 1e-6).cpu().numpy()
+        monkeypatch.delenv("BH_FC_XW")
+        assert rel_err(new, want) <= FFT_TOL, (it, rel_err(new, want))
+        assert rel_err(new, old) <= 2e-5, (it, rel_err(new, old))
+    # Tikhonov: the reference's natural-order transfer function is staged into the new column order
+    tf = compute_tranfser_function(psf, shape)
+    got = deconvolve(vol[None], transfer_function=tf, regularization_strength=1e-2)
+    assert rel_err(got, O.deconvolve_czyx(vol[None], tf, 1e-2)) <= FFT_TOL
+    # phase cross-correlation: bare forward / inverse pair of the engine
+    mov = np.roll(vol, (1, -3, 17), axis=(0, 1, 2))
+    shift, _ = phase_cross_corr(vol, mov, normalization="magnitude")
+    want_shift, _ = O.phase_cross_corr(vol, mov, "magnitude")
+    assert np.array_equal(np.asarray(shift), np.asarray(want_shift)), (shift, want_shift)
