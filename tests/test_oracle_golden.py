@@ -233,3 +233,22 @@ def test_estimate_crop_oracle_matches_reference():
         got = O.estimate_crop_arrays(z[f"lf{j}"], z[f"ls{j}"], radius, find_lir)
         assert np.array_equal(np.array(got), z[f"crop{j}"]), (j, got)
 
+
+
+def test_wave_private_x_pass_model():
+    """tools/xw_model.py is the executable specification of csrc/fftconv_xw.inc (index maps, LDS addresses, twiddles,
+    untangle pairing, stored column order): its own checks against numpy's FFT must hold for both row lengths in use."""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("xw_model", Path(__file__).resolve().parent.parent / "tools" / "xw_model.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for logm in (9, 10):
+        m.check(logm)
+        x = m.XW(logm)
+        # lane 0 owns the two self-mirrored groups, every other lane a group and the group of the mirrored frequencies
+        for lam in range(1, x.lg):
+            g0, g1 = x.group_of(lam, 0), x.group_of(lam, 1)
+            assert all(x.mirror(8 * g0 + n) == 8 * g1 + 7 - n for n in range(8))
+        assert (x.group_of(0, 0), x.group_of(0, 1)) == (0, 1)
