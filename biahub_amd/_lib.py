@@ -20,6 +20,7 @@ FILL_NONE, FILL_CONSTANT, FILL_MEAN = 0, 1, 2
 INTERP_NEAREST, INTERP_LINEAR = 0, 1
 BOUNDARY_ITK, BOUNDARY_SCIPY_CONSTANT, BOUNDARY_ZEROS = 0, 1, 2
 PCC_NORM = {None: 0, "magnitude": 1, "classic": 2}
+FILTER_F32, FILTER_BF16 = 0, 1
 (T_DESKEW, T_FILL, T_RL_TOTAL, T_TIKHONOV, T_AFFINE, T_CROPFLIP, T_RL_ITER, T_TF, T_FLATFIELD) = range(9)
 
 _i64, _f64, _f32, _int, _vp = C.c_int64, C.c_double, C.c_float, C.c_int, C.c_void_p
@@ -59,6 +60,10 @@ SIGNATURES = {
     "bh_ctx_fft_plans_replaced": (_int, [_vp, C.POINTER(_int)]),
     "bh_richardson_lucy_plan": (_int, [_i64, _i64, _i64, _i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_int)]),
     "bh_tikhonov": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f64, _vp]),
+    "bh_inverse_filter": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _f64, _int, _int, _vp]),
+    "bh_phase_transfer_function_3d": (_int, [_vp, _i64, _i64, _i64, _f64, _f64, _f64, _i64, _f64, _f64, _f64, _int, _vp, _vp]),
+    "bh_fluorescence_transfer_function_3d": (_int, [_vp, _i64, _i64, _i64, _f64, _f64, _f64, _i64, _f64, _f64, _vp]),
+    "bh_fourier_central_cuboid": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64]),
     "bh_richardson_lucy": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _f32, _vp]),
     "bh_phase_cross_corr": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, C.POINTER(_f32), _vp]),
     "bh_image_stats": (_int, [_vp, _vp, _i64, _i64, _i64, C.POINTER(_f64)]),

@@ -314,6 +314,103 @@ def deconvolve_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, mon
                    Path(output_dirpath).parent)
 
 
+def _apply_inverse_transfer_function(input_position_dirpaths, transfer_function_dirpath, config_filepath, output_dirpath,
+                                     sbatch_filepath=None, cluster="debug", init_only=False, filter_storage="f32"):
+    """Orchestrator of biahub/apply_inverse_transfer_function.py:74-196: validate the config, lay the output plate out,
+    print the resource line, then one in-process job per position (sharded over ranks)."""
+    from .apply_inverse_transfer_function import (apply_inverse_transfer_function_single_position, estimate_resources as wo_estimate,
+                                                  get_reconstruction_output_metadata)
+    from .compute_transfer_function import _refuse_unsupported
+    from .settings import ReconstructionSettings
+
+    settings = yaml_to_model(config_filepath, ReconstructionSettings)
+    with open_ome_zarr(input_position_dirpaths[0]) as ds:
+        input_shape = ds.data.shape
+    meta = get_reconstruction_output_metadata(input_position_dirpaths[0], config_filepath)
+    _create_plate_once(output_dirpath, [p.parts[-3:] for p in input_position_dirpaths], meta["channel_names"], meta["shape"],
+                       scale=meta["scale"], dtype=np.float32, version=meta["version"], compressor=_output_compressor())
+    num_cpus, mem_per_cpu = wo_estimate(list(input_shape), settings, 16)
+    T, C, Z, Y, X = input_shape
+    minutes, _, _ = estimate_resources((T, len(settings.input_channel_names), Z, Y, X), time_multiplier=3.0, max_num_cpus=16)
+    echo_resources(num_cpus, num_cpus * mem_per_cpu, minutes)
+    if init_only:
+        click.echo(f"Created {output_dirpath} ({len(input_position_dirpaths)} positions, "
+                   f"{len(settings.output_channel_names)} output channels)")
+        return
+    try:
+        _refuse_unsupported(settings)
+    except NotImplementedError as e:
+        raise click.UsageError(str(e)) from e
+    if sbatch_filepath:
+        sbatch_to_submitit(sbatch_filepath)
+    _resolve_cluster(cluster)
+    outs = get_output_paths(input_position_dirpaths, output_dirpath)
+    _run_positions("apply-inv-tf", input_position_dirpaths, outs,
+                   lambda s, d: apply_inverse_transfer_function_single_position(
+                       s, transfer_function_dirpath, config_filepath, d, num_cpus, meta["channel_names"],
+                       filter_storage=filter_storage),
+                   Path(output_dirpath).parent)
+
+
+@cli.command("apply-inv-tf")
+@_common
+@click.option("--transfer-function-dirpath", "-t", default=None, type=click.Path(path_type=Path),
+              help="Path to transfer function zarr (not required for --init).")
+@_config
+@click.option("--cluster", type=click.Choice(["slurm", "local", "debug"], case_sensitive=False), default="debug",
+              show_default=True)
+@click.option("--init", "init_only", is_flag=True, default=False, help="Only initialize the output store and exit.")
+@click.option("--filter-storage", type=click.Choice(["f32", "bf16"]), default="f32", show_default=True,
+              help="Storage of the staged inverse filter on the GPU (bf16: half the filter bytes, products in float32).")
+def apply_inv_tf_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor, transfer_function_dirpath,
+                     config_filepath, cluster, init_only, filter_storage):
+    """Apply an inverse transfer function to a dataset using a configuration file (reference: ``biahub apply-inv-tf``,
+    apply_inverse_transfer_function.py:199-262)."""
+    if not init_only and transfer_function_dirpath is None:
+        raise click.UsageError("--transfer-function-dirpath / -t is required unless using --init.")
+    _apply_inverse_transfer_function(input_position_dirpaths, transfer_function_dirpath, config_filepath, output_dirpath,
+                                     sbatch_filepath, cluster, init_only, filter_storage)
+
+
+@cli.command("compute-tf")
+@click.option("--input-position-dirpaths", "-i", multiple=True, required=True, callback=_positions)
+@_config
+@click.option("--output-dirpath", "-o", required=True, type=click.Path(path_type=Path), help="Path to output.zarr")
+def compute_tf_cli(input_position_dirpaths, config_filepath, output_dirpath):
+    """Compute a transfer function using a dataset and configuration file; the shape of the first position counts
+    (reference: ``biahub compute-tf``, compute_transfer_function.py:16-38)."""
+    from .compute_transfer_function import compute_transfer_function_cli
+
+    try:
+        if parallel.init()[0] == 0:  # one writer; the store is shared by every rank of a later apply-inv-tf
+            compute_transfer_function_cli(input_position_dirpaths[0], config_filepath, output_dirpath)
+        parallel.barrier()
+    except NotImplementedError as e:
+        raise click.UsageError(str(e)) from e
+    click.echo(f"Transfer function computed and saved to {output_dirpath}.")
+
+
+@cli.command("reconstruct")
+@_common
+@_config
+@click.option("--cluster", type=click.Choice(["slurm", "local", "debug"], case_sensitive=False), default="debug",
+              show_default=True)
+def reconstruct_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor, config_filepath, cluster):
+    """``compute-tf`` followed by ``apply-inv-tf`` (reference: ``biahub reconstruct``, reconstruct.py:27-78): the transfer
+    function goes to ``<output parent>/transfer_function_<config stem>.zarr``."""
+    from .compute_transfer_function import compute_transfer_function_cli
+
+    tf_path = Path(output_dirpath).parent / ("transfer_function_" + Path(config_filepath).stem + ".zarr")
+    try:
+        if parallel.init()[0] == 0:
+            compute_transfer_function_cli(input_position_dirpaths[0], config_filepath, tf_path)
+        parallel.barrier()
+    except NotImplementedError as e:
+        raise click.UsageError(str(e)) from e
+    _apply_inverse_transfer_function(input_position_dirpaths, tf_path, config_filepath, output_dirpath, sbatch_filepath,
+                                     cluster)
+
+
 @cli.command("rl-deconvolve")
 @_common
 @_config

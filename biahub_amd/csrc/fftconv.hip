@@ -480,7 +480,8 @@ struct ConvDims {
 // ================================================================================================
 // Column passes (Y: two length-Y/2 halves per z; Z: fused forward x OTF x inverse)
 // ================================================================================================
-enum ColMode { COL_FWD = 0, COL_INV = 1, COL_FWD_SCALE = 2, COL_CONV = 3, COL_CORR = 4, COL_FILTER = 5 };
+// COL_CONV16: COL_CONV with the multiplier stored as bfloat16 pairs (4 B per complex bin, widened in registers, f32 products)
+enum ColMode { COL_FWD = 0, COL_INV = 1, COL_FWD_SCALE = 2, COL_CONV = 3, COL_CORR = 4, COL_FILTER = 5, COL_CONV16 = 6 };
 
 struct ColParams {
     cf* S;
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
     const int lane = tid % LPS;
     const int r0 = tid / LPS;
     const long ntiles = (long)p.nouter * p.ncoltiles;
-    constexpr bool HAS_OTF = (MODE == COL_CONV || MODE == COL_CORR || MODE == COL_FILTER);
+    constexpr bool HAS_OTF = (MODE == COL_CONV || MODE == COL_CORR || MODE == COL_FILTER || MODE == COL_CONV16);
     const int ncoltiles = p.ncoltiles, nsub = p.nsub, W_ = p.W, N_ = p.N, logN = p.logN, logW = p.logW, XP = p.XP;
     const long outer_stride = p.outer_stride, sub_stride = p.sub_stride, row_stride = p.row_stride;
     cf* const S = p.S;
@@ -576,6 +577,18 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
         const float* fsrc_ = reinterpret_cast<const float*>(otf) + tile_base(T); \
         BH_FOR8(BH_LDF)                                                        \
     }
+    // complex multiplier stored as bfloat16 pairs (COL_CONV16): one 32-bit word per complex element
+#define BH_LDH(u)                                                                                          \
+    if (u < ROUNDS) {                                                                                      \
+        const uint2 h_ = *reinterpret_cast<const uint2*>(hsrc_ + (long)min(r0 + u * RPR, N_ - 1) * row_stride); \
+        v##u = make_float4(__uint_as_float(h_.x << 16), __uint_as_float(h_.x & 0xffff0000u),               \
+                           __uint_as_float(h_.y << 16), __uint_as_float(h_.y & 0xffff0000u));              \
+    }
+#define BH_LOAD_FILTER16(T)                                                            \
+    {                                                                                  \
+        const unsigned int* hsrc_ = reinterpret_cast<const unsigned int*>(otf) + tile_base(T); \
+        BH_FOR8(BH_LDH)                                                                \
+    }
 #define BH_TO_LDS(u)                                                                            \
     if (u < ROUNDS && r0 + u * RPR < N_)                                                        \
         *reinterpret_cast<float4*>(buf + (size_t)(r0 + u * RPR) * W_ + 2 * lane) = v##u;
@@ -590,7 +603,7 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
             c.y = a.y * b.y;                                                                    \
             c.z = a.z * b.z;                                                                    \
             c.w = a.w * b.w;                                                                    \
-        } else if (MODE == COL_CONV) {                                                          \
+        } else if (MODE == COL_CONV || MODE == COL_CONV16) {                                    \
             c.x = a.x * b.x - a.y * b.y;                                                        \
             c.y = a.x * b.y + a.y * b.x;                                                        \
             c.z = a.z * b.z - a.w * b.w;                                                        \
@@ -639,6 +652,10 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
         if (MODE == COL_FILTER) {                                                                                  \
             const float2 f_ = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(otf) + tb_ + (long)row_ * row_stride); \
             v##u = make_float4(f_.x, f_.x, f_.y, f_.y);                                                            \
+        } else if (MODE == COL_CONV16) {                                                                           \
+            const uint2 h_ = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned int*>(otf) + tb_ + (long)row_ * row_stride); \
+            v##u = make_float4(__uint_as_float(h_.x << 16), __uint_as_float(h_.x & 0xffff0000u),                   \
+                               __uint_as_float(h_.y << 16), __uint_as_float(h_.y & 0xffff0000u));                  \
         } else {                                                                                                   \
             v##u = *reinterpret_cast<const float4*>(otf + tb_ + (long)row_ * row_stride);                          \
         }                                                                                                          \
@@ -649,7 +666,7 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
             BH_FFT_FWD(1, 2, false, true)
 #define BH_SPEC_MUL(a, b)                                                                                          \
     (MODE == COL_FILTER ? make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w)                                  \
-     : MODE == COL_CONV ? make_float4(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x, a.z * b.z - a.w * b.w,         \
+     : (MODE == COL_CONV || MODE == COL_CONV16) ? make_float4(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x, a.z * b.z - a.w * b.w, \
                                       a.z * b.w + a.w * b.z)                                                       \
                         : make_float4(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y, a.z * b.z + a.w * b.w,         \
                                       a.w * b.z - a.z * b.w))
@@ -690,7 +707,7 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
             BH_FFT_INV(1, 2, false, true)
         } else if (HAS_OTF) {
             // this tile's OTF arrives behind the forward FFT; the next tile's data behind the inverse FFT
-            if (MODE == COL_FILTER) BH_LOAD_FILTER(t) else BH_LOAD_TILE(otf, t)
+            if (MODE == COL_FILTER) BH_LOAD_FILTER(t) else if (MODE == COL_CONV16) BH_LOAD_FILTER16(t) else BH_LOAD_TILE(otf, t)
             BH_FFT_FWD(1, 2, FC_R16)
             BH_FOR8(BH_OTF_MUL)
             __syncthreads();
@@ -712,6 +729,8 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
 #undef BH_LD
 #undef BH_LDF
 #undef BH_LOAD_FILTER
+#undef BH_LDH
+#undef BH_LOAD_FILTER16
 #undef BH_LOAD_TILE
 #undef BH_TO_LDS
 #undef BH_OTF_MUL
@@ -970,6 +989,7 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
         case COL_FWD_SCALE: return run(col_pass_kernel<COL_FWD_SCALE, R, RDX>); \
         case COL_CONV: return run(col_pass_kernel<COL_CONV, R, RDX>);      \
         case COL_FILTER: return run(col_pass_kernel<COL_FILTER, R, RDX>);  \
+        case COL_CONV16: return run(col_pass_kernel<COL_CONV16, R, RDX>);  \
         default: return run(col_pass_kernel<COL_CORR, R, RDX>);            \
     }
 #define BH_COL_DISPATCH(R)                                 \
@@ -1092,6 +1112,94 @@ __global__ __launch_bounds__(256) void tikhonov_filter_rows_kernel(const float* 
         for (int ps = threadIdx.x; ps < d.XP; ps += 256) filt[row * d.XP + ps] = rowbuf[ps];
         __syncthreads();
     }
+}
+
+// Inverse filter of a general transfer function H (natural order, full spectrum (Z, Y, X), complex64 or float32), staged in
+// the engine's scrambled half-spectrum layout:  F = conj(H) / (|H|^2 + reg) * scale.  The real part of ifftn(fftn(x) F) is
+// what the reference keeps (waveorder: `.real` of the filtered inverse transform), i.e. only the Hermitian part
+// F_h(k) = (F(k) + conj(F(-k))) / 2 acts on a real volume — that is what a half-spectrum product can and does apply.
+// One workgroup per stored spectrum row; `bf16`: the staged value is rounded to bfloat16 pairs (round to nearest even).
+__device__ __forceinline__ unsigned int f32_to_bf16_bits(float f) {
+    const unsigned int u = __float_as_uint(f);
+    if ((u & 0x7f800000u) == 0x7f800000u) return u >> 16;  // inf / nan: truncate (a quiet-nan payload bit survives)
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+template <bool CPLX>
+__global__ __launch_bounds__(256) void inverse_filter_rows_kernel(const void* __restrict__ tf, void* __restrict__ filt,
+                                                                  ConvDims d, float reg, float scale, int bf16,
+                                                                  const int* __restrict__ xcol) {
+    extern __shared__ cf rowc[];  // [XP]
+    const int Yh = d.Y / 2;
+    for (long row = blockIdx.x; row < (long)d.Z * d.Y; row += gridDim.x) {
+        const int zs = (int)(row / d.Y), ys = (int)(row - (long)zs * d.Y);
+        const int tz = zs / d.Lz, rz = zs - tz * d.Lz;
+        const int kz = (d.Z / d.Lz) * (int)(__brev((unsigned)rz) >> (32 - d.logZ)) + tz;
+        const int half = ys / Yh, r = ys - half * Yh;
+        const int ty = r / d.Lyh, ry = r - ty * d.Lyh;
+        const int ky = 2 * ((Yh / d.Lyh) * (int)(__brev((unsigned)ry) >> (32 - d.logYh)) + ty) + half;
+        const int mz = kz ? d.Z - kz : 0, my = ky ? d.Y - ky : 0;  // -k
+        const long src = ((long)kz * d.Y + ky) * d.X, msrc = ((long)mz * d.Y + my) * d.X;
+        for (int kx = threadIdx.x; kx < d.XP; kx += 256) {
+            cf f = make_float2(0.f, 0.f);
+            if (kx <= d.M) {
+                const int mx = kx ? d.X - kx : 0;
+                cf h, hm;
+                if (CPLX) {
+                    h = reinterpret_cast<const cf*>(tf)[src + kx];
+                    hm = reinterpret_cast<const cf*>(tf)[msrc + mx];
+                } else {
+                    h = make_float2(reinterpret_cast<const float*>(tf)[src + kx], 0.f);
+                    hm = make_float2(reinterpret_cast<const float*>(tf)[msrc + mx], 0.f);
+                }
+                const float q = 1.0f / (h.x * h.x + h.y * h.y + reg), qm = 1.0f / (hm.x * hm.x + hm.y * hm.y + reg);
+                // F(k) = conj(h) q ; conj(F(-k)) = hm qm
+                f = make_float2(0.5f * (h.x * q + hm.x * qm) * scale, 0.5f * (-h.y * q + hm.y * qm) * scale);
+            }
+            int ps = kx;  // Nyquist and pad columns keep their place
+            if (kx < d.M) {
+                const int rx = d.M / d.Lm, jx = kx / rx, tx = kx - rx * jx;
+                ps = tx * d.Lm + (int)(__brev((unsigned)jx) >> (32 - d.logM));
+                if (xcol) ps = xcol[ps];
+            }
+            rowc[ps] = f;
+        }
+        __syncthreads();
+        for (int ps = threadIdx.x; ps < d.XP; ps += 256) {
+            const cf f = rowc[ps];
+            if (bf16)
+                reinterpret_cast<unsigned int*>(filt)[row * d.XP + ps] = f32_to_bf16_bits(f.x) | (f32_to_bf16_bits(f.y) << 16);
+            else
+                reinterpret_cast<cf*>(filt)[row * d.XP + ps] = f;
+        }
+        __syncthreads();
+    }
+}
+
+// filt: NS complex (f32) or NS 32-bit words (bf16 pairs), NS = fftconv_spectrum_elems
+int fftconv_stage_inverse_filter(bh_ctx* ctx, const ConvPlan& pl, const void* tf, bool tf_complex, float reg, bool bf16,
+                                 void* filt) {
+    const double V = (double)pl.d.Z * pl.d.Y * pl.d.X;
+    const int grid = ctx->num_cus * 8;
+    const int* xcol = pl.xw ? pl.xw_col : nullptr;
+    if (tf_complex)
+        hipLaunchKernelGGL(inverse_filter_rows_kernel<true>, dim3(grid), dim3(256), pl.d.XP * sizeof(cf), ctx->stream, tf, filt,
+                           pl.d, reg, (float)(2.0 / V), bf16 ? 1 : 0, xcol);
+    else
+        hipLaunchKernelGGL(inverse_filter_rows_kernel<false>, dim3(grid), dim3(256), pl.d.XP * sizeof(cf), ctx->stream, tf, filt,
+                           pl.d, reg, (float)(2.0 / V), bf16 ? 1 : 0, xcol);
+    BH_CHECK_HIP(hipGetLastError());
+    return BH_OK;
+}
+
+// out = irfft( rfft(in) * staged filter ): 5 passes, the product rides in the Z pass
+int fftconv_apply_staged_filter(bh_ctx* ctx, const ConvPlan& pl, const float* in, const void* filt, bool bf16, cf* spec,
+                                float* out) {
+    BH_TRY(launch_x(ctx, pl, false, 0, in, spec, nullptr, nullptr, 0.f));
+    BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));
+    BH_TRY(launch_col(ctx, pl, bf16 ? COL_CONV16 : COL_CONV, true, spec, reinterpret_cast<const cf*>(filt), 1.f));
+    BH_TRY(launch_col(ctx, pl, COL_INV, false, spec, nullptr, 1.f));
+    BH_TRY(launch_x(ctx, pl, true, XE_STORE, nullptr, spec, out, nullptr, 0.f));
+    return BH_OK;
 }
 
 // z-slab variants: the X passes and the Y column pass work plane by plane, so a range of planes is the same launch on

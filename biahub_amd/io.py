@@ -104,7 +104,8 @@ def _host_volume(shape, dtype) -> np.ndarray:
 
 
 _V3_DTYPES = {"bool": "|b1", "int8": "|i1", "uint8": "|u1", "int16": "<i2", "uint16": "<u2", "int32": "<i4",
-              "uint32": "<u4", "int64": "<i8", "uint64": "<u8", "float16": "<f2", "float32": "<f4", "float64": "<f8"}
+              "uint32": "<u4", "int64": "<i8", "uint64": "<u8", "float16": "<f2", "float32": "<f4", "float64": "<f8",
+              "complex64": "<c8"}
 _V3_NAMES = {np.dtype(v): k for k, v in _V3_DTYPES.items()}
 _MISSING = 0xFFFFFFFFFFFFFFFF  # offset and length of an absent inner chunk in a shard index
 
@@ -631,7 +632,9 @@ class Position:
         if self.zarr_format is None:
             raise FileNotFoundError(f"{path} is not a zarr group")
         self.zattrs = _read_group_attrs(self.path)
-        self.data = ZarrArray(self.path / "0")
+        # a transfer-function store (waveorder's "fov" layout, biahub/compute_transfer_function.py:36) holds named arrays
+        # and no "0"
+        self.data = ZarrArray(self.path / "0") if self._is_array(self.path / "0") else None
 
     def __enter__(self):
         return self
@@ -642,13 +645,37 @@ class Position:
     def close(self) -> None:
         """Nothing is held open between calls; present because callers of iohub's nodes close them."""
 
+    @staticmethod
+    def _is_array(p: Path) -> bool:
+        return (p / ".zarray").exists() or ((p / "zarr.json").exists() and
+                                            json.loads((p / "zarr.json").read_text()).get("node_type") == "array")
+
     def array_keys(self) -> list[str]:
-        return ["0"]
+        return sorted(c.name for c in self.path.iterdir() if c.is_dir() and self._is_array(c))
 
     def __getitem__(self, name):
-        if str(name) != "0":
+        if str(name) == "0" and self.data is not None:
+            return self.data
+        if not self._is_array(self.path / str(name)):
             raise KeyError(name)
-        return self.data
+        return ZarrArray(self.path / str(name))
+
+    def create_image(self, name: str, data: np.ndarray, chunks=None, compressor=None) -> "ZarrArray":
+        """Write a named 5-D array next to (or instead of) "0" — iohub's ``Position.create_image`` as waveorder's
+        compute-tf uses it for the transfer functions."""
+        data = np.asarray(data)
+        if data.ndim != 5:
+            raise ValueError("create_image expects a (T, C, Z, Y, X) array")
+        T, C, Z, Y, X = data.shape
+        if chunks is None:
+            chunks = (1, 1, max(1, min(Z, (64 << 20) // max(1, Y * X * data.dtype.itemsize))), Y, X)
+        _create_array(self.path / str(name), data.shape, tuple(int(c) for c in chunks), data.dtype, self.zarr_format,
+                      dict(BLOSC_DEFAULT) if compressor == "blosc" else compressor, None)
+        arr = ZarrArray(self.path / str(name))
+        for t in range(T):
+            for c in range(C):
+                arr.write_volume(t, c, data[t, c])
+        return arr
 
     @property
     def channel_names(self) -> list[str]:
@@ -741,13 +768,32 @@ def create_empty_position(path, channel_names, shape, chunks=None, scale=(1, 1, 
         zc = max(1, min(Z, (64 << 20) // max(1, Y * X * dt.itemsize)))
         chunks = (1, 1, zc, Y, X)
     chunks = tuple(int(c) for c in chunks)
-    (path / "0").mkdir(parents=True, exist_ok=True)
     fmt = 2 if version == "0.4" else 3
     _write_group(path, fmt, _position_zattrs(channel_names, scale, version, metadata), version)
+    _create_array(path / "0", (T, C, Z, Y, X), chunks, dt, fmt, compressor, shards_ratio)
+
+
+def create_empty_fov(path, channel_names, scale=(1, 1, 1, 1, 1), version="0.4", metadata=None) -> "Position":
+    """A position group without an array "0": the container of a transfer-function store (``open_ome_zarr(path,
+    layout="fov", mode="w", channel_names=...)`` in waveorder's compute-tf), filled with ``Position.create_image``."""
+    path = Path(path)
+    version = str(version)
+    fmt = 2 if version == "0.4" else 3
+    path.mkdir(parents=True, exist_ok=True)
+    _write_group(path, fmt, _position_zattrs(channel_names, scale, version, metadata), version)
+    return Position(path)
+
+
+def _create_array(apath: Path, shape, chunks, dt, fmt: int, compressor, shards_ratio) -> None:
+    """Metadata of one 5-D array (zarr v2 ``.zarray`` or v3 ``zarr.json``); chunks appear as they are written."""
+    apath = Path(apath)
+    dt = np.dtype(dt)
+    T, C, Z, Y, X = (int(v) for v in shape)
+    apath.mkdir(parents=True, exist_ok=True)
     if fmt == 2:
         if shards_ratio:
             raise ValueError("sharding needs OME-Zarr 0.5 (zarr v3)")
-        _write_json(path / "0" / ".zarray", {
+        _write_json(apath / ".zarray", {
             "zarr_format": 2, "shape": [T, C, Z, Y, X], "chunks": list(chunks),
             "dtype": dt.str, "compressor": compressor, "fill_value": 0, "filters": None, "order": "C",
             "dimension_separator": "/"})
@@ -766,7 +812,7 @@ def create_empty_position(path, channel_names, shape, chunks=None, scale=(1, 1, 
             "index_location": "end"}}]
     else:
         outer, codecs = chunks, inner
-    _write_json(path / "0" / "zarr.json", {
+    _write_json(apath / "zarr.json", {
         "zarr_format": 3, "node_type": "array", "shape": [T, C, Z, Y, X], "data_type": _V3_NAMES[dt],
         "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": list(outer)}},
         "chunk_key_encoding": {"name": "default", "configuration": {"separator": "/"}},

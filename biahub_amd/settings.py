@@ -10,7 +10,8 @@ from __future__ import annotations
 from typing import Literal
 
 import numpy as np
-from pydantic import BaseModel, ConfigDict, NonNegativeInt, PositiveFloat, PositiveInt, field_validator, model_validator
+from pydantic import (BaseModel, ConfigDict, NonNegativeFloat, NonNegativeInt, PositiveFloat, PositiveInt, field_validator,
+                      model_validator)
 
 OmeZarrVersion = Literal["0.4", "0.5"]
 
@@ -314,3 +315,86 @@ class ConcatenateSettings(_Strict):
                     raise ValueError(f"{axis}_slice must be 'all', a single slice specification, or a list with the same length "
                                      f"as concat_data_paths ({n})")
         return self
+
+
+# ----------------------------------------------------------------------------- reconstruction (compute-tf / apply-inv-tf)
+# The YAML surface of waveorder's ReconstructionSettings (waveorder/cli/settings.py, 3.0.5 — absent from the reference tree,
+# restated from its published models and from the configurations the reference ships and tests with:
+# nextflow/configs/a549/reconstruct.yml, tests/test_cli/test_reconstruct_cli.py:13-37).  biahub validates its configs
+# against that model (biahub/apply_inverse_transfer_function.py:113).
+class FourierApplyInverseSettings(_Strict):
+    reconstruction_algorithm: Literal["Tikhonov", "TV"] = "Tikhonov"
+    regularization_strength: NonNegativeFloat = 1e-3
+    TV_rho_strength: PositiveFloat = 1e-3
+    TV_iterations: NonNegativeInt = 1
+
+
+class _FourierTransferFunctionSettings(_Strict):
+    yx_pixel_size: PositiveFloat | None = None  # None: the input store's scale
+    z_pixel_size: PositiveFloat | None = None
+    z_padding: NonNegativeInt = 0
+    z_focus_offset: int | float | Literal["auto"] = 0
+    index_of_refraction_media: PositiveFloat = 1.3
+    numerical_aperture_detection: PositiveFloat = 1.2
+
+    @model_validator(mode="after")
+    def _na_below_index(self):
+        if self.numerical_aperture_detection > self.index_of_refraction_media:
+            raise ValueError("numerical_aperture_detection must not exceed index_of_refraction_media")
+        return self
+
+
+class PhaseTransferFunctionSettings(_FourierTransferFunctionSettings):
+    wavelength_illumination: PositiveFloat = 0.532
+    numerical_aperture_illumination: NonNegativeFloat = 0.5
+    invert_phase_contrast: bool = False
+
+    @model_validator(mode="after")
+    def _na_ill(self):
+        if self.numerical_aperture_illumination > self.numerical_aperture_detection:
+            raise ValueError("numerical_aperture_illumination must not exceed numerical_aperture_detection")
+        return self
+
+
+class FluorescenceTransferFunctionSettings(_FourierTransferFunctionSettings):
+    wavelength_emission: PositiveFloat = 0.507
+
+
+class PhaseSettings(_Strict):
+    transfer_function: PhaseTransferFunctionSettings = PhaseTransferFunctionSettings()
+    apply_inverse: FourierApplyInverseSettings = FourierApplyInverseSettings()
+
+
+class FluorescenceSettings(_Strict):
+    transfer_function: FluorescenceTransferFunctionSettings = FluorescenceTransferFunctionSettings()
+    apply_inverse: FourierApplyInverseSettings = FourierApplyInverseSettings()
+
+
+class ReconstructionSettings(_Strict):
+    input_channel_names: list[str] = [f"State{i}" for i in range(4)]
+    time_indices: NonNegativeInt | list[NonNegativeInt] | Literal["all"] = "all"
+    reconstruction_dimension: Literal[2, 3] = 3
+    birefringence: dict | None = None  # accepted so that such configs are refused with a clear message, not a schema error
+    phase: PhaseSettings | None = None
+    fluorescence: FluorescenceSettings | None = None
+
+    @model_validator(mode="after")
+    def _one_modality(self):
+        if self.fluorescence is not None and (self.phase is not None or self.birefringence is not None):
+            raise ValueError("fluorescence reconstructions cannot be combined with phase or birefringence")
+        if self.fluorescence is None and self.phase is None and self.birefringence is None:
+            raise ValueError("specify one of birefringence, phase, fluorescence")
+        return self
+
+    @property
+    def output_channel_names(self) -> list[str]:
+        """Channels of the reconstruction (waveorder get_reconstruction_output_metadata)."""
+        d = self.reconstruction_dimension
+        names = []
+        if self.birefringence is not None:
+            names += ["Retardance", "Orientation", "BF", "Pol"]
+        if self.phase is not None:
+            names.append(f"Phase{d}D")
+        if self.fluorescence is not None:
+            names.append(f"{self.input_channel_names[0]}_Density{d}D")
+        return names

@@ -20,6 +20,12 @@
  *   bh_overhang_fill       <- biahub/deskew.py:339-368  _fill_overhang_torch
  *   bh_transfer_function   <- biahub/deconvolve.py:30-43 compute_tranfser_function
  *   bh_tikhonov            <- biahub/deconvolve.py:46-66 deconvolve (waveorder Tikhonov)
+ *   bh_inverse_filter      <- biahub/apply_inverse_transfer_function.py:158-170 (the per-position job: waveorder's
+ *                             apply_inverse_transfer_function_single_position -> models.phase_thick_3d /
+ *                             isotropic_fluorescent_thick_3d .apply_inverse_transfer_function, Tikhonov)
+ *   bh_phase_transfer_function_3d, bh_fluorescence_transfer_function_3d
+ *                          <- biahub/compute_transfer_function.py:16-38, reconstruct.py:59-64 (waveorder's
+ *                             compute_transfer_function_cli -> models.*.calculate_transfer_function)
  *   bh_richardson_lucy     <- (north-star extension; no reference function)
  *   bh_phase_cross_corr    <- biahub/estimate_stabilization.py:199-256 phase_cross_corr
  *   bh_image_stats, bh_smooth_shrink, bh_mattes_mi
@@ -193,6 +199,36 @@ int bh_transfer_function(bh_ctx* ctx, const float* psf, int64_t pz, int64_t py, 
  * may alias. */
 int bh_tikhonov(bh_ctx* ctx, const float* in, const float* tf_full, int64_t Z, int64_t Y, int64_t X,
                 double regularization_strength, float* out);
+
+/* Inverse transfer function (BASELINE config 5).  waveorder 3.0.5 is not in the reference tree: the arithmetic is restated
+ * from its published algorithm — parity unpinned.
+ *   out = crop_z( Re ifftn( fftn( pad_z( n(in) ) ) * conj(H) / (|H|^2 + reg) ) )
+ * in / out: float32 (Z, Y, X) (may alias); tf: H in natural FFT order over (Z + 2 z_padding, Y, X), complex64
+ * (tf_is_complex = 1: a phase transfer function) or float32 (an optical transfer function); normalize = 1 applies
+ * n(x) = x / mean(x) - 1 first (waveorder inten_normalization_3D, phase) and the z padding planes hold 0.
+ * filter_storage: BH_FILTER_F32, or BH_FILTER_BF16 — the staged filter is kept as bfloat16 pairs (half the filter bytes in
+ * the Z pass, products in float32); only for shapes the fused FFT engine takes. */
+enum { BH_FILTER_F32 = 0, BH_FILTER_BF16 = 1 };
+int bh_inverse_filter(bh_ctx* ctx, const float* in, const void* tf, int tf_is_complex, int64_t Z, int64_t Y, int64_t X,
+                      int64_t z_padding, double regularization_strength, int normalize, int filter_storage, float* out);
+
+/* Transfer functions from the optical parameters, complex64 (Z + 2 z_padding, Y, X) in natural FFT order.
+ * Phase: weak-object transfer functions of the real and imaginary scattering potential (waveorder
+ * phase_thick_3d.calculate_transfer_function at its native sampling; the caller refuses pixel sizes above Nyquist, where
+ * waveorder oversamples).  Fluorescence: fftn(|ifft2(pupil * propagation)|^2) / max. */
+int bh_phase_transfer_function_3d(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, double yx_pixel_size, double z_pixel_size,
+                                  double wavelength_illumination, int64_t z_padding, double index_of_refraction_media,
+                                  double numerical_aperture_illumination, double numerical_aperture_detection,
+                                  int invert_phase_contrast, void* real_potential_tf, void* imag_potential_tf);
+int bh_fluorescence_transfer_function_3d(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, double yx_pixel_size,
+                                         double z_pixel_size, double wavelength_emission, int64_t z_padding,
+                                         double index_of_refraction_media, double numerical_aperture_detection,
+                                         void* optical_transfer_function);
+
+/* dst (nz, ny, nx) = the low-frequency corners of the complex64 spectrum src (NZ, NY, NX), both in FFT order (waveorder
+ * sampling.nd_fourier_central_cuboid: how a transfer function computed on a finer grid comes back to the data's grid). */
+int bh_fourier_central_cuboid(bh_ctx* ctx, const void* src, int64_t NZ, int64_t NY, int64_t NX, void* dst, int64_t nz,
+                              int64_t ny, int64_t nx);
 
 /* Host-only: the transform box and back-end bh_richardson_lucy picks for a shape.  BH_RL_ENGINE: the fused FFT engine at
  * the volume's own (power-of-two) shape; BH_RL_ENGINE_PADDED: the engine at a larger box (axes of 2^k, 3 * 2^k or

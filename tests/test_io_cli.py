@@ -541,3 +541,131 @@ def test_cli_two_ranks_under_torchrun(gpu, tmp_path):
     res = subprocess.run(cmd[:-6] + ["-c", str(cfg), "-o", str(tmp_path / "again.zarr"), "--cluster", "debug"], env=env,
                          capture_output=True, text=True, timeout=600)
     assert res.returncode != 0
+
+
+RECON_YML = {
+    "input_channel_names": ["BF"], "time_indices": "all", "reconstruction_dimension": 3,
+    "phase": {"transfer_function": {"wavelength_illumination": 0.450, "yx_pixel_size": 0.1, "z_pixel_size": 0.25, "z_padding": 0,
+                                    "index_of_refraction_media": 1.3, "numerical_aperture_detection": 1.2,
+                                    "numerical_aperture_illumination": 0.5, "invert_phase_contrast": False},
+              "apply_inverse": {"reconstruction_algorithm": "Tikhonov", "regularization_strength": 1e-3}}}
+
+
+def test_reconstruction_settings_surface():
+    """The reference's reconstruct configurations load (tests/test_cli/test_reconstruct_cli.py:13-37,
+    nextflow/configs/a549/reconstruct.yml); what this package does not reconstruct is refused by name."""
+    from biahub_amd.compute_transfer_function import _refuse_unsupported
+    from biahub_amd.settings import ReconstructionSettings
+
+    s = ReconstructionSettings(**RECON_YML)
+    assert s.output_channel_names == ["Phase3D"] and s.phase.apply_inverse.TV_iterations == 1
+    a549 = {"input_channel_names": ["BF - Oblique"], "time_indices": "all", "reconstruction_dimension": 3,
+            "phase": {"transfer_function": {"wavelength_illumination": 0.532, "z_padding": 5, "index_of_refraction_media": 1.4,
+                                            "numerical_aperture_detection": 1.35, "numerical_aperture_illumination": 0.52,
+                                            "invert_phase_contrast": False},
+                      "apply_inverse": {"reconstruction_algorithm": "Tikhonov", "regularization_strength": 0.01,
+                                        "TV_rho_strength": 0.001, "TV_iterations": 1}}}
+    s = ReconstructionSettings(**a549)
+    assert s.phase.transfer_function.yx_pixel_size is None and s.phase.transfer_function.z_padding == 5
+    _refuse_unsupported(s)
+    f = ReconstructionSettings(input_channel_names=["GFP"], fluorescence={})
+    assert f.output_channel_names == ["GFP_Density3D"] and f.fluorescence.transfer_function.wavelength_emission == 0.507
+    with pytest.raises(ValueError, match="cannot be combined"):
+        ReconstructionSettings(input_channel_names=["GFP"], fluorescence={}, phase={})
+    with pytest.raises(ValueError, match="specify one of"):
+        ReconstructionSettings(input_channel_names=["GFP"])
+    with pytest.raises(ValueError):
+        ReconstructionSettings(input_channel_names=["GFP"], phase={"transfer_function": {"unknown_key": 1}})
+    with pytest.raises(NotImplementedError, match="birefringence"):
+        _refuse_unsupported(ReconstructionSettings(birefringence={"transfer_function": {"swing": 0.1}}))
+    with pytest.raises(NotImplementedError, match="3-D"):
+        _refuse_unsupported(ReconstructionSettings(input_channel_names=["BF"], phase={}, reconstruction_dimension=2))
+    with pytest.raises(NotImplementedError, match="Tikhonov"):
+        _refuse_unsupported(ReconstructionSettings(input_channel_names=["BF"], phase={"apply_inverse": {"reconstruction_algorithm": "TV"}}))
+
+
+def test_apply_inv_tf_cli_init_only(tmp_path):
+    """``apply-inv-tf --init`` lays the output plate out and prints the resource line without a GPU
+    (reference: tests/test_cli/test_reconstruct_cli.py:69-91)."""
+    import yaml
+
+    src = tmp_path / "input.zarr"
+    make_plate(src, positions=(("A", "1", "0"), ("B", "1", "0")), shape=(1, 1, 5, 8, 8), dtype=np.float32,
+               scale=(1, 1, 0.25, 0.1, 0.1))
+    for key in (("A", "1", "0"), ("B", "1", "0")):  # make_plate names channels ch0..: the config asks for "BF"
+        pos = io.open_ome_zarr(src.joinpath(*key))
+        pos.zattrs["omero"]["channels"][0]["label"] = "BF"
+        pos.update_zattrs({})
+    cfg = tmp_path / "reconstruct.yml"
+    cfg.write_text(yaml.dump(RECON_YML))
+    out = tmp_path / "output.zarr"
+    res = CliRunner().invoke(cli, expand_eat_all(["apply-inv-tf", "--init", "-i", str(src / "A/1/0"), str(src / "B/1/0"), "-c", str(cfg),
+                                                  "-o", str(out)]))
+    assert res.exit_code == 0, res.output
+    assert "RESOURCES:" in res.output and "2 positions, 1 output channels" in res.output
+    pos = io.open_ome_zarr(out / "B/1/0")
+    assert pos.channel_names == ["Phase3D"] and pos.data.shape == (1, 1, 5, 8, 8) and pos.data.dtype == np.float32
+    assert pos.scale == [1.0, 1.0, 0.25, 0.1, 0.1]
+    res = CliRunner().invoke(cli, ["apply-inv-tf", "-i", str(src / "A/1/0"), "-c", str(cfg), "-o", str(out)])
+    assert res.exit_code != 0 and "--transfer-function-dirpath / -t is required unless using --init." in res.output
+
+
+@pytest.mark.gpu
+def test_cli_compute_tf_apply_inv_tf_reconstruct(gpu, tmp_path):
+    """compute-tf -> apply-inv-tf --cluster debug, and reconstruct (= both), as the reference's CLI test drives them
+    (tests/test_cli/test_reconstruct_cli.py:94-157), with the values held to the oracle's restatement of waveorder."""
+    import yaml
+
+    src = tmp_path / "input.zarr"
+    shape = (2, 2, 8, 16, 20)
+    data = make_plate(src, positions=(("A", "1", "0"), ("B", "1", "0")), shape=shape, dtype=np.float32, scale=(1, 1, 0.25, 0.1, 0.1))
+    for key in (("A", "1", "0"), ("B", "1", "0")):
+        pos = io.open_ome_zarr(src.joinpath(*key))
+        pos.zattrs["omero"]["channels"][1]["label"] = "BF"
+        pos.update_zattrs({})
+    cfg_d = json.loads(json.dumps(RECON_YML))
+    cfg_d["phase"]["transfer_function"]["z_padding"] = 2
+    cfg = tmp_path / "reconstruct.yml"
+    cfg.write_text(yaml.dump(cfg_d))
+    r = CliRunner()
+    tf = tmp_path / "tf.zarr"
+    res = r.invoke(cli, ["compute-tf", "-i", str(src / "A/1/0"), "-c", str(cfg), "-o", str(tf)])
+    assert res.exit_code == 0, res.output
+    assert "Transfer function computed and saved to" in res.output
+    store = io.open_ome_zarr(tf)
+    assert store.array_keys() == ["imaginary_potential_transfer_function", "real_potential_transfer_function"]
+    H = store["real_potential_transfer_function"][0, 0]
+    assert H.shape == (12, 16, 20) and H.dtype == np.complex64
+    assert store.zattrs["settings"]["phase"]["transfer_function"]["z_padding"] == 2
+    wre, _ = O.wo_phase_transfer_function_3d((8, 16, 20), 0.1, 0.25, 0.45, 2, 1.3, 0.5, 1.2)
+    assert np.abs(H - wre).max() <= 2e-5 * np.abs(wre).max()
+    out = tmp_path / "output.zarr"
+    res = r.invoke(cli, expand_eat_all(["apply-inv-tf", "--cluster", "debug", "-i", str(src / "A/1/0"), str(src / "B/1/0"), "-t", str(tf),
+                                        "-c", str(cfg), "-o", str(out)]))
+    assert res.exit_code == 0, res.output
+    assert res.output.count("Apply-inv-tf complete:") == 2 and "RESOURCES:" in res.output
+    got = io.open_ome_zarr(out / "B/1/0")
+    assert got.channel_names == ["Phase3D"] and got.data.shape == (2, 1, 8, 16, 20)
+    for t in (0, 1):
+        want = O.wo_apply_inverse_transfer_function(data[("B", "1", "0", t, 1)], wre, 2, 1e-3, True)
+        assert np.abs(got.data[t, 0] - want).max() <= 1e-4 * np.abs(want).max()
+    # reconstruct = compute-tf + apply-inv-tf; the transfer function lands next to the output, named after the config
+    out2 = tmp_path / "rec" / "output.zarr"
+    out2.parent.mkdir()
+    res = r.invoke(cli, ["reconstruct", "-i", str(src / "A/1/0"), "-c", str(cfg), "-o", str(out2)])
+    assert res.exit_code == 0, res.output
+    assert (out2.parent / "transfer_function_reconstruct.zarr").exists()
+    assert np.array_equal(io.open_ome_zarr(out2 / "A/1/0").data[1, 0], io.open_ome_zarr(out / "A/1/0").data[1, 0])
+    # a fluorescence configuration through the same commands
+    fcfg = tmp_path / "fluor.yml"
+    fcfg.write_text(yaml.dump({"input_channel_names": ["ch0"], "reconstruction_dimension": 3,
+                               "fluorescence": {"transfer_function": {"yx_pixel_size": 0.1, "z_pixel_size": 0.25},
+                                                "apply_inverse": {"regularization_strength": 1e-2}}}))
+    out3 = tmp_path / "fl" / "output.zarr"
+    out3.parent.mkdir()
+    res = r.invoke(cli, ["reconstruct", "-i", str(src / "A/1/0"), "-c", str(fcfg), "-o", str(out3)])
+    assert res.exit_code == 0, res.output
+    otf = O.wo_fluorescence_transfer_function_3d((8, 16, 20), 0.1, 0.25, 0.507, 0, 1.3, 1.2)
+    want = O.wo_apply_inverse_transfer_function(data[("A", "1", "0", 0, 0)], otf, 0, 1e-2, False)
+    g3 = io.open_ome_zarr(out3 / "A/1/0")
+    assert g3.channel_names == ["ch0_Density3D"] and np.abs(g3.data[0, 0] - want).max() <= 1e-4 * np.abs(want).max()
