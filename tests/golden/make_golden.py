@@ -19,6 +19,7 @@ Fixtures written:
   phase_cross_corr.npz    estimate_stabilization.phase_cross_corr (three normalisations)
   estimate_crop.npz       estimate_crop.estimate_crop_one_position on in-memory arrays (LIR from biahub_amd's restatement)
   legacy_fill.npz         deskew._fill_overhang_with_mean (legacy 6-connected SciPy dilation)
+  deskew_transform_matrix.json  deskew._get_transform_matrix over a grid of (angle, ratio)
   concatenate.json        biahub.concatenate slicing/channel-layout helpers, ConcatenateSettings validation
   helpers.json            settings dumps, fingerprints, estimate_resources, output paths,
                           sbatch parsing, matrix builders
@@ -336,7 +337,22 @@ def concatenate_vectors():
     print("concatenate.json written")
 
 
+def deskew_transform_matrix_vectors():
+    """biahub/deskew.py:180-210 — _get_transform_matrix over a grid of (angle, ratio), incl. the example settings."""
+    import biahub.deskew as D
+
+    cases = [(36.17, 0.371), (30.0, 0.25), (45.0, 1.0), (0.5, 0.05), (22.5, 0.6543), (36.0, 0.375)]
+    out = [{"ls_angle_deg": a, "px_to_scan_ratio": r, "matrix": np.asarray(D._get_transform_matrix(a, r), dtype=np.float64).tolist()}
+           for a, r in cases]
+    (HERE / "deskew_transform_matrix.json").write_text(json.dumps(out, indent=1))
+    print("deskew_transform_matrix.json written")
+
+
 def main():
+    if sys.argv[1:] == ["deskew_transform_matrix"]:
+        load_reference()
+        deskew_transform_matrix_vectors()
+        return 0
     if sys.argv[1:] == ["estimate_crop"]:
         load_reference()
         estimate_crop_vectors()
@@ -561,6 +577,7 @@ def main():
     detect_peaks_vectors()
     pcc_chain_vectors()
     binning_vectors()
+    deskew_transform_matrix_vectors()
     total = sum(p.stat().st_size for p in HERE.glob("*.np*")) + sum(p.stat().st_size for p in HERE.glob("*.json"))
     print(f"golden fixtures written to {HERE} ({total/1e6:.2f} MB)")
     return 0

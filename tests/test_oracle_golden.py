@@ -252,3 +252,28 @@ def test_wave_private_x_pass_model():
             g0, g1 = x.group_of(lam, 0), x.group_of(lam, 1)
             assert all(x.mirror(8 * g0 + n) == 8 * g1 + 7 - n for n in range(8))
         assert (x.group_of(0, 0), x.group_of(0, 1)) == (0, 1)
+
+
+def test_get_transform_matrix_golden():
+    """D2: the deskew pull matrix of the product's host mirror, against the reference's own outputs
+    (biahub/deskew.py:180-210; fixture: tests/golden/make_golden.py deskew_transform_matrix)."""
+    import json
+
+    from biahub_amd.deskew import _get_transform_matrix
+
+    cases = json.load(open(GOLDEN / "deskew_transform_matrix.json"))
+    assert len(cases) >= 6
+    for c in cases:
+        got = _get_transform_matrix(c["ls_angle_deg"], c["px_to_scan_ratio"])
+        assert got.shape == (4, 4) and np.array_equal(got, np.asarray(c["matrix"])), c
+
+
+def test_product_average_n_slices_golden():
+    """D7: the product's `_average_n_slices` host helper (not only the oracle's) on the reference's known answers
+    (biahub/deskew.py:43-68, tests/test_cli/test_deskew_cli.py:11-30)."""
+    from biahub_amd.deskew import _average_n_slices
+
+    z = np.load(GOLDEN / "average_n_slices.npz")
+    for w in (1, 2, 3):
+        got = _average_n_slices(z["data"], w)
+        assert got.shape == z[f"w{w}"].shape and np.array_equal(got, z[f"w{w}"]), w

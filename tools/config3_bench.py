@@ -13,7 +13,6 @@ from biahub_amd.registration import metric as R
 from biahub_amd.registration.ants import estimate, postprocess_transform
 
 dev = torch.device("cuda", 0)
-shape = tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 1024, 1024)
 th = np.deg2rad(2.0)
 M = np.array([[1.02, 0, 0, 3.5], [0, 1.02 * np.cos(th), -1.02 * np.sin(th), -12.25],
               [0, 1.02 * np.sin(th), 1.02 * np.cos(th), 20.75], [0, 0, 0, 1.0]])
@@ -40,43 +39,53 @@ def beads_volume(shape, n_blobs, seed):
     return vol.round_().clamp_(0, 65535)
 
 
-arm_a = beads_volume(shape, max(64, int(np.prod(shape)) // 65536), 0xB1A0)   # 4096 blobs at (256,1024,1024)
-arm_b = affine_device(arm_a, M, shape)
-arm_b = torch.where(arm_b == 0, torch.full_like(arm_b, 110.0), arm_b)
-# estimate_czyx's flow (registration/ants.py:281-366) on device tensors: rough initial guess -> pre-warp -> estimate
-th0 = np.deg2rad(1.5)
-centre = np.append((np.array(shape) - 1) / 2, 1)
-init = np.eye(4)
-init[1:3, 1:3] = [[np.cos(th0), -np.sin(th0)], [np.sin(th0), np.cos(th0)]]        # 1.5 deg, scale 1.0 (truth: 2 deg, 1.02)
-init[:3, 3] = (M @ centre)[:3] - init[:3, :3] @ centre[:3] + np.array([1.0, 3.0, -2.5])  # a few voxels off at the centre
-rng0 = (float(arm_b.min()), float(arm_b.max()), float(arm_a.min()), float(arm_a.max()))
-print("arm A min/max/frac>150:", rng0[2], rng0[3], float((arm_a > 150).float().mean()), " arm B min/max:", rng0[:2])
-print("MI at truth / at the initial guess / at identity (full res, stride 5):",
-      [round(R.mattes_mi(arm_b, arm_a, P[:3], rng0, stride=5)[0], 5) for P in (M, init, np.eye(4))])
-print(f"initial guess: centre error {np.linalg.norm((init @ centre - M @ centre)[:3]):.2f} voxels")
-torch.cuda.synchronize()
-for _ in range(2):
-    t0 = time.perf_counter()
-    pre = affine_device(arm_a, init, shape)
-    zs, ys, xs = find_lir((pre != 0).cpu().numpy().astype(np.uint8))          # crop=True of preprocess_czyx
-    t1 = time.perf_counter()
-    fwd, inv = estimate(ref=arm_b[zs, ys, xs].contiguous(), mov=pre[zs, ys, xs].contiguous(), verbose="-v" in sys.argv)
+def run(shape=(256, 1024, 1024), verbose=False, echo=print):
+    """Returns {"dA": max |A - A_true|, "centre_error": voxels, "estimate_s", "register_ms", "mi_ms"}; `echo` gets the log."""
+    print = echo  # noqa: A001 - the body below logs through `echo`
+    arm_a = beads_volume(shape, max(64, int(np.prod(shape)) // 65536), 0xB1A0)   # 4096 blobs at (256,1024,1024)
+    arm_b = affine_device(arm_a, M, shape)
+    arm_b = torch.where(arm_b == 0, torch.full_like(arm_b, 110.0), arm_b)
+    # estimate_czyx's flow (registration/ants.py:281-366) on device tensors: rough initial guess -> pre-warp -> estimate
+    th0 = np.deg2rad(1.5)
+    centre = np.append((np.array(shape) - 1) / 2, 1)
+    init = np.eye(4)
+    init[1:3, 1:3] = [[np.cos(th0), -np.sin(th0)], [np.sin(th0), np.cos(th0)]]        # 1.5 deg, scale 1.0 (truth: 2 deg, 1.02)
+    init[:3, 3] = (M @ centre)[:3] - init[:3, :3] @ centre[:3] + np.array([1.0, 3.0, -2.5])  # a few voxels off at the centre
+    rng0 = (float(arm_b.min()), float(arm_b.max()), float(arm_a.min()), float(arm_a.max()))
+    print("arm A min/max/frac>150:", rng0[2], rng0[3], float((arm_a > 150).float().mean()), " arm B min/max:", rng0[:2])
+    print("MI at truth / at the initial guess / at identity (full res, stride 5):",
+          [round(R.mattes_mi(arm_b, arm_a, P[:3], rng0, stride=5)[0], 5) for P in (M, init, np.eye(4))])
+    print(f"initial guess: centre error {np.linalg.norm((init @ centre - M @ centre)[:3]):.2f} voxels")
     torch.cuda.synchronize()
-    dt, dt_est = time.perf_counter() - t0, time.perf_counter() - t1
-off = np.array([zs.start, ys.start, xs.start], dtype=np.float64)
-fwd = postprocess_transform(type(fwd)(init), fwd, off)
-print(f"crop {zs}, {ys}, {xs}; estimate alone {dt_est:.3f} s")
-T = fwd.matrix
-print(f"estimate {shape}: {dt:.3f} s   |dA|max {np.abs(T[:3,:3]-M[:3,:3]).max():.2e}   "
-      f"centre error {np.linalg.norm((T @ centre - M @ centre)[:3]):.3f} voxels")
-# one full-resolution metric evaluation (the per-iteration unit of the last level)
-rng = (float(arm_b.min()), float(arm_b.max()), float(arm_a.min()), float(arm_a.max()))
-for _ in range(3):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    v, g, n = R.mattes_mi(arm_b, arm_a, T[:3], rng, stride=5)
-    dt = time.perf_counter() - t0
-V = np.prod(shape)
-print(f"mattes_mi full res: {dt*1e3:.2f} ms for {n} samples (MI {v:.4f})")
-t0 = time.perf_counter()
-out = affine_device(arm_a, T, shape); torch.cuda.synchronize()
-print(f"register warp: {(time.perf_counter()-t0)*1e3:.2f} ms")
+    for _ in range(2):
+        t0 = time.perf_counter()
+        pre = affine_device(arm_a, init, shape)
+        zs, ys, xs = find_lir((pre != 0).cpu().numpy().astype(np.uint8))          # crop=True of preprocess_czyx
+        t1 = time.perf_counter()
+        fwd, inv = estimate(ref=arm_b[zs, ys, xs].contiguous(), mov=pre[zs, ys, xs].contiguous(), verbose=verbose)
+        torch.cuda.synchronize()
+        dt, dt_est = time.perf_counter() - t0, time.perf_counter() - t1
+    off = np.array([zs.start, ys.start, xs.start], dtype=np.float64)
+    fwd = postprocess_transform(type(fwd)(init), fwd, off)
+    print(f"crop {zs}, {ys}, {xs}; estimate alone {dt_est:.3f} s")
+    T = fwd.matrix
+    print(f"estimate {shape}: {dt:.3f} s   |dA|max {np.abs(T[:3,:3]-M[:3,:3]).max():.2e}   "
+          f"centre error {np.linalg.norm((T @ centre - M @ centre)[:3]):.3f} voxels")
+    # one full-resolution metric evaluation (the per-iteration unit of the last level)
+    rng = (float(arm_b.min()), float(arm_b.max()), float(arm_a.min()), float(arm_a.max()))
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        v, g, n = R.mattes_mi(arm_b, arm_a, T[:3], rng, stride=5)
+        dt = time.perf_counter() - t0
+    V = np.prod(shape)
+    print(f"mattes_mi full res: {dt*1e3:.2f} ms for {n} samples (MI {v:.4f})")
+    t0 = time.perf_counter()
+    out = affine_device(arm_a, T, shape); torch.cuda.synchronize()
+    print(f"register warp: {(time.perf_counter()-t0)*1e3:.2f} ms")
+
+    return {"dA": float(np.abs(T[:3, :3] - M[:3, :3]).max()), "centre_error": float(np.linalg.norm((T @ centre - M @ centre)[:3])),
+            "estimate_s": dt_est, "mi_ms": dt * 1e3}
+
+
+if __name__ == "__main__":
+    run(tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 1024, 1024), "-v" in sys.argv)
