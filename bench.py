@@ -64,38 +64,90 @@ def synthetic_position(shape, seed, device):
 
 
 def pmc_traffic(key, shape):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json: separate
+    """HBM bytes per launch from the newest committed PMC passes (profiles/rNN_pmc_hbm_traffic.json: separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command, fetch doubled for gfx950 as
-    MI355X_MICROARCH.md prescribes).  Only valid for the shape it was collected on."""
-    f = ROOT / "profiles" / "r01_pmc_hbm_traffic.json"
-    if not f.exists():
-        return None
-    rec = json.load(open(f))
-    if list(shape) != rec.get("shape"):
-        return None
-    return rec.get(key)
+    MI355X_MICROARCH.md prescribes).  STATIC: collected once per round on the kernels of that round, not during this run
+    (counters cannot be read from inside the process); only valid for the shape it was collected on.  -> (bytes, source)"""
+    files = sorted((ROOT / "profiles").glob("r*_pmc_hbm_traffic.json"))
+    for f in reversed(files):
+        rec = json.load(open(f))
+        if list(shape) == rec.get("shape") and rec.get(key):
+            return rec.get(key), f"static from profiles/{f.name}"
+    return None, None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(iterations):
-    """The oracle (CPU restatement) timed on a bounded sample of the same workload, rank 0 only."""
+    """The oracle (CPU restatement of the path) timed on bounded samples of the same workload, rank 0 only: the two sizes
+    SURVEY.md 8(d) names, (128, 512, 512) and (256, 1024, 1024) — about half a minute of host work together."""
+    import scipy.fft
+
     from oracle import oracle_np as O  # checker / baseline only — never the thing measured as `value`
 
-    shape = (192, 768, 768)
-    vol = O.synthetic_volume(shape, seed=7, n_blobs=32)
-    psf = O.gaussian_psf(PSF_SHAPE, PSF_SIGMA)
-    t0 = time.perf_counter()
-    rl = O.richardson_lucy_zyx(vol, psf, iterations, 1e-6)
-    O.fast_deskew_zyx(rl, DESKEW["ls_angle_deg"], DESKEW["px_to_scan_ratio"], True, DESKEW["average_n_slices"],
-                      DESKEW["overhang_fill"])
-    dt = time.perf_counter() - t0
+    samples = []
+    for shape in ((128, 512, 512), (256, 1024, 1024)):
+        vol = O.synthetic_volume(shape, seed=7, n_blobs=32)
+        psf = O.gaussian_psf(PSF_SHAPE, PSF_SIGMA)
+        t0 = time.perf_counter()
+        rl = O.richardson_lucy_zyx(vol, psf, iterations, 1e-6)
+        t1 = time.perf_counter()
+        O.fast_deskew_zyx(rl, DESKEW["ls_angle_deg"], DESKEW["px_to_scan_ratio"], True, DESKEW["average_n_slices"],
+                          DESKEW["overhang_fill"])
+        t2 = time.perf_counter()
+        samples.append({"shape": list(shape), "seconds": t2 - t0, "rl_seconds": t1 - t0, "deskew_seconds": t2 - t1,
+                        "voxels_per_s": float(np.prod(shape) / (t2 - t0))})
+        del vol, rl
+    big = samples[-1]
     return {
-        "value": float(np.prod(shape) / dt),
+        "value": big["voxels_per_s"],
         "unit": "voxels/s",
         "cores": os.cpu_count(),
+        "threads": {"scipy_fft_workers": os.cpu_count(), "torch": torch.get_num_threads()},
+        "cpu_model": cpu_model(),
         "kind": "port",
-        "sample": f"oracle RL({iterations} it, scipy.fft workers=all) + deskew(fill mean) on one {shape} float32 "
-                  f"volume, {dt:.1f} s",
+        "sample": f"oracle RL({iterations} it, scipy.fft workers=all cores) + deskew(fill mean) on one float32 volume of "
+                  f"{tuple(samples[0]['shape'])} ({samples[0]['seconds']:.1f} s) and of {tuple(big['shape'])} "
+                  f"({big['seconds']:.1f} s); value = the larger sample",
+        "samples": samples,
     }
+
+
+def end_to_end(vol_host_u16, psf, iterations, dev):
+    """What the reference's operator boundary costs beside the resident figure (biahub/deskew.py:578-579: the worker uploads
+    the volume and takes the result back): uint16 camera stack in pinned host memory -> H2D -> R-L + deskew -> float32
+    result D2H into a pinned block, through the adapters' own transfer helpers.  PCIe-bound, never `value`."""
+    from biahub_amd.device import to_host
+
+    def once():
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        d = vol_host_u16.to(dev, non_blocking=False)           # 2 B/voxel across PCIe
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        out = fast_deskew_zyx(richardson_lucy(d, psf, iterations, 1e-6), **DESKEW)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        host = to_host(out)                                    # 4 B/voxel of the deskewed volume, pinned destination
+        t3 = time.perf_counter()
+        nbytes_out = host.nbytes
+        del out, host, d
+        return t1 - t0, t2 - t1, t3 - t2, nbytes_out
+
+    once()  # pinned blocks and allocator warm
+    h2d, comp, d2h, nb_out = once()
+    V = vol_host_u16.numel()
+    return {"voxels_per_s": V / (h2d + comp + d2h), "ms": (h2d + comp + d2h) * 1e3, "h2d_ms": h2d * 1e3, "compute_ms": comp * 1e3,
+            "d2h_ms": d2h * 1e3, "h2d_GBps": V * 2 / h2d / 1e9, "d2h_GBps": nb_out / d2h / 1e9,
+            "note": "uint16 in (pinned) -> float32 deskewed out (pinned); serial, no overlap between positions"}
 
 
 def main():
@@ -106,6 +158,7 @@ def main():
     ap.add_argument("--shape", type=int, nargs=3, default=[512, 2048, 2048], metavar=("Z", "Y", "X"))
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
 
     rank, local_rank, world = parallel.world_info()
@@ -125,11 +178,15 @@ def main():
                                            DESKEW["average_n_slices"])
     V_out = int(np.prod(out_shape))
     psf = gaussian_psf(PSF_SHAPE, PSF_SIGMA, dev)
-    vol = synthetic_position(shape, 0xB1A0 + rank, dev)  # position index = rank (weak scaling)
+    # two distinct synthetic positions per rank, alternated over the steps (position index = rank: weak scaling)
+    vols = [synthetic_position(shape, 0xB1A0 + rank + 1000 * k, dev) for k in range(2)]
     ctx = get_context(dev)
     ctx.set_timing(True)
+    nstep = [0]
 
     def step():
+        vol = vols[nstep[0] % len(vols)]
+        nstep[0] += 1
         rl = richardson_lucy(vol, psf, args.iterations, 1e-6)
         return fast_deskew_zyx(rl, **DESKEW)
 
@@ -161,7 +218,10 @@ def main():
         deskew_s = float(np.mean(dk_ms)) / 1e3
         fill_s = float(np.mean(fill_ms)) / 1e3
         rl_bytes = 112.0 * V            # 4 real 3-D FFTs (3-pass model) + fused pointwise
+        rl_bytes_1pass = 48.0 * V       # SURVEY.md §8d lower bound: every FFT one read + one write
         dk_bytes = 4.0 * (V + V_out)    # read every input voxel once, write every output voxel once
+        rl_moved, rl_src = pmc_traffic("rl_iteration", shape)
+        dk_moved, dk_src = pmc_traffic("deskew_kernel", shape)
         result = {
             "metric": "voxels/s for deskew+10-iter R-L deconv, 2048^2x512 f32",
             "value": world * args.steps * V / dt,
@@ -177,22 +237,30 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"1 position/GPU: R-L {args.iterations} it (PSF {PSF_SHAPE}) then deskew "
-                            f"{shape}->{tuple(out_shape)} (36.17 deg, 0.371, N=3, fill mean), input resident in HBM",
+                            f"{shape}->{tuple(out_shape)} (36.17 deg, 0.371, N=3, fill mean), input resident in HBM; two "
+                            "distinct positions alternate over the steps; the OTF is cached across positions of one PSF "
+                            "(built once, in warm-up: a plate shares its PSF), so it is outside the timed region",
                 "raw_shape_zyx": list(shape),
                 "deskewed_shape_zyx": list(out_shape),
                 "positions_per_step": world,
             },
             "roofline": {
                 "kernel": "one Richardson-Lucy iteration = 8 in-place passes of csrc/fftconv.hip: 2 x (col_pass Y fwd, "
-                          "col_pass Z fwd*OTF*inv, col_pass Y inv, x_inv_kernel<FUSE>: inverse X + RL epilogue + next forward X)",
+                          "col_pass Z fwd*OTF*inv, col_pass Y inv, xw_kernel<FUSED_*>: inverse X + RL epilogue + next forward X "
+                          "in registers, csrc/fftconv_xw.inc)",
                 "bound": "hbm",
                 "achieved": rl_bytes / rl_iter_s / 1e9,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": rl_bytes / rl_iter_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("rl_iteration", shape),
+                "traffic": rl_moved,
+                "traffic_source": rl_src,
                 "algorithmic_bytes": rl_bytes,
                 "ms": rl_iter_s * 1e3,
+                # the same time priced two more ways: the 1-pass-per-FFT lower bound of SURVEY 8(d), and the bytes the
+                # engine physically moved (PMC): frac is the contract's model, frac_moved the HBM utilisation
+                "frac_1pass": rl_bytes_1pass / rl_iter_s / 1e9 / HBM_PEAK_GBS,
+                "frac_moved": (rl_moved / rl_iter_s / 1e9 / HBM_PEAK_GBS) if rl_moved else None,
             },
             "roofline_deskew": {
                 "kernel": "deskew_kernel (fused shear-interpolate + N-mean)",
@@ -201,13 +269,21 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": dk_bytes / deskew_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("deskew_kernel", shape),
+                "traffic": dk_moved,
+                "traffic_source": dk_src,
+                "frac_moved": (dk_moved / deskew_s / 1e9 / HBM_PEAK_GBS) if dk_moved else None,
                 "algorithmic_bytes": dk_bytes,
                 "ms": deskew_s * 1e3,
                 "fill_passes_ms": fill_s * 1e3,
             },
             "workspace_gb": ctx.workspace_bytes() / 1e9,
         }
+        if not args.no_end_to_end and world == 1:
+            del vols[1:]
+            host = torch.empty(shape, dtype=torch.uint16, pin_memory=True)
+            host.copy_(vols[0].to(torch.uint16))
+            result["end_to_end"] = end_to_end(host, psf, args.iterations, dev)
+            del host
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             result["cpu_baseline"] = cpu_baseline(args.iterations)
         print(json.dumps(result), flush=True)

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch from two rocprofv3 counter passes of the bench command (tools/pmc_bench.sh NAME "FETCH_SIZE" /
+"WRITE_SIZE"): `tools/pmc_traffic.py gpurun_out/pmc_FETCH gpurun_out/pmc_WRITE profiles/rNN` writes
+profiles/rNN_pmc_hbm_traffic.txt (per kernel) and profiles/rNN_pmc_hbm_traffic.json (what bench.py reads).
+FETCH_SIZE / WRITE_SIZE count KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of wide coalesced reads at 64 B
+(MI355X_MICROARCH.md, HBM): the read side is doubled."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def load(d, name):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == name:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+prefix = sys.argv[3]
+shape = [int(v) for v in sys.argv[4:7]] if len(sys.argv) >= 7 else [512, 2048, 2048]
+rows = {}
+lines = [f"{'kernel':70s} {'calls':>5s} {'fetch GB':>9s} {'fetch x2':>9s} {'write GB':>9s} {'moved GB':>9s}"]
+for k in sorted(fetch, key=lambda k: -sum(fetch[k])):
+    if "bh::" not in k:
+        continue
+    fv = sum(fetch[k]) / len(fetch[k]) * 1024 / 1e9
+    wv = sum(write.get(k, [0])) / max(1, len(write.get(k, [0]))) * 1024 / 1e9
+    rows[k] = (len(fetch[k]), 2 * fv, wv)
+    lines.append(f"{k[:70]:70s} {len(fetch[k]):5d} {fv:9.3f} {2 * fv:9.3f} {wv:9.3f} {2 * fv + wv:9.3f}")
+
+
+def moved(sub, count=1):
+    hit = [v for k, v in rows.items() if sub in k]
+    assert len(hit) == 1, (sub, [k for k in rows if sub in k])
+    return count * (hit[0][1] + hit[0][2]) * 1e9
+
+
+# one Richardson-Lucy iteration: 2 x (Y fwd, Z x OTF, Y inv) + fused ratio X + fused update X
+it = (moved("col_pass_kernel<0,", 2) + moved("col_pass_kernel<1,", 2) + moved("col_pass_kernel<3,") + moved("col_pass_kernel<4,") +
+      moved("xw_kernel<10, 4>") + moved("xw_kernel<10, 5>"))
+rec = {"shape": shape, "unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KiB counters x1024)", "rl_iteration": it,
+       "deskew_kernel": moved("deskew_kernel<"),
+       "per_kernel_gb": {k[:60]: round(v[1] + v[2], 3) for k, v in rows.items()},
+       "source": f"{prefix}_pmc_hbm_traffic.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of "
+                 "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end`, summed over the 8 passes of one iteration"}
+open(prefix + "_pmc_hbm_traffic.txt", "w").write("\n".join(lines) + "\n")
+json.dump(rec, open(prefix + "_pmc_hbm_traffic.json", "w"), indent=1)
+print("\n".join(lines[:14]))
+print("rl_iteration GB:", it / 1e9, " deskew GB:", rec["deskew_kernel"] / 1e9)
