@@ -121,6 +121,61 @@ def cpu_baseline(iterations):
     }
 
 
+def ops_suite(vol, psf, dev, ctx):
+    """The other operators of the path at the bench shape, device-resident, each timed by the library's own HIP events on its
+    stream (third run of three): ms, algorithmic bytes and that rate as a fraction of 8 TB/s.  Reported
+    beside the headline, never part of `value`."""
+    from biahub_amd.apply_inverse_transfer_function import apply_inverse_transfer_function_zyx
+    from biahub_amd.deconvolve import tikhonov_zyx, transfer_function_device
+    from biahub_amd.estimate_stabilization import phase_cross_corr_device
+    from biahub_amd.flat_field import flat_field_device
+    from biahub_amd.register import affine_device
+
+    shape = tuple(vol.shape)
+    V = float(np.prod(shape))
+    out = {}
+
+    def rec(name, fn, slot, nbytes, note=None):
+        ms = 0.0
+        for _ in range(3):
+            r = fn()
+            ms = ctx.elapsed_ms(slot)
+            del r
+        out[name] = {"ms": ms, "algorithmic_bytes": nbytes, "GBps": nbytes / ms / 1e6, "frac": nbytes / ms / 1e6 / HBM_PEAK_GBS}
+        if note:
+            out[name]["note"] = note
+
+    th = np.deg2rad(2.0)
+    M = np.array([[1.02, 0, 0, 3.5], [0, 1.02 * np.cos(th), -1.02 * np.sin(th), -12.25],
+                  [0, 1.02 * np.sin(th), 1.02 * np.cos(th), 20.75], [0, 0, 0, 1.0]])  # SURVEY 8(d): 2 deg, 1.02x, fractional shift
+    rec("affine_linear_f32", lambda: affine_device(vol, M, shape, "linear"), _lib.T_AFFINE, 8 * V, "4 (V_in + V_out)")
+    rec("affine_nearest_f32", lambda: affine_device(vol, M, shape, "nearestneighbor"), _lib.T_AFFINE, 8 * V)
+    v16 = vol.to(torch.uint16)
+    rec("affine_linear_u16_in", lambda: affine_device(v16, M, shape, "linear"), _lib.T_AFFINE, 6 * V, "2 V_in + 4 V_out")
+    rec("flat_field_u16", lambda: flat_field_device(v16), _lib.T_FLATFIELD, 8 * V, "two 2-byte reads (median, apply) + one f32 write")
+    del v16
+    tf = transfer_function_device(psf, shape, dev)
+    rec("tikhonov", lambda: tikhonov_zyx(vol, tf, 1e-3), _lib.T_TIKHONOV, 50 * V, "50 V: 2 FFTs (3-pass model) + real filter")
+    rec("apply_inv_tf_f32", lambda: apply_inverse_transfer_function_zyx(vol, tf, 0, 1e-3, True, "f32"), _lib.T_TIKHONOV, 56 * V,
+        "config 5 step: 2 FFTs (48 V) + complex filter (8 V), incl. mean normalisation and filter staging")
+    rec("apply_inv_tf_bf16", lambda: apply_inverse_transfer_function_zyx(vol, tf, 0, 1e-3, True, "bf16"), _lib.T_TIKHONOV, 52 * V,
+        "filter kept as bfloat16 pairs")
+    del tf
+    mov = torch.roll(vol, (1, -3, 17), (0, 1, 2))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        sh, _ = phase_cross_corr_device(vol, mov, "magnitude", want_corr=False)
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    assert tuple(float(v) for v in sh) == (-1.0, 3.0, -17.0), sh
+    out["phase_cross_corr"] = {"ms": ms, "algorithmic_bytes": 80 * V, "GBps": 80 * V / ms / 1e6, "frac": 80 * V / ms / 1e6 / HBM_PEAK_GBS,
+                               "note": "wall clock incl. the argmax read-back; 3 FFTs (72 V) + product (8 V)"}
+    del mov
+    ctx.release_workspace()
+    return out
+
+
 def end_to_end(vol_host_u16, psf, iterations, dev):
     """What the reference's operator boundary costs beside the resident figure (biahub/deskew.py:578-579: the worker uploads
     the volume and takes the result back): uint16 camera stack in pinned host memory -> H2D -> R-L + deskew -> float32
@@ -159,6 +214,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-ops", action="store_true")
     args = ap.parse_args()
 
     rank, local_rank, world = parallel.world_info()
@@ -278,6 +334,10 @@ def main():
             },
             "workspace_gb": ctx.workspace_bytes() / 1e9,
         }
+        if not args.no_ops and world == 1:
+            del vols[1:]
+            ctx.release_workspace()
+            result["ops"] = ops_suite(vols[0], psf, dev, ctx)
         if not args.no_end_to_end and world == 1:
             del vols[1:]
             host = torch.empty(shape, dtype=torch.uint16, pin_memory=True)

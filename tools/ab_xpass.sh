@@ -4,7 +4,7 @@ python -m pytest tests/test_io_cli.py -x -q -m gpu -k "two_ranks or end_to_end o
 tail -3 gpurun_out/ab/cli_tests.log
 for v in default xnt512 xnt512r16; do
   if [ $v = default ]; then unset BHCORE_LIB; else export BHCORE_LIB=$PWD/biahub_amd/build/variants/libbhcore_$v.so; fi
-  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > gpurun_out/ab/$v.json 2> gpurun_out/ab/$v.err || (tail -5 gpurun_out/ab/$v.err; exit 1)
+  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-ops > gpurun_out/ab/$v.json 2> gpurun_out/ab/$v.err || (tail -5 gpurun_out/ab/$v.err; exit 1)
   python - <<PY
 import json
 r=json.load(open("gpurun_out/ab/$v.json"))

@@ -7,7 +7,7 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/pmc_$name
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -- python3 $root/bench.py --no-cpu-baseline --no-end-to-end "$@" > $out/bench.log 2>&1 || (tail -20 $out/bench.log; exit 1)
+rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -- python3 $root/bench.py --no-cpu-baseline --no-end-to-end --no-ops "$@" > $out/bench.log 2>&1 || (tail -20 $out/bench.log; exit 1)
 cd $root
 python3 - "$out" <<'PY' | tee $out/summary.txt
 import csv, glob, sys, collections
