@@ -27,7 +27,7 @@ def needs_build() -> bool:
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.hpp", CSRC / "fftconv_xpass.inc", CSRC / "fftconv_xw.inc", INCLUDE / "bhcore.h"]
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.hpp", CSRC / "fftconv_xpass.inc", CSRC / "fftconv_xw.inc", CSRC / "fftconv_colw.inc", INCLUDE / "bhcore.h"]
     return any(d.stat().st_mtime > t for d in deps)
 
 
@@ -43,7 +43,8 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         obj = objdir / (src + ".o")
         srcp = CSRC / src
         hdr_t = max((CSRC / "common.hpp").stat().st_mtime, (INCLUDE / "bhcore.h").stat().st_mtime,
-                    max((CSRC / "fftconv_xpass.inc").stat().st_mtime, (CSRC / "fftconv_xw.inc").stat().st_mtime)
+                    max((CSRC / "fftconv_xpass.inc").stat().st_mtime, (CSRC / "fftconv_xw.inc").stat().st_mtime,
+                        (CSRC / "fftconv_colw.inc").stat().st_mtime)
                     if src == "fftconv.hip" else 0.0)
         if not force and obj.exists() and obj.stat().st_mtime > max(srcp.stat().st_mtime, hdr_t):
             return obj

@@ -770,6 +770,8 @@ struct ConvPlan {
     bool xw = false;
     cf* xw_tab = nullptr;
     int* xw_col = nullptr;
+    // register-stage column passes (fftconv_colw.inc) for columns of 256 / 512 / 1024 points: their twiddle tables
+    cf *colw_y = nullptr, *colw_z = nullptr;
 };
 
 // The X passes exist for two tile heights: 16 rows (M = X/2 up to 1024) and 8 rows (M up to 1536: a 3072-voxel row, for which
@@ -790,6 +792,7 @@ namespace xr8 {
 }  // namespace xr8
 
 #include "fftconv_xw.inc"
+#include "fftconv_colw.inc"
 
 // ================================================================================================
 // host side
@@ -913,6 +916,15 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     };
     pl.Wy = tile_w(Y / 2);
     pl.Wz = tile_w(Z);
+    auto colw_tables = [&](int64_t n, cf** dptr) -> int {
+        if (n == 256) colw::make_tables<8>(h);
+        else if (n == 512) colw::make_tables<9>(h);
+        else if (n == 1024) colw::make_tables<10>(h);
+        else return BH_OK;
+        return upload(h, dptr);
+    };
+    BH_TRY(colw_tables(Y / 2, &pl.colw_y));
+    BH_TRY(colw_tables(Z, &pl.colw_z));
     if (xw_on) {
         std::vector<int> col;
         if (X == 2048) xw::make_tables<10>(h, col); else xw::make_tables<9>(h, col);
@@ -930,6 +942,31 @@ int fftconv_plan_tag(const ConvPlan& pl) { return pl.xw ? 1 : 0; }
 
 size_t fftconv_spectrum_elems(const ConvPlan& pl) {
     return (size_t)pl.d.Z * pl.d.Y * pl.d.XP + 64;  // slack: a ragged last column tile reads past its row
+}
+
+template <int LOGN>
+static int launch_colw(bh_ctx* ctx, ColParams p, int mode) {
+    using G = colw::Geo<LOGN>;
+    p.W = G::W;
+    p.ncoltiles = (int)ceil_div(p.XP, p.W);
+    const long ntiles = (long)p.nouter * p.ncoltiles;
+    const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
+    auto run = [&](auto kern) -> int {
+        BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)G::LDS_BYTES));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(colw::NT), G::LDS_BYTES, ctx->stream, p);
+        BH_CHECK_HIP(hipGetLastError());
+        return BH_OK;
+    };
+    switch (mode) {
+        case COL_FWD: return run(colw::colw_kernel<LOGN, COL_FWD>);
+        case COL_INV: return run(colw::colw_kernel<LOGN, COL_INV>);
+        case COL_FWD_SCALE: return run(colw::colw_kernel<LOGN, COL_FWD_SCALE>);
+        case COL_CONV: return run(colw::colw_kernel<LOGN, COL_CONV>);
+        case COL_FILTER: return run(colw::colw_kernel<LOGN, COL_FILTER>);
+        case COL_CONV16: return run(colw::colw_kernel<LOGN, COL_CONV16>);
+        default: return run(colw::colw_kernel<LOGN, COL_CORR>);
+    }
 }
 
 static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf* S, const cf* otf, float scale) {
@@ -964,6 +1001,19 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
         p.sub_stride = 0;
         p.nsub = 1;
         p.nouter = pl.d.Y;
+    }
+    // columns of 256 / 512 / 1024 points: the register-stage kernels (BH_FC_COLW=0 keeps the LDS-stepped ones: A/B switch)
+    const cf* colw_tab = zaxis ? pl.colw_z : pl.colw_y;
+    // BH_FC_COLW: 0 never, 1 always, 2 the Y passes only, 3 the Z passes only; default (4): the Y passes, and the Z pass for
+    // columns of 256 points (one exchange per transform).  Measured (tools/ab_env.sh): the Z pass of 512-point columns pays
+    // more for its 8 barriers per tile at 8 wavefronts than it saves in LDS round trips (6.97 against 6.52 ms at config 2;
+    // 5.66 ms with the barriers compiled out), the others win.
+    const int colw_mode = getenv("BH_FC_COLW") ? atoi(getenv("BH_FC_COLW")) : 4;
+    const bool colw_axis = colw_mode == 1 || (colw_mode == 2 && !zaxis) || (colw_mode == 3 && zaxis) ||
+                           (colw_mode == 4 && (!zaxis || p.N == 256));
+    if (colw_tab && (long)p.N * p.row_stride < (1l << 31) && colw_axis) {
+        p.tw = colw_tab;
+        return p.N == 1024 ? launch_colw<10>(ctx, p, mode) : (p.N == 512 ? launch_colw<9>(ctx, p, mode) : launch_colw<8>(ctx, p, mode));
     }
     p.logW = ilog2(p.W);
     p.midfuse = getenv("BH_FC_NOZMID") == nullptr;

@@ -1267,3 +1267,55 @@ def test_config4_position_chain_full_size(gpu):
                 got = stab[z0:z0 + n, y0:y0 + n, x0:x0 + n].cpu().numpy()
                 assert rel_err(got, want) <= 1e-5
             del raw, dsk, rl, stab, rawf
+
+
+# ----------------------------------------------------------------------------- register-stage column passes (csrc/fftconv_colw.inc)
+@pytest.mark.parametrize("shape,pshape", [
+    ((256, 64, 128), (9, 5, 5)),      # Z = 256: radix 16 x 16, one exchange
+    ((512, 32, 64), (7, 3, 5)),       # Z = 512: 16 x 16 x 2
+    ((1024, 32, 64), (11, 3, 3)),     # Z = 1024: 16 x 16 x 4
+    ((4, 512, 64), (3, 9, 5)),        # Y/2 = 256
+    ((8, 1024, 128), (3, 7, 5)),      # Y/2 = 512
+    ((4, 2048, 64), (3, 11, 3)),      # Y/2 = 1024
+    ((256, 512, 1024), (5, 5, 5)),    # both column kernels + the wave-private X passes; a ragged last column tile (528 = 8 x 64 + 16)
+])
+def test_register_stage_column_passes(gpu, shape, pshape, monkeypatch):
+    """Columns of 256 / 512 / 1024 points run the register-stage column kernels (three register stages, two LDS exchanges;
+    the Z pass multiplies by the OTF between its forward and inverse halves without touching LDS).  Richardson-Lucy
+    (convolution, correlation, plain forward / inverse Y passes), Tikhonov (real filter), the inverse filter with bfloat16
+    storage and phase cross-correlation agree with the oracle and with the LDS-stepped kernels (BH_FC_COLW=0)."""
+    from biahub_amd.apply_inverse_transfer_function import apply_inverse_transfer_function_zyx
+    from biahub_amd.deconvolve import compute_tranfser_function, deconvolve, richardson_lucy
+    from biahub_amd.estimate_stabilization import phase_cross_corr
+
+    big = int(np.prod(shape)) > 1 << 24
+    vol = O.synthetic_volume(shape, seed=33, n_blobs=16)
+    vol[0, :, :] += 300.0
+    vol[:, -1, :] += 200.0
+    psf = O.gaussian_psf(pshape, tuple(max(p / 4.0, 0.8) for p in pshape))
+    psf[0, 0, 0] += 0.02
+    v, pt = torch.from_numpy(vol).to(gpu), torch.from_numpy(psf).to(gpu)
+    its = 2 if big else 3
+    monkeypatch.setenv("BH_FC_COLW", "1")   # both axes on the register-stage kernels (the default keeps Z on the LDS-stepped ones)
+    new = richardson_lucy(v, pt, its, 1e-6).cpu().numpy()
+    monkeypatch.setenv("BH_FC_COLW", "0")
+    old = richardson_lucy(v, pt, its, 1e-6).cpu().numpy()
+    monkeypatch.setenv("BH_FC_COLW", "1")
+    assert rel_err(new, old) <= 2e-5, rel_err(new, old)
+    if not big:
+        want = O.richardson_lucy_zyx(vol, psf, iterations=its, eps=1e-6)
+        assert rel_err(new, want) <= FFT_TOL, rel_err(new, want)
+    tf = compute_tranfser_function(psf, shape)
+    got = deconvolve(vol[None], transfer_function=tf, regularization_strength=1e-2)[0]
+    monkeypatch.setenv("BH_FC_COLW", "0")
+    got_old = deconvolve(vol[None], transfer_function=tf, regularization_strength=1e-2)[0]
+    g16_old = apply_inverse_transfer_function_zyx(v, tf, 0, 1e-2, False, "bf16").cpu().numpy()
+    monkeypatch.setenv("BH_FC_COLW", "1")
+    assert rel_err(got, got_old) <= 2e-5
+    g16 = apply_inverse_transfer_function_zyx(v, tf, 0, 1e-2, False, "bf16").cpu().numpy()
+    assert rel_err(g16, g16_old) <= 2e-5   # the same bfloat16 filter through both kernel families
+    if not big:
+        assert rel_err(got, O.deconvolve_czyx(vol[None], tf, 1e-2)[0]) <= FFT_TOL
+    mov = np.roll(vol, (1, -5, 9), axis=(0, 1, 2))
+    shift, _ = phase_cross_corr(vol, mov, normalization="magnitude")
+    assert tuple(float(s) for s in shift) == (-1.0, 5.0, -9.0)
