@@ -125,7 +125,7 @@ def ops_suite(vol, psf, dev, ctx):
     """The other operators of the path at the bench shape, device-resident, each timed by the library's own HIP events on its
     stream (third run of three): ms, algorithmic bytes and that rate as a fraction of 8 TB/s.  Reported
     beside the headline, never part of `value`."""
-    from biahub_amd.apply_inverse_transfer_function import apply_inverse_transfer_function_zyx
+    from biahub_amd.apply_inverse_transfer_function import PreparedInverseFilter, apply_inverse_transfer_function_zyx
     from biahub_amd.deconvolve import tikhonov_zyx, transfer_function_device
     from biahub_amd.estimate_stabilization import phase_cross_corr_device
     from biahub_amd.flat_field import flat_field_device
@@ -156,10 +156,16 @@ def ops_suite(vol, psf, dev, ctx):
     del v16
     tf = transfer_function_device(psf, shape, dev)
     rec("tikhonov", lambda: tikhonov_zyx(vol, tf, 1e-3), _lib.T_TIKHONOV, 50 * V, "50 V: 2 FFTs (3-pass model) + real filter")
-    rec("apply_inv_tf_f32", lambda: apply_inverse_transfer_function_zyx(vol, tf, 0, 1e-3, True, "f32"), _lib.T_TIKHONOV, 56 * V,
-        "config 5 step: 2 FFTs (48 V) + complex filter (8 V), incl. mean normalisation and filter staging")
-    rec("apply_inv_tf_bf16", lambda: apply_inverse_transfer_function_zyx(vol, tf, 0, 1e-3, True, "bf16"), _lib.T_TIKHONOV, 52 * V,
-        "filter kept as bfloat16 pairs")
+    prep = PreparedInverseFilter(tf, shape, 0, 1e-3, "f32", dev)
+    rec("apply_inv_tf_f32", lambda: prep(vol, True), _lib.T_TIKHONOV, 56 * V,
+        "config 5 step per volume with the inverse filter staged once per position: 2 FFTs (48 V) + complex filter (8 V), "
+        "mean normalisation fused into the forward X pass")
+    prep.close()
+    prep = PreparedInverseFilter(tf, shape, 0, 1e-3, "bf16", dev)
+    rec("apply_inv_tf_bf16", lambda: prep(vol, True), _lib.T_TIKHONOV, 52 * V, "the staged filter kept as bfloat16 pairs")
+    prep.close()
+    rec("apply_inv_tf_f32_one_shot", lambda: apply_inverse_transfer_function_zyx(vol, tf, 0, 1e-3, True, "f32"), _lib.T_TIKHONOV,
+        56 * V, "stage the filter (reads the transfer function twice) + apply + release, per call")
     del tf
     mov = torch.roll(vol, (1, -3, 17), (0, 1, 2))
     torch.cuda.synchronize(dev)

@@ -24,6 +24,64 @@ from .utils.config import yaml_to_model
 _STORAGE = {"f32": _lib.FILTER_F32, "bf16": _lib.FILTER_BF16}
 
 
+def _tf_tensor(transfer_function, dev) -> torch.Tensor:
+    H = transfer_function if isinstance(transfer_function, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(transfer_function))
+    H = H.to(dev)
+    if H.dtype not in (torch.complex64, torch.float32):
+        H = H.to(torch.complex64 if H.is_complex() else torch.float32)
+    return H.contiguous()
+
+
+class PreparedInverseFilter:
+    """The inverse filter of one transfer function, staged once on the GPU (``bh_inverse_filter_create``) and applied to any
+    number of volumes of one shape — what the per-position job needs: waveorder reads the transfer function once per
+    position and reconstructs every time point with it.  Staging is a quarter of a one-shot call."""
+
+    def __init__(self, transfer_function, zyx_shape, z_padding: int = 0, regularization_strength: float = 1e-3,
+                 filter_storage: str = "f32", device="cuda"):
+        import ctypes
+
+        self.device = resolve_device(device)
+        H = _tf_tensor(transfer_function, self.device)
+        Z, Y, X = (int(s) for s in zyx_shape)
+        if H.ndim != 3 or tuple(H.shape) != (Z + 2 * int(z_padding), Y, X):
+            raise ValueError(f"transfer function shape {tuple(H.shape)} != padded data shape {(Z + 2 * int(z_padding), Y, X)}")
+        if filter_storage not in _STORAGE:
+            raise ValueError(f"filter_storage {filter_storage!r}: 'f32' or 'bf16'")
+        self.shape = (Z, Y, X)
+        self._ctx = get_context(self.device)
+        self._handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._ctx.lib.bh_inverse_filter_create(self._ctx.handle, ptr(H), int(H.is_complex()), Z, Y, X,
+                                                              int(z_padding), float(regularization_strength),
+                                                              _STORAGE[filter_storage], ctypes.byref(self._handle)))
+            torch.cuda.current_stream(self.device).synchronize()  # H may be dropped by the caller from here on
+
+    def __call__(self, zyx, normalize: bool = False) -> torch.Tensor:
+        x, code, _ = as_device_volume(zyx, self.device)
+        if code != _lib.DT_F32:
+            x = x.to(torch.float32)
+        if tuple(x.shape) != self.shape:
+            raise ValueError(f"volume shape {tuple(x.shape)} != the shape this filter was prepared for {self.shape}")
+        ctx = get_context(self.device)
+        with torch.cuda.device(self.device):
+            out = torch.empty_like(x)
+            _lib.check(ctx.lib.bh_inverse_filter_apply(ctx.handle, self._handle, ptr(x), int(bool(normalize)), ptr(out)))
+        return out
+
+    def close(self) -> None:
+        if self._handle:
+            torch.cuda.synchronize(self.device)
+            _lib.check(self._ctx.lib.bh_inverse_filter_destroy(self._handle))
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 def apply_inverse_transfer_function_zyx(zyx, transfer_function, z_padding: int = 0, regularization_strength: float = 1e-3,
                                         normalize: bool = False, filter_storage: str = "f32") -> torch.Tensor:
     """One volume on device.  ``transfer_function``: ``(Z + 2 z_padding, Y, X)`` in natural FFT order, complex64 (phase) or
@@ -55,11 +113,16 @@ def apply_inverse_transfer_function_zyx(zyx, transfer_function, z_padding: int =
 def apply_inverse_transfer_function_czyx(czyx_data: np.ndarray, transfer_function=None, z_padding: int = 0,
                                          regularization_strength: float = 1e-3, normalize: bool = False,
                                          absorption_ratio: float = 0.0, imaginary_transfer_function=None,
-                                         filter_storage: str = "f32", device="cuda") -> np.ndarray:
+                                         filter_storage: str = "f32", device="cuda", prepared: PreparedInverseFilter | None = None
+                                         ) -> np.ndarray:
     """Operator ``func(czyx, **kwargs) -> czyx`` of the per-position driver: the reconstruction of the (single) input channel.
     Phase: ``transfer_function`` = real potential transfer function, ``normalize=True``; a non-zero ``absorption_ratio`` adds
-    that fraction of ``imaginary_transfer_function`` (waveorder's effective transfer function)."""
+    that fraction of ``imaginary_transfer_function`` (waveorder's effective transfer function).  ``prepared``: a
+    ``PreparedInverseFilter`` staged by the caller (the per-position job stages one for all its time points)."""
     dev = resolve_device(device)
+    if prepared is not None:
+        return np.stack([to_host(prepared(torch.from_numpy(np.ascontiguousarray(zyx)).to(dev), normalize))
+                         for zyx in np.asarray(czyx_data)])
     H = transfer_function if isinstance(transfer_function, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(transfer_function))
     H = H.to(dev)
     if absorption_ratio:
@@ -144,6 +207,15 @@ def apply_inverse_transfer_function_single_position(input_position_dirpath, tran
         kw.update(transfer_function=H, z_padding=settings.fluorescence.transfer_function.z_padding, normalize=False,
                   regularization_strength=settings.fluorescence.apply_inverse.regularization_strength)
     times = meta["time_indices"]
-    process_single_position(apply_inverse_transfer_function_czyx, input_position_dirpath, output_position_dirpath,
-                            input_channel_indices=[[in_c]], output_channel_indices=[[0]], input_time_indices=times,
-                            output_time_indices=list(range(len(times))), **kw)
+    with open_ome_zarr(input_position_dirpath) as ds:
+        zyx_shape = tuple(ds.data.shape[-3:])
+    # the inverse filter is staged once for the position and applied to every time point
+    prepared = PreparedInverseFilter(kw.pop("transfer_function"), zyx_shape, kw.pop("z_padding"), kw.pop("regularization_strength"),
+                                     kw.pop("filter_storage"), dev)
+    del H
+    try:
+        process_single_position(apply_inverse_transfer_function_czyx, input_position_dirpath, output_position_dirpath,
+                                input_channel_indices=[[in_c]], output_channel_indices=[[0]], input_time_indices=times,
+                                output_time_indices=list(range(len(times))), prepared=prepared, **kw)
+    finally:
+        prepared.close()

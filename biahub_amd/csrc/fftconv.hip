@@ -1078,8 +1078,9 @@ static int launch_xw_m(bh_ctx* ctx, const xw::Params& p, int mode) {
 }
 
 static int launch_xw(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, const float* in, cf* S, float* out,
-                     const float* aux, float eps, bool fuse_fwd) {
+                     const float* aux, float eps, bool fuse_fwd, const double* norm_mean = nullptr) {
     xw::Params p;
+    p.norm_mean = norm_mean;
     p.in = in;
     p.S = S;
     p.out = out;
@@ -1241,9 +1242,17 @@ int fftconv_stage_inverse_filter(bh_ctx* ctx, const ConvPlan& pl, const void* tf
     return BH_OK;
 }
 
-// out = irfft( rfft(in) * staged filter ): 5 passes, the product rides in the Z pass
+// whether fftconv_apply_staged_filter can take the x / mean - 1 normalisation into its first pass
+bool fftconv_fuses_normalisation(const ConvPlan& pl) { return pl.xw; }
+
+// out = irfft( rfft(in) * staged filter ): 5 passes, the product rides in the Z pass.  norm_mean (device, may be null; only
+// when fftconv_fuses_normalisation): the forward X pass transforms in / *norm_mean - 1.
 int fftconv_apply_staged_filter(bh_ctx* ctx, const ConvPlan& pl, const float* in, const void* filt, bool bf16, cf* spec,
-                                float* out) {
+                                float* out, const double* norm_mean) {
+    if (norm_mean) {
+        BH_REQUIRE(pl.xw, "internal: fused normalisation needs the wave-private X passes");
+        BH_TRY(launch_xw(ctx, pl, false, 0, in, spec, nullptr, nullptr, 0.f, false, norm_mean));
+    } else
     BH_TRY(launch_x(ctx, pl, false, 0, in, spec, nullptr, nullptr, 0.f));
     BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));
     BH_TRY(launch_col(ctx, pl, bf16 ? COL_CONV16 : COL_CONV, true, spec, reinterpret_cast<const cf*>(filt), 1.f));

@@ -28,7 +28,8 @@ size_t fftconv_spectrum_elems(const ConvPlan& pl);
 int fftconv_stage_inverse_filter(bh_ctx* ctx, const ConvPlan& pl, const void* tf, bool tf_complex, float reg, bool bf16,
                                  void* filt);
 int fftconv_apply_staged_filter(bh_ctx* ctx, const ConvPlan& pl, const float* in, const void* filt, bool bf16, cf* spec,
-                                float* out);
+                                float* out, const double* norm_mean);
+bool fftconv_fuses_normalisation(const ConvPlan& pl);
 
 static dim3 grid_for(bh_ctx* ctx, int64_t n, int block = 256) {
     int64_t g = (n + block - 1) / block;
@@ -70,10 +71,26 @@ __global__ __launch_bounds__(256) void normalize_pad_kernel(const float* __restr
     }
 }
 
-// library path: S *= Hermitian part of conj(H) / (|H|^2 + reg), scaled by 1/V, on the (Z, Y, X/2+1) half spectrum
+}  // namespace bh
+
+using namespace bh;
+
+// A prepared inverse filter: the transfer function staged once (engine: the scrambled half-spectrum filter; library: the
+// Hermitian part on the (Z', Y, X/2+1) half spectrum), applied to any number of volumes of the same shape — a position's
+// time points, a plate's positions.  Staging reads the transfer function twice (k and -k) and is a quarter of a one-shot call.
+struct bh_filter {
+    int device = 0;
+    int64_t Z = 0, Y = 0, X = 0, z_padding = 0;
+    bool engine = false, bf16 = false;
+    bh::ConvPlan* plan = nullptr;   // engine
+    void* filt = nullptr;           // owned device memory
+};
+
+namespace bh {
+// library path: the staged filter is one complex factor per half-spectrum bin (incl. 1/V)
 template <bool CPLX>
-__global__ void inverse_filter_pointwise_kernel(cf* __restrict__ spec, const void* __restrict__ tf, int64_t Z, int64_t Y,
-                                                int64_t X, float reg, float inv_v) {
+__global__ void inverse_filter_stage_library_kernel(cf* __restrict__ filt, const void* __restrict__ tf, int64_t Z, int64_t Y,
+                                                    int64_t X, float reg, float inv_v) {
     const int64_t Xh = X / 2 + 1, n = Z * Y * Xh;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t x = i % Xh, zy = i / Xh, y = zy % Y, z = zy / Y;
@@ -87,39 +104,105 @@ __global__ void inverse_filter_pointwise_kernel(cf* __restrict__ spec, const voi
             hm = make_float2(reinterpret_cast<const float*>(tf)[(mz * Y + my) * X + mx], 0.f);
         }
         const float q = 1.0f / (h.x * h.x + h.y * h.y + reg), qm = 1.0f / (hm.x * hm.x + hm.y * hm.y + reg);
-        const cf f = make_float2(0.5f * (h.x * q + hm.x * qm) * inv_v, 0.5f * (-h.y * q + hm.y * qm) * inv_v);
-        const cf c = spec[i];
-        spec[i] = make_float2(c.x * f.x - c.y * f.y, c.x * f.y + c.y * f.x);
+        filt[i] = make_float2(0.5f * (h.x * q + hm.x * qm) * inv_v, 0.5f * (-h.y * q + hm.y * qm) * inv_v);
     }
 }
-
+__global__ void cmul_inplace_kernel(cf* __restrict__ spec, const cf* __restrict__ f, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cf c = spec[i], g = f[i];
+        spec[i] = make_float2(c.x * g.x - c.y * g.y, c.x * g.y + c.y * g.x);
+    }
+}
 }  // namespace bh
 
-using namespace bh;
-
-extern "C" int bh_inverse_filter(bh_ctx* ctx, const float* in, const void* tf, int tf_is_complex, int64_t Z, int64_t Y,
-                                 int64_t X, int64_t z_padding, double regularization_strength, int normalize,
-                                 int filter_storage, float* out) {
-    BH_REQUIRE(ctx && in && tf && out, "NULL argument");
+extern "C" int bh_inverse_filter_create(bh_ctx* ctx, const void* tf, int tf_is_complex, int64_t Z, int64_t Y, int64_t X,
+                                        int64_t z_padding, double regularization_strength, int filter_storage,
+                                        bh_filter** out) {
+    BH_REQUIRE(ctx && tf && out, "NULL argument");
     BH_REQUIRE(Z > 0 && Y > 0 && X > 0 && z_padding >= 0, "invalid shape");
     BH_REQUIRE(filter_storage == BH_FILTER_F32 || filter_storage == BH_FILTER_BF16, "filter_storage must be BH_FILTER_F32 or BH_FILTER_BF16");
     BH_REQUIRE(regularization_strength >= 0, "regularization_strength must be >= 0");
     BH_CHECK_HIP(hipSetDevice(ctx->device));
+    const int64_t Zp = Z + 2 * z_padding;
+    bh_filter* f = new bh_filter;
+    f->device = ctx->device;
+    f->Z = Z;
+    f->Y = Y;
+    f->X = X;
+    f->z_padding = z_padding;
+    f->bf16 = filter_storage == BH_FILTER_BF16;
+    f->engine = fftconv_supported_ex(Zp, Y, X, true) && !(getenv("BH_FFT_BACKEND") && !strcmp(getenv("BH_FFT_BACKEND"), "hipfft"));
+    auto fail = [&](int rc) {
+        if (f->filt) (void)hipFree(f->filt);
+        delete f;
+        return rc;
+    };
+    if (f->engine) {
+        int rc = fftconv_plan(ctx, Zp, Y, X, &f->plan);
+        if (rc != BH_OK) return fail(rc);
+        const size_t NS = fftconv_spectrum_elems(*f->plan);
+        if (hipMalloc(&f->filt, NS * (f->bf16 ? 4 : sizeof(cf))) != hipSuccess) {
+            set_error("out of device memory for the staged inverse filter (%zu bytes)", NS * (f->bf16 ? 4 : sizeof(cf)));
+            return fail(BH_ERR_NOMEM);
+        }
+        rc = fftconv_stage_inverse_filter(ctx, *f->plan, tf, tf_is_complex != 0, (float)regularization_strength, f->bf16, f->filt);
+        if (rc != BH_OK) return fail(rc);
+    } else {
+        if (f->bf16) {
+            set_error("the bfloat16 filter needs a shape the fused FFT engine takes (got %lld x %lld x %lld)", (long long)Zp,
+                      (long long)Y, (long long)X);
+            return fail(BH_ERR_INVALID);
+        }
+        const int64_t NS = Zp * Y * (X / 2 + 1);
+        if (hipMalloc(&f->filt, NS * sizeof(cf)) != hipSuccess) {
+            set_error("out of device memory for the staged inverse filter (%lld bytes)", (long long)(NS * sizeof(cf)));
+            return fail(BH_ERR_NOMEM);
+        }
+        const float inv_v = (float)(1.0 / ((double)Zp * Y * X));
+        if (tf_is_complex)
+            hipLaunchKernelGGL(inverse_filter_stage_library_kernel<true>, grid_for(ctx, NS), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<cf*>(f->filt), tf, Zp, Y, X, (float)regularization_strength, inv_v);
+        else
+            hipLaunchKernelGGL(inverse_filter_stage_library_kernel<false>, grid_for(ctx, NS), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<cf*>(f->filt), tf, Zp, Y, X, (float)regularization_strength, inv_v);
+        if (hipGetLastError() != hipSuccess) {
+            set_error("inverse filter staging kernel failed to launch");
+            return fail(BH_ERR_HIP);
+        }
+    }
+    *out = f;
+    return BH_OK;
+}
+
+extern "C" int bh_inverse_filter_destroy(bh_filter* f) {
+    if (!f) return BH_OK;
+    if (f->filt) {
+        (void)hipSetDevice(f->device);
+        (void)hipFree(f->filt);
+    }
+    delete f;
+    return BH_OK;
+}
+
+static int inverse_filter_apply_impl(bh_ctx* ctx, const bh_filter* f, const float* in, int normalize, float* out) {
     hipStream_t s = ctx->stream;
+    const int64_t Z = f->Z, Y = f->Y, X = f->X, z_padding = f->z_padding;
     const int64_t Zp = Z + 2 * z_padding, plane = Y * X, V = Z * plane, Vp = Zp * plane;
-    ScopedTimer timer(ctx, T_TIKHONOV);
-    const bool staged_input = normalize != 0 || z_padding != 0;
     const float* src = in;
     float* padded = nullptr;
+    double* part = nullptr;
+    const int nb = 1024;
+    if (normalize) {
+        BH_TRY(get_scratch(ctx, "itf_partials", (nb + 1) * sizeof(double), (void**)&part));
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, s, in, V, part);
+        hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(1), 0, s, part, nb, V);
+    }
+    // x / mean - 1 rides in the forward X pass when nothing has to be padded and the plan's X passes can take it
+    const bool fuse_norm = normalize && z_padding == 0 && f->engine && fftconv_fuses_normalisation(*f->plan);
+    const bool staged_input = (normalize != 0 && !fuse_norm) || z_padding != 0;
     if (staged_input) {
         BH_TRY(get_scratch(ctx, "itf_padded", Vp * sizeof(float), (void**)&padded));
-        double* part;
-        const int nb = 1024;
-        BH_TRY(get_scratch(ctx, "itf_partials", (nb + 1) * sizeof(double), (void**)&part));
-        if (normalize) {
-            hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, s, in, V, part);
-            hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(1), 0, s, part, nb, V);
-        }
+        if (!part) BH_TRY(get_scratch(ctx, "itf_partials", (nb + 1) * sizeof(double), (void**)&part));
         hipLaunchKernelGGL(normalize_pad_kernel, grid_for(ctx, Vp), dim3(256), 0, s, in, padded, V, plane, z_padding, Vp,
                            (const double*)(part + nb), normalize ? 1 : 0);
         BH_CHECK_HIP(hipGetLastError());
@@ -127,39 +210,51 @@ extern "C" int bh_inverse_filter(bh_ctx* ctx, const float* in, const void* tf, i
     }
     // the transforms write a full padded volume: straight into `out` when there is nothing to crop
     float* dst = z_padding ? padded : out;
-    const bool engine = fftconv_supported_ex(Zp, Y, X, true) && !(getenv("BH_FFT_BACKEND") && !strcmp(getenv("BH_FFT_BACKEND"), "hipfft"));
-    if (engine) {
-        ConvPlan* cp;
-        BH_TRY(fftconv_plan(ctx, Zp, Y, X, &cp));
-        const size_t NS = fftconv_spectrum_elems(*cp);
+    if (f->engine) {
+        const size_t NS = fftconv_spectrum_elems(*f->plan);
         cf* spec;
-        void* filt;
         BH_TRY(get_scratch(ctx, "fc_spec", NS * sizeof(cf), (void**)&spec));
-        BH_TRY(get_scratch(ctx, "itf_filter", NS * (filter_storage == BH_FILTER_BF16 ? 4 : sizeof(cf)), &filt));
-        BH_TRY(fftconv_stage_inverse_filter(ctx, *cp, tf, tf_is_complex != 0, (float)regularization_strength,
-                                            filter_storage == BH_FILTER_BF16, filt));
-        BH_TRY(fftconv_apply_staged_filter(ctx, *cp, src, filt, filter_storage == BH_FILTER_BF16, spec, dst));
+        BH_TRY(fftconv_apply_staged_filter(ctx, *f->plan, src, f->filt, f->bf16, spec, dst, fuse_norm ? part + nb : nullptr));
     } else {
-        BH_REQUIRE(filter_storage == BH_FILTER_F32, "the bfloat16 filter needs a shape the fused FFT engine takes (got %lld x %lld x %lld)",
-                   (long long)Zp, (long long)Y, (long long)X);
         FftPlans* pl;
         BH_TRY(get_plans(ctx, Zp, Y, X, &pl));
         const int64_t NS = Zp * Y * (X / 2 + 1);
         cf* spec;
         BH_TRY(get_scratch(ctx, "fft_spec", NS * sizeof(cf), (void**)&spec));
         BH_TRY(fft_forward(pl, src, spec));
-        if (tf_is_complex)
-            hipLaunchKernelGGL(inverse_filter_pointwise_kernel<true>, grid_for(ctx, NS), dim3(256), 0, s, spec, tf, Zp, Y, X,
-                               (float)regularization_strength, (float)(1.0 / (double)Vp));
-        else
-            hipLaunchKernelGGL(inverse_filter_pointwise_kernel<false>, grid_for(ctx, NS), dim3(256), 0, s, spec, tf, Zp, Y, X,
-                               (float)regularization_strength, (float)(1.0 / (double)Vp));
+        hipLaunchKernelGGL(cmul_inplace_kernel, grid_for(ctx, NS), dim3(256), 0, s, spec, reinterpret_cast<const cf*>(f->filt), NS);
         BH_CHECK_HIP(hipGetLastError());
         BH_TRY(fft_inverse(pl, spec, dst));
     }
     if (z_padding)
         BH_CHECK_HIP(hipMemcpyAsync(out, padded + z_padding * plane, V * sizeof(float), hipMemcpyDeviceToDevice, s));
     return BH_OK;
+}
+
+extern "C" int bh_inverse_filter_apply(bh_ctx* ctx, const bh_filter* f, const float* in, int normalize, float* out) {
+    BH_REQUIRE(ctx && f && in && out, "NULL argument");
+    BH_REQUIRE(f->device == ctx->device, "the filter was prepared on device %d, the context is on device %d", f->device, ctx->device);
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    ScopedTimer timer(ctx, T_TIKHONOV);
+    return inverse_filter_apply_impl(ctx, f, in, normalize, out);
+}
+
+// one-shot form: prepare, apply, release (timed as a whole)
+extern "C" int bh_inverse_filter(bh_ctx* ctx, const float* in, const void* tf, int tf_is_complex, int64_t Z, int64_t Y,
+                                 int64_t X, int64_t z_padding, double regularization_strength, int normalize,
+                                 int filter_storage, float* out) {
+    BH_REQUIRE(ctx && in && tf && out, "NULL argument");
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    bh_filter* f = nullptr;
+    ScopedTimer timer(ctx, T_TIKHONOV);
+    BH_TRY(bh_inverse_filter_create(ctx, tf, tf_is_complex, Z, Y, X, z_padding, regularization_strength, filter_storage, &f));
+    int rc = inverse_filter_apply_impl(ctx, f, in, normalize, out);
+    if (rc == BH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {  // the filter memory is released below
+        set_error("hipStreamSynchronize failed after bh_inverse_filter_apply");
+        rc = BH_ERR_HIP;
+    }
+    (void)bh_inverse_filter_destroy(f);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------ compute

@@ -211,6 +211,16 @@ int bh_tikhonov(bh_ctx* ctx, const float* in, const float* tf_full, int64_t Z, i
 enum { BH_FILTER_F32 = 0, BH_FILTER_BF16 = 1 };
 int bh_inverse_filter(bh_ctx* ctx, const float* in, const void* tf, int tf_is_complex, int64_t Z, int64_t Y, int64_t X,
                       int64_t z_padding, double regularization_strength, int normalize, int filter_storage, float* out);
+/* The same in two steps, for the time points of a position / the positions of a plate that share one transfer function
+ * (what waveorder's per-position job does with the array it reads once from the transfer-function store): `create` stages
+ * the inverse filter (a quarter of a one-shot call's time) into device memory the handle owns, `apply` runs one volume
+ * through it (in / out float32 (Z, Y, X), may alias), `destroy` releases it.  A handle belongs to the device of the context
+ * that created it and may be used from any context of that device. */
+typedef struct bh_filter bh_filter;
+int bh_inverse_filter_create(bh_ctx* ctx, const void* tf, int tf_is_complex, int64_t Z, int64_t Y, int64_t X, int64_t z_padding,
+                             double regularization_strength, int filter_storage, bh_filter** out);
+int bh_inverse_filter_apply(bh_ctx* ctx, const bh_filter* filter, const float* in, int normalize, float* out);
+int bh_inverse_filter_destroy(bh_filter* filter);
 
 /* Transfer functions from the optical parameters, complex64 (Z + 2 z_padding, Y, X) in natural FFT order.
  * Phase: weak-object transfer functions of the real and imaginary scattering potential (waveorder
