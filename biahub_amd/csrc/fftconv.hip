@@ -950,7 +950,7 @@ static int launch_colw(bh_ctx* ctx, ColParams p, int mode) {
     p.W = G::W;
     p.ncoltiles = (int)ceil_div(p.XP, p.W);
     const long ntiles = (long)p.nouter * p.ncoltiles;
-    const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
+    const int grid = (int)std::min<long>(ntiles, (long)ctx->num_cus * (512 / colw::NT));
     auto run = [&](auto kern) -> int {
         BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)G::LDS_BYTES));

@@ -277,3 +277,23 @@ def test_product_average_n_slices_golden():
     for w in (1, 2, 3):
         got = _average_n_slices(z["data"], w)
         assert got.shape == z[f"w{w}"].shape and np.array_equal(got, z[f"w{w}"]), w
+
+
+def test_register_stage_column_pass_model():
+    """tools/colw_model.py is the executable specification of csrc/fftconv_colw.inc: index maps, the three-stage column
+    transform against numpy's FFT, and conflict-free LDS exchanges with the kernel's padding rule (128 B per 32 rows)."""
+    import importlib.util
+    import sys
+    from pathlib import Path
+
+    tools = Path(__file__).resolve().parent.parent / "tools"
+    sys.path.insert(0, str(tools))
+    try:
+        spec = importlib.util.spec_from_file_location("colw_model", tools / "colw_model.py")
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        for logn in (8, 9, 10):
+            tot = m.check(logn, lambda row: (row >> 5) * 8, verbose=False)
+            assert all(c == i for c, i in tot.values()), (logn, tot)
+    finally:
+        sys.path.remove(str(tools))
