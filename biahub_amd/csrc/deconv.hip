@@ -117,6 +117,11 @@ __global__ void tikhonov_filter_kernel(cf* __restrict__ spec, const float* __res
     }
 }
 
+// real parts of a complex array (the real transfer function of a point-symmetric PSF)
+__global__ void real_part_kernel(const cf* __restrict__ a, float* __restrict__ re, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) re[i] = a[i].x;
+}
+
 // ---- Richardson-Lucy pointwise kernels (float4 / 2x complex per lane) ---------------------
 __global__ void scale_spectrum_kernel(cf* __restrict__ s, int64_t n, float f) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -449,7 +454,7 @@ int fftconv_plan_tag(const ConvPlan& pl);
 int fftconv_make_otf(bh_ctx* ctx, const ConvPlan& pl, const float* padded_psf, cf* otf);
 int fftconv_apply(bh_ctx* ctx, const ConvPlan& pl, const float* in, const cf* otf, bool correlate, cf* spec,
                   int epilogue, const float* aux, float eps, float* out);
-int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, const cf* otf, cf* spec, int iterations,
+int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, const cf* otf, bool otf_real, cf* spec, int iterations,
                             float eps, float* est);
 int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, const float* est_p, const float* d_p, const cf* otf,
                                 cf* spec, float eps, float* corr_p);
@@ -472,18 +477,19 @@ static bool use_fused_engine_any_order(int64_t Z, int64_t Y, int64_t X) {
 
 // order-sensitive 64-bit content hash of a small device array (one block; the PSF is a few thousand floats).  With `kept`
 // (the device copy of the PSF whose OTF is cached) out[1] also says whether the two arrays are equal word for word: a hash
-// match alone never validates the cache.
+// match alone never validates the cache.  out[2]: the array equals its point mirror bit for bit (flat index i <-> n - 1 - i).
 __global__ __launch_bounds__(256) void content_hash_kernel(const uint32_t* __restrict__ data, int64_t n,
                                                            const uint32_t* __restrict__ kept, unsigned long long* out) {
     __shared__ unsigned long long sh[256];
-    __shared__ int differs;
-    if (threadIdx.x == 0) differs = 0;
+    __shared__ int differs, asym;
+    if (threadIdx.x == 0) differs = asym = 0;
     __syncthreads();
     unsigned long long h = 0xcbf29ce484222325ull ^ (unsigned long long)threadIdx.x;
     int diff = 0;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const uint32_t v = data[i];
         if (kept && kept[i] != v) diff = 1;
+        if (data[n - 1 - i] != v) asym = 1;  // point symmetry h(-n) == h(n) of an array with odd extents: flat index i <-> n - 1 - i
         h ^= (unsigned long long)v + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
         h *= 0x100000001b3ull;
         h ^= h >> 29;
@@ -496,6 +502,7 @@ __global__ __launch_bounds__(256) void content_hash_kernel(const uint32_t* __res
         for (int i = 0; i < 256; ++i) t = (t ^ sh[i]) * 0x100000001b3ull + (t >> 31);
         out[0] = t;
         out[1] = (kept && !differs) ? 1ull : 0ull;
+        out[2] = asym ? 0ull : 1ull;
     }
 }
 
@@ -540,9 +547,10 @@ static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, 
     // The OTF only depends on the PSF and the shapes: a plate reuses one PSF for every position, so keep the OTF
     // across calls and rebuild it only when the PSF's content hash (or a shape) changes.
     unsigned long long* dhash = reinterpret_cast<unsigned long long*>(psum) + 1;
-    unsigned long long hv[2] = {0, 0};
+    unsigned long long hv[3] = {0, 0, 0};
     const int64_t dims[6] = {pz, py, px, Z, Y, X};
-    const int tag = fftconv_plan_tag(*pl);  // which spectrum layout the plan's kernels keep: an OTF only fits its own
+    // which spectrum layout the plan's kernels keep (an OTF only fits its own) and whether the real form is wanted too
+    const int tag = fftconv_plan_tag(*pl) + (getenv("BH_RL_COMPLEX_OTF") ? 0 : 2);
     bool same_key = ctx->otf_valid && ctx->otf_tag == tag;
     for (int i = 0; i < 6; ++i) same_key = same_key && ctx->otf_dims[i] == dims[i];
     const size_t psf_bytes = (size_t)(pz * py * px) * sizeof(float);
@@ -556,6 +564,13 @@ static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, 
     BH_CHECK_HIP(hipMemcpyAsync(hv, dhash, sizeof(hv), hipMemcpyDeviceToHost, s));
     BH_CHECK_HIP(hipStreamSynchronize(s));
     const bool hit = same_key && hv[1] == 1ull;
+    // A PSF with odd extents that equals its point mirror bit for bit (every theoretical PSF; the bench's Gaussian) sits
+    // symmetric about the origin after staging, so its transfer function is REAL: the imaginary parts the transforms leave
+    // are round-off.  The Z passes then read one float per bin instead of two (17.4 -> 8.7 GB per iteration at config 2) and
+    // convolution and correlation are the same pass.  BH_RL_COMPLEX_OTF=1 keeps the general path (A/B switch).
+    const bool real_otf = (pz & 1) && (py & 1) && (px & 1) && hv[2] == 1ull && getenv("BH_RL_COMPLEX_OTF") == nullptr;
+    float* otf_real = nullptr;
+    if (real_otf) BH_TRY(get_scratch(ctx, "fc_otf_real", NS * sizeof(float), (void**)&otf_real));
     if (!hit) {
         ctx->otf_valid = false;
         // the padded PSF is staged in the spectrum buffer's own memory? no: it must survive the forward X pass that
@@ -563,6 +578,10 @@ static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, 
         BH_TRY(get_scratch(ctx, "fft_real", V * sizeof(float), (void**)&real));
         BH_TRY(stage_rl_psf(ctx, psf, pz, py, px, Z, Y, X, real, psum));
         BH_TRY(fftconv_make_otf(ctx, *pl, real, otf));
+        if (real_otf) {
+            hipLaunchKernelGGL(real_part_kernel, grid_for(ctx, (int64_t)NS), dim3(256), 0, s, otf, otf_real, (int64_t)NS);
+            BH_CHECK_HIP(hipGetLastError());
+        }
         BH_CHECK_HIP(hipMemcpyAsync(kept, psf, psf_bytes, hipMemcpyDeviceToDevice, s));
         ctx->otf_hash = hv[0];
         ctx->otf_tag = tag;
@@ -576,7 +595,8 @@ static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, 
         BH_CHECK_HIP(hipEventCreate(&e1));
         BH_CHECK_HIP(hipEventRecord(e0, s));
     }
-    BH_TRY(fftconv_richardson_lucy(ctx, *pl, d, otf, spec, iterations, eps, out));
+    BH_TRY(fftconv_richardson_lucy(ctx, *pl, d, real_otf ? reinterpret_cast<const cf*>(otf_real) : otf, real_otf, spec, iterations,
+                                   eps, out));
     if (e0) {
         BH_CHECK_HIP(hipEventRecord(e1, s));
         BH_CHECK_HIP(hipEventSynchronize(e1));

@@ -1293,9 +1293,12 @@ static int slab_planes(const ConvPlan& pl) {
 // `est` is output only: the first pass fills it with max(d, 0).
 // With BH_FC_SLAB_MB set, the Yinv -> X -> Yfwd chain between two Z passes runs slab by slab (a few z planes at a time), so
 // that each kernel finds the planes its predecessor just wrote in the 256-MB memory-side cache instead of HBM.
-int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, const cf* otf, cf* spec, int iterations,
-                            float eps, float* est) {
+int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, const cf* otf, bool otf_real, cf* spec,
+                            int iterations, float eps, float* est) {
     if (iterations <= 0) return BH_OK;
+    // otf_real: `otf` holds one float per bin (the transfer function of a point-symmetric PSF); convolution and correlation
+    // are then the same real product
+    const int CONV = otf_real ? COL_FILTER : COL_CONV, CORR = otf_real ? COL_FILTER : COL_CORR;
     const int slab = slab_planes(pl);
     if (slab > 0) {
         const int Z = pl.d.Z;
@@ -1306,14 +1309,14 @@ int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, con
         }
         for (int it = 0; it < iterations; ++it) {
             const bool last = it + 1 == iterations;
-            BH_TRY(launch_col(ctx, pl, COL_CONV, true, spec, otf, 1.f));
+            BH_TRY(launch_col(ctx, pl, CONV, true, spec, otf, 1.f));
             for (int z0 = 0; z0 < Z; z0 += slab) {
                 const int nz = std::min(slab, Z - z0);
                 BH_TRY(launch_col_y_slab(ctx, pl, COL_INV, spec, z0, nz));
                 BH_TRY(launch_x_slab(ctx, pl, true, XE_RATIO, nullptr, spec, nullptr, d, eps, true, z0, nz));
                 BH_TRY(launch_col_y_slab(ctx, pl, COL_FWD, spec, z0, nz));
             }
-            BH_TRY(launch_col(ctx, pl, COL_CORR, true, spec, otf, 1.f));
+            BH_TRY(launch_col(ctx, pl, CORR, true, spec, otf, 1.f));
             for (int z0 = 0; z0 < Z; z0 += slab) {
                 const int nz = std::min(slab, Z - z0);
                 BH_TRY(launch_col_y_slab(ctx, pl, COL_INV, spec, z0, nz));
@@ -1326,11 +1329,11 @@ int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, con
     BH_TRY(launch_x(ctx, pl, false, 0, d, spec, est, nullptr, 0.f));  // est = max(d, 0) written by the same pass
     for (int it = 0; it < iterations; ++it) {
         BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));
-        BH_TRY(launch_col(ctx, pl, COL_CONV, true, spec, otf, 1.f));
+        BH_TRY(launch_col(ctx, pl, CONV, true, spec, otf, 1.f));
         BH_TRY(launch_col(ctx, pl, COL_INV, false, spec, nullptr, 1.f));
         BH_TRY(launch_x(ctx, pl, true, XE_RATIO, nullptr, spec, nullptr, d, eps, true));
         BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));
-        BH_TRY(launch_col(ctx, pl, COL_CORR, true, spec, otf, 1.f));
+        BH_TRY(launch_col(ctx, pl, CORR, true, spec, otf, 1.f));
         BH_TRY(launch_col(ctx, pl, COL_INV, false, spec, nullptr, 1.f));
         BH_TRY(launch_x(ctx, pl, true, XE_UPDATE, nullptr, spec, est, est, eps, it + 1 < iterations));
     }

@@ -1319,3 +1319,29 @@ def test_register_stage_column_passes(gpu, shape, pshape, monkeypatch):
     mov = np.roll(vol, (1, -5, 9), axis=(0, 1, 2))
     shift, _ = phase_cross_corr(vol, mov, normalization="magnitude")
     assert tuple(float(s) for s in shift) == (-1.0, 5.0, -9.0)
+
+
+@pytest.mark.parametrize("shape,pshape", [((32, 64, 128), (9, 7, 5)), ((256, 64, 1024), (5, 5, 9))])
+def test_richardson_lucy_real_otf_of_symmetric_psf(gpu, shape, pshape, monkeypatch):
+    """A PSF with odd extents that equals its point mirror has a real transfer function: the Z passes then read one float
+    per bin and run convolution and correlation as the same real product.  Same result as the general complex path
+    (BH_RL_COMPLEX_OTF=1) and as the oracle; a PSF that is not symmetric (or has an even extent) keeps the complex path."""
+    from biahub_amd.deconvolve import richardson_lucy
+
+    vol = O.synthetic_volume(shape, seed=41, n_blobs=12)
+    psf = O.gaussian_psf(pshape, tuple(p / 4.0 for p in pshape))
+    assert np.array_equal(psf, psf[::-1, ::-1, ::-1])
+    v, pt = torch.from_numpy(vol).to(gpu), torch.from_numpy(psf).to(gpu)
+    real = richardson_lucy(v, pt, 5, 1e-6).cpu().numpy()
+    monkeypatch.setenv("BH_RL_COMPLEX_OTF", "1")
+    cplx = richardson_lucy(v, pt, 5, 1e-6).cpu().numpy()
+    monkeypatch.delenv("BH_RL_COMPLEX_OTF")
+    assert rel_err(real, cplx) <= 2e-6, rel_err(real, cplx)
+    assert rel_err(real, O.richardson_lucy_zyx(vol, psf, 5, 1e-6)) <= FFT_TOL
+    # asymmetric PSF right after a symmetric one of the same shape: the cache must not hand out the real form
+    psf2 = psf.copy()
+    psf2[0, 1, 2] *= 1.5
+    got = richardson_lucy(v, torch.from_numpy(psf2).to(gpu), 5, 1e-6).cpu().numpy()
+    assert rel_err(got, O.richardson_lucy_zyx(vol, psf2, 5, 1e-6)) <= FFT_TOL
+    again = richardson_lucy(v, pt, 5, 1e-6).cpu().numpy()
+    assert np.array_equal(again, real)
