@@ -307,9 +307,10 @@ def main():
                 "positions_per_step": world,
             },
             "roofline": {
-                "kernel": "one Richardson-Lucy iteration = 8 in-place passes of csrc/fftconv.hip: 2 x (col_pass Y fwd, "
-                          "col_pass Z fwd*OTF*inv, col_pass Y inv, xw_kernel<FUSED_*>: inverse X + RL epilogue + next forward X "
-                          "in registers, csrc/fftconv_xw.inc)",
+                "kernel": "one Richardson-Lucy iteration = 8 in-place passes of csrc/fftconv.hip: 2 x (colw_kernel Y fwd "
+                          "[register stages, csrc/fftconv_colw.inc], col_pass_kernel Z fwd*OTF*inv [real OTF: the Gaussian PSF is "
+                          "point-symmetric], colw_kernel Y inv, xw_kernel<FUSED_*>: inverse X + RL epilogue + next forward X in "
+                          "registers, csrc/fftconv_xw.inc)",
                 "bound": "hbm",
                 "achieved": rl_bytes / rl_iter_s / 1e9,
                 "peak": HBM_PEAK_GBS,

@@ -40,9 +40,20 @@ def moved(sub, count=1):
     return count * (hit[0][1] + hit[0][2]) * 1e9
 
 
-# one Richardson-Lucy iteration: 2 x (Y fwd, Z x OTF, Y inv) + fused ratio X + fused update X
-it = (moved("col_pass_kernel<0,", 2) + moved("col_pass_kernel<1,", 2) + moved("col_pass_kernel<3,") + moved("col_pass_kernel<4,") +
-      moved("xw_kernel<10, 4>") + moved("xw_kernel<10, 5>"))
+# one Richardson-Lucy iteration: 2 x (Y fwd, Z x OTF, Y inv) + fused ratio X + fused update X.  Which kernels those are
+# depends on the build's defaults (register-stage or LDS-stepped column passes; real or complex transfer function): take the
+# per-launch bytes of whatever ran, weighted by how often it ran per iteration (calls / iterations).
+def per_iteration(sub):
+    hit = [(k, v) for k, v in rows.items() if sub in k]
+    return sum(v[1] + v[2] for _, v in hit) * 1e9 / max(1, len(hit)), sum(v[0] for _, v in hit)
+
+
+n_it = rows[[k for k in rows if "xw_kernel<10, 4>" in k][0]][0]  # one fused-ratio launch per iteration
+it = moved("xw_kernel<10, 4>") + moved("xw_kernel<10, 5>")
+col = {k: v for k, v in rows.items() if "col_pass_kernel<" in k or "colw_kernel<" in k}
+for k, v in col.items():
+    per_it = round(v[0] / n_it)          # launches of this kernel per iteration (the OTF build adds a stray call or two)
+    it += per_it * (v[1] + v[2]) * 1e9
 rec = {"shape": shape, "unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KiB counters x1024)", "rl_iteration": it,
        "deskew_kernel": moved("deskew_kernel<"),
        "per_kernel_gb": {k[:60]: round(v[1] + v[2], 3) for k, v in rows.items()},
