@@ -64,6 +64,7 @@ SIGNATURES = {
     "bh_inverse_filter_create": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, _f64, _int, C.POINTER(_vp)]),
     "bh_inverse_filter_apply": (_int, [_vp, _vp, _vp, _int, _vp]),
     "bh_inverse_filter_destroy": (_int, [_vp]),
+    "bh_inverse_filter_trim": (_int, []),
     "bh_phase_transfer_function_3d": (_int, [_vp, _i64, _i64, _i64, _f64, _f64, _f64, _i64, _f64, _f64, _f64, _int, _vp, _vp]),
     "bh_fluorescence_transfer_function_3d": (_int, [_vp, _i64, _i64, _i64, _f64, _f64, _f64, _i64, _f64, _f64, _vp]),
     "bh_fourier_central_cuboid": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64]),

@@ -16,6 +16,7 @@
 #include "common.hpp"
 
 #include <cstring>
+#include <mutex>
 
 namespace bh {
 
@@ -83,10 +84,31 @@ struct bh_filter {
     int64_t Z = 0, Y = 0, X = 0, z_padding = 0;
     bool engine = false, bf16 = false;
     bh::ConvPlan* plan = nullptr;   // engine
-    void* filt = nullptr;           // owned device memory
+    void* filt = nullptr;           // the staged filter
+    size_t filt_bytes = 0;
+    bool owned = true;              // false: `filt` is the context's scratch (one-shot form), not released with the handle
 };
 
 namespace bh {
+// Staged filters are gigabytes; hipMalloc / hipFree of such blocks cost hundreds of milliseconds (page-table work) — more
+// than reconstructing a position's time points.  Released blocks are therefore kept per (device, size) and handed to the next
+// handle of that size: a plate's positions all ask for the same size.  bh_ctx_release_workspace does not touch them;
+// they live until the process ends or bh_inverse_filter_trim() is called.
+static std::mutex g_filter_pool_mu;
+static std::map<std::pair<int, size_t>, std::vector<void*>> g_filter_pool;
+static void* filter_pool_take(int device, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_filter_pool_mu);
+    auto it = g_filter_pool.find({device, bytes});
+    if (it == g_filter_pool.end() || it->second.empty()) return nullptr;
+    void* p = it->second.back();
+    it->second.pop_back();
+    return p;
+}
+static void filter_pool_give(int device, size_t bytes, void* p) {
+    std::lock_guard<std::mutex> lock(g_filter_pool_mu);
+    g_filter_pool[{device, bytes}].push_back(p);
+}
+
 // library path: the staged filter is one complex factor per half-spectrum bin (incl. 1/V)
 template <bool CPLX>
 __global__ void inverse_filter_stage_library_kernel(cf* __restrict__ filt, const void* __restrict__ tf, int64_t Z, int64_t Y,
@@ -115,9 +137,9 @@ __global__ void cmul_inplace_kernel(cf* __restrict__ spec, const cf* __restrict_
 }
 }  // namespace bh
 
-extern "C" int bh_inverse_filter_create(bh_ctx* ctx, const void* tf, int tf_is_complex, int64_t Z, int64_t Y, int64_t X,
-                                        int64_t z_padding, double regularization_strength, int filter_storage,
-                                        bh_filter** out) {
+static int inverse_filter_create_impl(bh_ctx* ctx, const void* tf, int tf_is_complex, int64_t Z, int64_t Y, int64_t X,
+                                      int64_t z_padding, double regularization_strength, int filter_storage, bool use_scratch,
+                                      bh_filter** out) {
     BH_REQUIRE(ctx && tf && out, "NULL argument");
     BH_REQUIRE(Z > 0 && Y > 0 && X > 0 && z_padding >= 0, "invalid shape");
     BH_REQUIRE(filter_storage == BH_FILTER_F32 || filter_storage == BH_FILTER_BF16, "filter_storage must be BH_FILTER_F32 or BH_FILTER_BF16");
@@ -132,19 +154,31 @@ extern "C" int bh_inverse_filter_create(bh_ctx* ctx, const void* tf, int tf_is_c
     f->z_padding = z_padding;
     f->bf16 = filter_storage == BH_FILTER_BF16;
     f->engine = fftconv_supported_ex(Zp, Y, X, true) && !(getenv("BH_FFT_BACKEND") && !strcmp(getenv("BH_FFT_BACKEND"), "hipfft"));
+    f->owned = !use_scratch;
     auto fail = [&](int rc) {
-        if (f->filt) (void)hipFree(f->filt);
+        if (f->filt && f->owned) filter_pool_give(f->device, f->filt_bytes, f->filt);
         delete f;
         return rc;
+    };
+    // device memory of the staged filter: the handle's own, or (one-shot form: hipMalloc / hipFree of gigabytes cost far more
+    // than the filter pass itself) the context's grow-only scratch
+    auto alloc = [&](size_t bytes) -> int {
+        f->filt_bytes = bytes;
+        if (use_scratch) return get_scratch(ctx, "itf_filter", bytes, &f->filt);
+        if ((f->filt = filter_pool_take(ctx->device, bytes)) != nullptr) return BH_OK;
+        if (hipMalloc(&f->filt, bytes) != hipSuccess) {
+            f->filt = nullptr;
+            set_error("out of device memory for the staged inverse filter (%zu bytes)", bytes);
+            return BH_ERR_NOMEM;
+        }
+        return BH_OK;
     };
     if (f->engine) {
         int rc = fftconv_plan(ctx, Zp, Y, X, &f->plan);
         if (rc != BH_OK) return fail(rc);
         const size_t NS = fftconv_spectrum_elems(*f->plan);
-        if (hipMalloc(&f->filt, NS * (f->bf16 ? 4 : sizeof(cf))) != hipSuccess) {
-            set_error("out of device memory for the staged inverse filter (%zu bytes)", NS * (f->bf16 ? 4 : sizeof(cf)));
-            return fail(BH_ERR_NOMEM);
-        }
+        rc = alloc(NS * (f->bf16 ? 4 : sizeof(cf)));
+        if (rc != BH_OK) return fail(rc);
         rc = fftconv_stage_inverse_filter(ctx, *f->plan, tf, tf_is_complex != 0, (float)regularization_strength, f->bf16, f->filt);
         if (rc != BH_OK) return fail(rc);
     } else {
@@ -154,10 +188,8 @@ extern "C" int bh_inverse_filter_create(bh_ctx* ctx, const void* tf, int tf_is_c
             return fail(BH_ERR_INVALID);
         }
         const int64_t NS = Zp * Y * (X / 2 + 1);
-        if (hipMalloc(&f->filt, NS * sizeof(cf)) != hipSuccess) {
-            set_error("out of device memory for the staged inverse filter (%lld bytes)", (long long)(NS * sizeof(cf)));
-            return fail(BH_ERR_NOMEM);
-        }
+        const int rc = alloc((size_t)NS * sizeof(cf));
+        if (rc != BH_OK) return fail(rc);
         const float inv_v = (float)(1.0 / ((double)Zp * Y * X));
         if (tf_is_complex)
             hipLaunchKernelGGL(inverse_filter_stage_library_kernel<true>, grid_for(ctx, NS), dim3(256), 0, ctx->stream,
@@ -174,13 +206,28 @@ extern "C" int bh_inverse_filter_create(bh_ctx* ctx, const void* tf, int tf_is_c
     return BH_OK;
 }
 
+extern "C" int bh_inverse_filter_create(bh_ctx* ctx, const void* tf, int tf_is_complex, int64_t Z, int64_t Y, int64_t X,
+                                        int64_t z_padding, double regularization_strength, int filter_storage,
+                                        bh_filter** out) {
+    return inverse_filter_create_impl(ctx, tf, tf_is_complex, Z, Y, X, z_padding, regularization_strength, filter_storage, false, out);
+}
+
 extern "C" int bh_inverse_filter_destroy(bh_filter* f) {
     if (!f) return BH_OK;
-    if (f->filt) {
-        (void)hipSetDevice(f->device);
-        (void)hipFree(f->filt);
-    }
+    // the block goes back to the pool, not to the driver; work already enqueued on it is ordered before any reuse as long
+    // as handles of one device are used on one stream at a time (the contexts of this library are)
+    if (f->filt && f->owned) filter_pool_give(f->device, f->filt_bytes, f->filt);
     delete f;
+    return BH_OK;
+}
+
+extern "C" int bh_inverse_filter_trim(void) {
+    std::lock_guard<std::mutex> lock(g_filter_pool_mu);
+    for (auto& kv : g_filter_pool) {
+        (void)hipSetDevice(kv.first.first);
+        for (void* p : kv.second) (void)hipFree(p);
+    }
+    g_filter_pool.clear();
     return BH_OK;
 }
 
@@ -247,13 +294,9 @@ extern "C" int bh_inverse_filter(bh_ctx* ctx, const float* in, const void* tf, i
     BH_CHECK_HIP(hipSetDevice(ctx->device));
     bh_filter* f = nullptr;
     ScopedTimer timer(ctx, T_TIKHONOV);
-    BH_TRY(bh_inverse_filter_create(ctx, tf, tf_is_complex, Z, Y, X, z_padding, regularization_strength, filter_storage, &f));
-    int rc = inverse_filter_apply_impl(ctx, f, in, normalize, out);
-    if (rc == BH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {  // the filter memory is released below
-        set_error("hipStreamSynchronize failed after bh_inverse_filter_apply");
-        rc = BH_ERR_HIP;
-    }
-    (void)bh_inverse_filter_destroy(f);
+    BH_TRY(inverse_filter_create_impl(ctx, tf, tf_is_complex, Z, Y, X, z_padding, regularization_strength, filter_storage, true, &f));
+    const int rc = inverse_filter_apply_impl(ctx, f, in, normalize, out);
+    (void)bh_inverse_filter_destroy(f);  // the staged filter lives in the context's scratch: nothing to free, nothing to wait for
     return rc;
 }
 

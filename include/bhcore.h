@@ -221,6 +221,9 @@ int bh_inverse_filter_create(bh_ctx* ctx, const void* tf, int tf_is_complex, int
                              double regularization_strength, int filter_storage, bh_filter** out);
 int bh_inverse_filter_apply(bh_ctx* ctx, const bh_filter* filter, const float* in, int normalize, float* out);
 int bh_inverse_filter_destroy(bh_filter* filter);
+/* Released filter blocks are kept per (device, size) for the next handle of that size (allocating gigabytes costs more than
+ * reconstructing a position): this hands them back to the driver. */
+int bh_inverse_filter_trim(void);
 
 /* Transfer functions from the optical parameters, complex64 (Z + 2 z_padding, Y, X) in natural FFT order.
  * Phase: weak-object transfer functions of the real and imaginary scattering potential (waveorder

@@ -58,7 +58,10 @@ rec = {"shape": shape, "unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, Ki
        "deskew_kernel": moved("deskew_kernel<"),
        "per_kernel_gb": {k[:60]: round(v[1] + v[2], 3) for k, v in rows.items()},
        "source": f"{prefix}_pmc_hbm_traffic.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of "
-                 "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end`, summed over the 8 passes of one iteration"}
+                 "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-ops`, summed over the 8 passes of one "
+                 "iteration.  The x2 of FETCH_SIZE is calibrated for 16-B-per-lane reads; the real-OTF Z pass reads its multiplier "
+                 "with 8 B per lane, which the counter probably tallies exactly, so its fetch (and the iteration total, by up to "
+                 "2 x 4.4 GB at config 2) may be overstated"}
 open(prefix + "_pmc_hbm_traffic.txt", "w").write("\n".join(lines) + "\n")
 json.dump(rec, open(prefix + "_pmc_hbm_traffic.json", "w"), indent=1)
 print("\n".join(lines[:14]))
