@@ -55,9 +55,32 @@ constexpr bool FC_XR16 = BH_FC_XR16 != 0;
 
 __device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// Complex products as TWO packed instructions (v_pk_mul_f32 + v_pk_fma_f32 with op_sel / neg modifiers picking the halves):
+// the compiler's own lowering spends four to six instructions on them, a quarter of the arithmetic of the register FFT stages
+// being v_mov shuffles that line operands up for packed adds.  BH_FC_PK_CMUL=0 keeps the plain C form (A/B switch).
+#ifndef BH_FC_PK_CMUL
+#define BH_FC_PK_CMUL 1
+#endif
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+#if BH_FC_PK_CMUL
+    v2f_t av = {a.x, a.y}, bv = {b.x, b.y}, t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(av), "v"(bv));                     // (a.x b.x, a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));  // (-a.y b.y, a.y b.x) + t
+    return make_float2(r.x, r.y);
+#else
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+#endif
+}
 __device__ __forceinline__ cf cmulc(cf a, cf b) {  // a * conj(b)
+#if BH_FC_PK_CMUL
+    v2f_t av = {a.x, a.y}, bv = {b.x, b.y}, t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(av), "v"(bv));         // (a.x b.x, -a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));      // (a.y b.y, a.y b.x) + t
+    return make_float2(r.x, r.y);
+#else
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+#endif
 }
 __device__ __forceinline__ cf cconj(cf a) { return make_float2(a.x, -a.y); }
 __device__ __forceinline__ cf mul_mi(cf a) { return make_float2(a.y, -a.x); }  // a * (-i)
