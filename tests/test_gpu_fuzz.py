@@ -119,3 +119,43 @@ def test_fuzz_deskew_flatfield_affine_vs_oracle(gpu):
                 assert rel_err(g, w) <= 1e-5, (Z, Y, X, out_shape)
             else:
                 assert (g != w).mean() <= 1e-3, (Z, Y, X, out_shape)  # float64 ties at half-voxel coordinates
+
+
+def test_fuzz_round2_engine_kernels_vs_oracle(gpu):
+    """Random shapes that land on the round-2 kernels — rows of 1024 / 2048 voxels (wave-private X passes), columns of
+    256 / 512 / 1024 points (register-stage column passes) mixed with shorter and 3 * 2^k / 5 * 2^k axes — and random PSFs,
+    some of them point-symmetric with odd extents (real transfer function): R-L, Tikhonov and the inverse filter against the
+    NumPy oracle."""
+    from biahub_amd.apply_inverse_transfer_function import apply_inverse_transfer_function_zyx
+    from biahub_amd.deconvolve import richardson_lucy, richardson_lucy_plan, tikhonov_zyx
+
+    rng = np.random.default_rng(20261004)
+    zs, ys, xs = [4, 8, 16, 24, 40, 64, 256, 512], [32, 64, 96, 160, 512, 1024, 2048], [1024, 2048]
+    forced = [(256, 32, 1024), (512, 32, 1024), (4, 2048, 1024), (8, 1024, 2048), (16, 512, 1024)]  # the column kernels for sure
+    done, real_otf, colw = 0, 0, 0
+    while done < 12:
+        if forced:
+            Z, Y, X = forced.pop()
+        else:
+            Z, Y, X = int(rng.choice(zs)), int(rng.choice(ys)), int(rng.choice(xs))
+        if Z * Y * X > 2**24 or richardson_lucy_plan((1, 1, 1), (Z, Y, X))[1] != "engine":
+            continue
+        done += 1
+        colw += (Z in (256, 512, 1024)) + (Y // 2 in (256, 512, 1024))
+        pshape = tuple(int(min(2 * rng.integers(0, 5) + 1, n)) for n in (Z, Y, X))
+        psfh = (rng.random(pshape) + 0.05).astype(np.float32)
+        if done % 2 == 0:  # point-symmetric: the real-OTF path
+            psfh = (0.5 * (psfh + psfh[::-1, ::-1, ::-1])).astype(np.float32)
+            psfh = np.maximum(psfh, psfh[::-1, ::-1, ::-1])
+            real_otf += int(all(p & 1 for p in pshape))
+        volh = (rng.random((Z, Y, X)) * 300).astype(np.float32)
+        vol, psf = torch.from_numpy(volh).to(gpu), torch.from_numpy(psfh).to(gpu)
+        got = richardson_lucy(vol, psf, 2, 1e-6).cpu().numpy()
+        assert rel_err(got, O.richardson_lucy_zyx(volh, psfh, iterations=2, eps=1e-6)) <= 1e-4, ((Z, Y, X), pshape)
+        tf = O.compute_transfer_function(psfh, (Z, Y, X))
+        got = tikhonov_zyx(vol, torch.from_numpy(tf).to(gpu), 1e-2).cpu().numpy()
+        assert rel_err(got, O.tikhonov_zyx(volh, tf, 1e-2)) <= 1e-4, ((Z, Y, X), pshape)
+        H = (rng.standard_normal((Z, Y, X)) + 1j * rng.standard_normal((Z, Y, X))).astype(np.complex64) * 0.2
+        got = apply_inverse_transfer_function_zyx(vol, H, 0, 1e-2, True).cpu().numpy()
+        assert rel_err(got, O.wo_apply_inverse_transfer_function(volh, H, 0, 1e-2, True)) <= 1e-4, (Z, Y, X)
+    assert real_otf >= 3 and colw >= 3
