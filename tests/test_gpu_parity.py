@@ -162,6 +162,21 @@ def test_tikhonov_vs_oracle(gpu, shape):
     want = O.deconvolve_czyx(czyx, tf, 1e-3)
     assert got.shape == want.shape and got.dtype == np.float32
     assert rel_err(got, want) <= FFT_TOL
+    # the staged filter is kept per transfer-function object: a second call reuses it, an in-place edit or another
+    # regularisation must not
+    from biahub_amd import deconvolve as D
+
+    n0 = len(D._PREPARED)
+    assert rel_err(deconvolve(czyx[:1], transfer_function=tf, regularization_strength=1e-3), want[:1]) <= FFT_TOL
+    assert len(D._PREPARED) == n0
+    assert rel_err(deconvolve(czyx[:1], transfer_function=tf, regularization_strength=1e-2),
+                   O.deconvolve_czyx(czyx[:1], tf, 1e-2)) <= FFT_TOL
+    tf *= 0.5
+    assert rel_err(deconvolve(czyx[:1], transfer_function=tf, regularization_strength=1e-3),
+                   O.deconvolve_czyx(czyx[:1], tf, 1e-3)) <= FFT_TOL
+    assert len(D._PREPARED) <= D._PREPARED_MAX
+    with pytest.raises(ValueError):
+        deconvolve(czyx[:, 1:], transfer_function=tf)
 
 
 @pytest.mark.parametrize("shape,pshape", [((16, 20, 24), (5, 5, 5)), ((15, 21, 25), (7, 5, 3)), ((32, 48, 64), (9, 7, 7))])
