@@ -148,7 +148,26 @@ def ops_suite(vol, psf, dev, ctx):
     th = np.deg2rad(2.0)
     M = np.array([[1.02, 0, 0, 3.5], [0, 1.02 * np.cos(th), -1.02 * np.sin(th), -12.25],
                   [0, 1.02 * np.sin(th), 1.02 * np.cos(th), 20.75], [0, 0, 0, 1.0]])  # 2 deg, 1.02x, fractional shift
-    rec("affine_linear_f32", lambda: affine_device(vol, M, shape, "linear"), _lib.T_AFFINE, 8 * V, "4 (V_in + V_out)")
+    rec("affine_linear_f32", lambda: affine_device(vol, M, shape, "linear"), _lib.T_AFFINE, 8 * V,
+        "4 (V_in + V_out); rotation about z: the wave-private z walk (csrc/affine_zwalk.inc)")
+    ax = np.array([1.0, 0.4, 0.3]) / np.linalg.norm([1.0, 0.4, 0.3])
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    Mo = np.eye(4)
+    Mo[:3, :3] = 1.02 * (np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K)
+    Mo[:3, 3] = (3.5, -12.25, 20.75)
+    rec("affine_linear_f32_oblique", lambda: affine_device(vol, Mo, shape, "linear"), _lib.T_AFFINE, 8 * V,
+        "the same 2 deg / 1.02x similarity about an oblique axis: z couples with y and x, the staged-tile kernel")
+    x = torch.empty_like(vol)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for _ in range(3):
+        ev[0].record()
+        x.copy_(vol)
+        ev[1].record()
+        torch.cuda.synchronize(dev)
+    ms = ev[0].elapsed_time(ev[1])
+    out["copy_f32_reference"] = {"ms": ms, "algorithmic_bytes": 8 * V, "GBps": 8 * V / ms / 1e6, "frac": 8 * V / ms / 1e6 / HBM_PEAK_GBS,
+                                 "note": "torch copy_ of the same volume into a second buffer: the out-of-place streaming rate on this part"}
+    del x
     rec("affine_nearest_f32", lambda: affine_device(vol, M, shape, "nearestneighbor"), _lib.T_AFFINE, 8 * V)
     v16 = vol.to(torch.uint16)
     rec("affine_linear_u16_in", lambda: affine_device(v16, M, shape, "linear"), _lib.T_AFFINE, 6 * V, "2 V_in + 4 V_out")

@@ -23,11 +23,15 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+# textual includes of a translation unit (rebuild triggers)
+INCLUDES = {"fftconv.hip": ("fftconv_xpass.inc", "fftconv_xw.inc", "fftconv_colw.inc"), "affine.hip": ("affine_zwalk.inc",)}
+
+
 def needs_build() -> bool:
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.hpp", CSRC / "fftconv_xpass.inc", CSRC / "fftconv_xw.inc", CSRC / "fftconv_colw.inc", INCLUDE / "bhcore.h"]
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.hpp", INCLUDE / "bhcore.h"] + [CSRC / i for v in INCLUDES.values() for i in v]
     return any(d.stat().st_mtime > t for d in deps)
 
 
@@ -42,10 +46,8 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     def compile_one(src: str) -> Path:
         obj = objdir / (src + ".o")
         srcp = CSRC / src
-        hdr_t = max((CSRC / "common.hpp").stat().st_mtime, (INCLUDE / "bhcore.h").stat().st_mtime,
-                    max((CSRC / "fftconv_xpass.inc").stat().st_mtime, (CSRC / "fftconv_xw.inc").stat().st_mtime,
-                        (CSRC / "fftconv_colw.inc").stat().st_mtime)
-                    if src == "fftconv.hip" else 0.0)
+        hdr_t = max([(CSRC / "common.hpp").stat().st_mtime, (INCLUDE / "bhcore.h").stat().st_mtime]
+                    + [(CSRC / i).stat().st_mtime for i in INCLUDES.get(src, ())])
         if not force and obj.exists() and obj.stat().st_mtime > max(srcp.stat().st_mtime, hdr_t):
             return obj
         cmd = [_hipcc(), *flags, "-c", str(srcp), "-o", str(obj)]

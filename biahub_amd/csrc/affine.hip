@@ -18,7 +18,9 @@
 // MI355X, 512 x 2048 x 2048 f32, 2 deg / 1.02 similarity: 4.6 ms (8 B/voxel algorithmic = 3.7 TB/s).
 #include "common.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace bh {
 
@@ -83,14 +85,16 @@ __device__ __forceinline__ f2 clean2(f2 v) {
 // Trilinear blend of the taps P0 = (z0,y0,x0|x1), P1 = (z0,y1,..), P2 = (z1,y0,..), P3 = (z1,y1,..) with the Q0.32
 // fractions qz, qy, qx: y and z lerps on x-pairs (packed fp32 FMAs), x last.  Explicit fma so that every call site
 // rounds identically.
-__device__ __forceinline__ float lerp8(f2 P0, f2 P1, f2 P2, f2 P3, unsigned qz, unsigned qy, unsigned qx) {
-    const f2 fzy = f2{(float)qz, (float)qy} * 2.3283064365386963e-10f;
-    const float fx = (float)qx * 2.3283064365386963e-10f;
-    const f2 fy = {fzy.y, fzy.y}, fz = {fzy.x, fzy.x};
+__device__ __forceinline__ float lerp8f(f2 P0, f2 P1, f2 P2, f2 P3, float fzf, float fyf, float fx) {
+    const f2 fy = {fyf, fyf}, fz = {fzf, fzf};
     const f2 A0 = __builtin_elementwise_fma(fy, P1 - P0, P0);
     const f2 A1 = __builtin_elementwise_fma(fy, P3 - P2, P2);
     const f2 B = __builtin_elementwise_fma(fz, A1 - A0, A0);
     return __builtin_fmaf(fx, B.y - B.x, B.x);
+}
+__device__ __forceinline__ float lerp8(f2 P0, f2 P1, f2 P2, f2 P3, unsigned qz, unsigned qy, unsigned qx) {
+    const f2 fzy = f2{(float)qz, (float)qy} * 2.3283064365386963e-10f;
+    return lerp8f(P0, P1, P2, P3, fzy.x, fzy.y, (float)qx * 2.3283064365386963e-10f);
 }
 
 constexpr int A_NW = 4, A_NT = 64 * A_NW;  // waves / threads per workgroup
@@ -495,6 +499,8 @@ static int launch_affine(bh_ctx* ctx, const TIN* in, float* out, const AffinePar
 #undef BH_AFF
 }
 
+#include "affine_zwalk.inc"
+
 }  // namespace bh
 
 extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, int64_t Yi, int64_t Xi,
@@ -549,6 +555,15 @@ extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, 
         p.lds_floats = nb < (double)cap ? (int)nb : cap;
     }
     ScopedTimer timer(ctx, T_AFFINE);
+    if (zw::takes(p)) {  // z-separable linear warp: wave-private z walk (affine_zwalk.inc)
+        switch (in_dtype) {
+            case BH_DT_F32: return zw::launch(ctx, (const float*)in, out, p);
+            case BH_DT_U16: return zw::launch(ctx, (const uint16_t*)in, out, p);
+            case BH_DT_U8: return zw::launch(ctx, (const uint8_t*)in, out, p);
+            case BH_DT_I16: return zw::launch(ctx, (const int16_t*)in, out, p);
+            default: BH_REQUIRE(false, "unsupported input dtype code %d", in_dtype);
+        }
+    }
     switch (in_dtype) {
         case BH_DT_F32: return launch_affine(ctx, (const float*)in, out, p);
         case BH_DT_U16: return launch_affine(ctx, (const uint16_t*)in, out, p);

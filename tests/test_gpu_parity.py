@@ -457,6 +457,57 @@ def test_affine_interior_tiles_nonfinite(gpu, X):
     assert np.array_equal(apply_affine_transform(u16, np.eye(4), u16.shape), u16.astype(np.float32))
 
 
+def test_affine_z_walk_equals_staged_tiles(gpu, monkeypatch):
+    """Z-separable linear warps take the wave-private z walk (csrc/affine_zwalk.inc); every voxel must be BIT-identical to
+    the staged-tile kernel's (BH_AFFINE_NOZWALK=1), which the oracle / golden tests above pin: interior and every volume
+    face, both edge rules, crops, ragged extents, every input dtype, z scales from 0 to > 2, NaN / inf taps."""
+    from biahub_amd import _lib
+    from biahub_amd.register import affine_device
+
+    rng = np.random.default_rng(77)
+    vol = rng.random((37, 50, 203), dtype=np.float32) * 1000 - 200
+    vol[20, 24, 100] = np.nan
+    vol[21, 30, 64] = np.inf
+    vol[5, 7, 128] = -np.inf
+    vol[0, 0, 0] = np.inf       # a clamped corner tap
+    vol[36, 49, 202] = np.nan
+
+    def zsep(az, ang, s, t):
+        m = _similarity(ang, s, t)
+        m[0, 0] = az
+        return m
+
+    mats = [np.eye(4), zsep(1.0, 0, 1, (2.5, -7.5, 11.125)), zsep(1.02, 2.0, 1.02, (3.5, -12.25, 20.75)),
+            zsep(0.4, 30.0, 0.7, (1.0, 20.0, -5.0)), zsep(2.6, -5.0, 1.3, (-4.0, 3.0, 6.5)), zsep(0.0, 0.0, 1.0, (7.25, 0.5, -0.5)),
+            zsep(1.0, 90.0, 1.0, (0.0, 0.0, 49.0)), zsep(1.0, 0, 1, (-0.5, -0.5, -0.5)), zsep(1.0, 0, 1, (0.5, 0.5, 0.5)),
+            zsep(1.0, 180.0, 1.0, (0.0, 49.0, 202.0))]
+    cases = [(vol, _lib.DT_F32)]
+    cases.append((rng.integers(0, 60000, vol.shape).astype(np.uint16), None))
+    cases.append(((rng.integers(0, 60000, vol.shape) - 30000).astype(np.int16), None))
+    cases.append((rng.integers(0, 255, vol.shape).astype(np.uint8), None))
+    n_walk = 0
+    for src, _ in cases:
+        t = torch.from_numpy(src).to(gpu)
+        for M in mats:
+            for boundary in (_lib.BOUNDARY_ITK, _lib.BOUNDARY_SCIPY_CONSTANT):
+                for shape, lo, cs in (((37, 50, 203), (0, 0, 0), None), ((41, 57, 130), (3, 5, 66), (30, 46, 63))):
+                    monkeypatch.delenv("BH_AFFINE_NOZWALK", raising=False)
+                    got = affine_device(t, M, shape, "linear", boundary, -3.5, lo, cs)
+                    monkeypatch.setenv("BH_AFFINE_NOZWALK", "1")
+                    want = affine_device(t, M, shape, "linear", boundary, -3.5, lo, cs)
+                    assert torch.isfinite(got).all()
+                    assert torch.equal(got, want), (src.dtype, M.tolist(), boundary, shape)
+                    n_walk += 1
+    monkeypatch.delenv("BH_AFFINE_NOZWALK", raising=False)
+    assert n_walk == 4 * len(mats) * 4
+    # and against the oracle directly on the float volume (the walk is what the registration / stabilisation calls hit)
+    from biahub_amd.register import apply_affine_transform
+
+    for M in mats[:5]:
+        assert np.allclose(apply_affine_transform(vol, M, vol.shape), O.apply_affine_transform(vol, M, vol.shape, "linear"),
+                           rtol=2e-5, atol=2e-3)
+
+
 def test_affine_scipy_mode_golden(gpu):
     from biahub_amd.core.transform import Transform
 

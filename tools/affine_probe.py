@@ -1,4 +1,4 @@
-"""Affine warp alone at the bench shape (for profiling): python tools/affine_probe.py"""
+"""Affine warp alone at the bench shape (for profiling): python tools/affine_probe.py [similarity|identity|shift|oblique ...]"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -11,8 +11,29 @@ ctx = get_context(dev); ctx.set_timing(True)
 shape = (512, 2048, 2048)
 vol = torch.rand(shape, device=dev) * 1000
 th = np.deg2rad(2.0)
-M = np.array([[1.02, 0, 0, 3.5], [0, 1.02 * np.cos(th), -1.02 * np.sin(th), -12.25], [0, 1.02 * np.sin(th), 1.02 * np.cos(th), 20.75], [0, 0, 0, 1.0]])
-for interp in ("linear", "nearestneighbor"):
-    for _ in range(4):
-        out = affine_device(vol, M, shape, interp); ms = ctx.elapsed_ms(_lib.T_AFFINE)
-    print(interp, f"{ms:.3f} ms")
+c, s = np.cos(th), np.sin(th)
+MATS = {
+    "similarity": np.array([[1.02, 0, 0, 3.5], [0, 1.02 * c, -1.02 * s, -12.25], [0, 1.02 * s, 1.02 * c, 20.75], [0, 0, 0, 1.0]]),
+    "identity": np.eye(4),
+    "shift": np.array([[1, 0, 0, 2.25], [0, 1, 0, -7.5], [0, 0, 1, 11.125], [0, 0, 0, 1.0]]),
+    # the same 2 deg / 1.02x similarity about an oblique axis (z couples with y and x: the staged-tile kernel)
+    "oblique": None,
+}
+ax = np.array([1.0, 0.4, 0.3]); ax /= np.linalg.norm(ax)
+K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+Rm = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+ob = np.eye(4); ob[:3, :3] = 1.02 * Rm; ob[:3, 3] = (3.5, -12.25, 20.75)
+MATS["oblique"] = ob
+names = [a for a in sys.argv[1:] if a in MATS] or ["similarity"]
+for name in names:
+    for interp in ("linear", "nearestneighbor"):
+        if interp != "linear" and name != "similarity":
+            continue
+        for _ in range(4):
+            out = affine_device(vol, MATS[name], shape, interp); ms = ctx.elapsed_ms(_lib.T_AFFINE)
+        print(name, interp, f"{ms:.3f} ms")
+x = torch.empty_like(vol)
+for _ in range(3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); x.copy_(vol); e1.record(); torch.cuda.synchronize()
+print(f"torch copy_ {e0.elapsed_time(e1):.3f} ms")
