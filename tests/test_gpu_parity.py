@@ -458,7 +458,7 @@ def test_affine_interior_tiles_nonfinite(gpu, X):
 
 
 def test_affine_z_walk_equals_staged_tiles(gpu, monkeypatch):
-    """Z-separable linear warps take the wave-private z walk (csrc/affine_zwalk.inc); every voxel must be BIT-identical to
+    """Z-separable warps (linear and nearest) take the wave-private z walk (csrc/affine_zwalk.inc); every voxel must be BIT-identical to
     the staged-tile kernel's (BH_AFFINE_NOZWALK=1), which the oracle / golden tests above pin: interior and every volume
     face, both edge rules, crops, ragged extents, every input dtype, z scales from 0 to > 2, NaN / inf taps."""
     from biahub_amd import _lib
@@ -491,15 +491,16 @@ def test_affine_z_walk_equals_staged_tiles(gpu, monkeypatch):
         for M in mats:
             for boundary in (_lib.BOUNDARY_ITK, _lib.BOUNDARY_SCIPY_CONSTANT):
                 for shape, lo, cs in (((37, 50, 203), (0, 0, 0), None), ((41, 57, 130), (3, 5, 66), (30, 46, 63))):
-                    monkeypatch.delenv("BH_AFFINE_NOZWALK", raising=False)
-                    got = affine_device(t, M, shape, "linear", boundary, -3.5, lo, cs)
-                    monkeypatch.setenv("BH_AFFINE_NOZWALK", "1")
-                    want = affine_device(t, M, shape, "linear", boundary, -3.5, lo, cs)
-                    assert torch.isfinite(got).all()
-                    assert torch.equal(got, want), (src.dtype, M.tolist(), boundary, shape)
-                    n_walk += 1
+                    for interp in ("linear", "nearestneighbor"):
+                        monkeypatch.delenv("BH_AFFINE_NOZWALK", raising=False)
+                        got = affine_device(t, M, shape, interp, boundary, -3.5, lo, cs)
+                        monkeypatch.setenv("BH_AFFINE_NOZWALK", "1")
+                        want = affine_device(t, M, shape, interp, boundary, -3.5, lo, cs)
+                        assert torch.isfinite(got).all()
+                        assert torch.equal(got, want), (src.dtype, M.tolist(), boundary, shape, interp)
+                        n_walk += 1
     monkeypatch.delenv("BH_AFFINE_NOZWALK", raising=False)
-    assert n_walk == 4 * len(mats) * 4
+    assert n_walk == 4 * len(mats) * 4 * 2
     # and against the oracle directly on the float volume (the walk is what the registration / stabilisation calls hit)
     from biahub_amd.register import apply_affine_transform
 
