@@ -39,6 +39,7 @@ struct AffineParams {
     int lds_floats;  // staging capacity of this launch (dynamic LDS), <= A_LDS_FLOATS[_X8]
     int x4;          // float32 rows are 16-B aligned: stage with 16-B LDS-DMA, box x range rounded out to 4 floats
     int x8;          // 16-bit rows are 16-B aligned: stage 8 samples per lane (one 16-B load), x range rounded out to 8
+    int zslot;       // z walk: bytes of one plane slot of a wave's LDS ring (0: planes travel through registers)
 };
 
 template <typename T>
@@ -553,6 +554,14 @@ extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, 
         }
         const int cap = p.x8 ? A_LDS_FLOATS_X8 : A_LDS_FLOATS;
         p.lds_floats = nb < (double)cap ? (int)nb : cap;
+    }
+    p.zslot = 0;
+    if (p.x4 && getenv("BH_ZW_NOLDS") == nullptr) {
+        // the largest source box of a wave's 64 x RY outputs (as for lds_floats above), whole 16-B quads; 4 KiB at most
+        const double ey = std::floor((std::fabs(matrix[5]) * (zw::RY - 1) + std::fabs(matrix[6]) * 63.0) * (1.0 + 1e-6)) + 3.0;
+        const double ex = std::floor((std::fabs(matrix[9]) * (zw::RY - 1) + std::fabs(matrix[10]) * 63.0) * (1.0 + 1e-6)) + 3.0;
+        const double bytes = ey * (std::floor((ex + 6.0) / 4.0) * 4.0) * 4.0;
+        if (bytes <= 4096.0) p.zslot = ((int)bytes + 15) & ~15;
     }
     ScopedTimer timer(ctx, T_AFFINE);
     if (zw::takes(p)) {  // z-separable linear warp: wave-private z walk (affine_zwalk.inc)

@@ -481,7 +481,10 @@ def test_affine_z_walk_equals_staged_tiles(gpu, monkeypatch):
             zsep(0.4, 30.0, 0.7, (1.0, 20.0, -5.0)), zsep(2.6, -5.0, 1.3, (-4.0, 3.0, 6.5)), zsep(0.0, 0.0, 1.0, (7.25, 0.5, -0.5)),
             zsep(1.0, 90.0, 1.0, (0.0, 0.0, 49.0)), zsep(1.0, 0, 1, (-0.5, -0.5, -0.5)), zsep(1.0, 0, 1, (0.5, 0.5, 0.5)),
             zsep(1.0, 180.0, 1.0, (0.0, 49.0, 202.0))]
-    cases = [(vol, _lib.DT_F32)]
+    vol4 = rng.random((21, 70, 264), dtype=np.float32) * 1000 - 200   # 16-B aligned rows: interior waves take the LDS-DMA ring
+    vol4[10, 35, 130] = np.nan
+    vol4[11, 36, 131] = -np.inf
+    cases = [(vol, _lib.DT_F32), (vol4, None)]
     cases.append((rng.integers(0, 60000, vol.shape).astype(np.uint16), None))
     cases.append(((rng.integers(0, 60000, vol.shape) - 30000).astype(np.int16), None))
     cases.append((rng.integers(0, 255, vol.shape).astype(np.uint8), None))
@@ -500,7 +503,7 @@ def test_affine_z_walk_equals_staged_tiles(gpu, monkeypatch):
                         assert torch.equal(got, want), (src.dtype, M.tolist(), boundary, shape, interp)
                         n_walk += 1
     monkeypatch.delenv("BH_AFFINE_NOZWALK", raising=False)
-    assert n_walk == 4 * len(mats) * 4 * 2
+    assert n_walk == 5 * len(mats) * 4 * 2
     # and against the oracle directly on the float volume (the walk is what the registration / stabilisation calls hit)
     from biahub_amd.register import apply_affine_transform
 
