@@ -488,6 +488,8 @@ def test_affine_z_walk_equals_staged_tiles(gpu, monkeypatch):
     cases.append((rng.integers(0, 60000, vol.shape).astype(np.uint16), None))
     cases.append(((rng.integers(0, 60000, vol.shape) - 30000).astype(np.int16), None))
     cases.append((rng.integers(0, 255, vol.shape).astype(np.uint8), None))
+    cases.append((rng.integers(0, 60000, vol4.shape).astype(np.uint16), None))             # 16-B aligned 16-bit rows: LDS-DMA ring
+    cases.append(((rng.integers(0, 60000, vol4.shape) - 30000).astype(np.int16), None))
     n_walk = 0
     for src, _ in cases:
         t = torch.from_numpy(src).to(gpu)
@@ -503,7 +505,7 @@ def test_affine_z_walk_equals_staged_tiles(gpu, monkeypatch):
                         assert torch.equal(got, want), (src.dtype, M.tolist(), boundary, shape, interp)
                         n_walk += 1
     monkeypatch.delenv("BH_AFFINE_NOZWALK", raising=False)
-    assert n_walk == 5 * len(mats) * 4 * 2
+    assert n_walk == 7 * len(mats) * 4 * 2
     # and against the oracle directly on the float volume (the walk is what the registration / stabilisation calls hit)
     from biahub_amd.register import apply_affine_transform
 
