@@ -195,7 +195,7 @@ def ops_suite(vol, psf, dev, ctx):
     ms = (time.perf_counter() - t0) / 3 * 1e3
     assert tuple(float(v) for v in sh) == (-1.0, 3.0, -17.0), sh
     out["phase_cross_corr"] = {"ms": ms, "algorithmic_bytes": 80 * V, "GBps": 80 * V / ms / 1e6, "frac": 80 * V / ms / 1e6 / HBM_PEAK_GBS,
-                               "note": "wall clock incl. the argmax read-back; 3 FFTs (72 V) + product (8 V)"}
+                               "note": "wall clock incl. the argmax read-back; 3 FFTs (72 V) + product (8 V) by the model; the product runs inside the Z pass of the second transform"}
     del mov
     ctx.release_workspace()
     return out

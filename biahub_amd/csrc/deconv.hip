@@ -460,6 +460,7 @@ int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, const float* es
                                 cf* spec, float eps, float* corr_p);
 int fftconv_forward(bh_ctx* ctx, const ConvPlan& pl, const float* in, cf* spec);
 int fftconv_inverse(bh_ctx* ctx, const ConvPlan& pl, cf* spec, float* out);
+int fftconv_pcc(bh_ctx* ctx, const ConvPlan& pl, const float* ref, const float* mov, cf* s1, cf* s2, int norm, float scale, float* corr);
 int fftconv_tikhonov(bh_ctx* ctx, const ConvPlan& pl, const float* in, const float* tf_full, float reg, cf* spec,
                      float* filt, float* out);
 
@@ -824,12 +825,16 @@ int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t
         const size_t NSf = fftconv_spectrum_elems(*cp);
         BH_TRY(get_scratch(ctx, "fc_spec", NSf * sizeof(cf), (void**)&s1));
         BH_TRY(get_scratch(ctx, "pcc_spec2", NSf * sizeof(cf), (void**)&s2));
-        BH_TRY(fftconv_forward(ctx, *cp, ref, s1));
-        BH_TRY(fftconv_forward(ctx, *cp, mov, s2));
-        const int64_t nprod = (int64_t)NSf - 64;  // Z * Y * XP stored coefficients (pad columns are zero), not the tail slack
-        hipLaunchKernelGGL(pcc_product_kernel, grid_for(ctx, nprod), dim3(256), 0, s, s1, s2, nprod, normalization,
-                           (float)(2.0 / (double)V));
-        BH_TRY(fftconv_inverse(ctx, *cp, s1, corr));
+        if (getenv("BH_PCC_UNFUSED")) {  // A/B switch: the product as its own pass between whole transforms
+            BH_TRY(fftconv_forward(ctx, *cp, ref, s1));
+            BH_TRY(fftconv_forward(ctx, *cp, mov, s2));
+            const int64_t nprod = (int64_t)NSf - 64;  // Z * Y * XP stored coefficients (pad columns are zero), not the tail slack
+            hipLaunchKernelGGL(pcc_product_kernel, grid_for(ctx, nprod), dim3(256), 0, s, s1, s2, nprod, normalization,
+                               (float)(2.0 / (double)V));
+            BH_TRY(fftconv_inverse(ctx, *cp, s1, corr));
+        } else {
+            BH_TRY(fftconv_pcc(ctx, *cp, ref, mov, s1, s2, normalization, (float)(2.0 / (double)V), corr));
+        }
     } else {
         FftPlans *pl, *plc;
         BH_TRY(get_plans(ctx, Z, Y, X, &pl));

@@ -504,7 +504,21 @@ struct ConvDims {
 // Column passes (Y: two length-Y/2 halves per z; Z: fused forward x OTF x inverse)
 // ================================================================================================
 // COL_CONV16: COL_CONV with the multiplier stored as bfloat16 pairs (4 B per complex bin, widened in registers, f32 products)
-enum ColMode { COL_FWD = 0, COL_INV = 1, COL_FWD_SCALE = 2, COL_CONV = 3, COL_CORR = 4, COL_FILTER = 5, COL_CONV16 = 6 };
+// COL_PCC: the phase cross-correlation product in the Z pass — tile <- otf * conj(tile) / norm * scale between the forward and
+// the inverse transform (otf = the reference image's finished spectrum; norm per ColParams::pcc_norm)
+enum ColMode { COL_FWD = 0, COL_INV = 1, COL_FWD_SCALE = 2, COL_CONV = 3, COL_CORR = 4, COL_FILTER = 5, COL_CONV16 = 6, COL_PCC = 7 };
+
+// one bin of the phase cross-correlation product (estimate_stabilization.py:233-238): a * conj(b) / norm * scale
+__device__ __forceinline__ float2 pcc_bin(float2 a, float2 b, int mode, float scale) {
+    const float eps = 1.1920929e-07f;  // np.finfo(complex64).eps
+    float2 p = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+    float nrm = 1.0f;
+    if (mode == BH_PCC_NORM_MAGNITUDE) nrm = fmaxf(hypotf(p.x, p.y), eps);
+    if (mode == BH_PCC_NORM_CLASSIC) nrm = hypotf(a.x, a.y) * hypotf(b.x, b.y);
+    p.x = (p.x / nrm) * scale;
+    p.y = (p.y / nrm) * scale;
+    return p;
+}
 
 struct ColParams {
     cf* S;
@@ -523,6 +537,7 @@ struct ColParams {
     int ncoltiles;
     float scale;
     int midfuse;        // fuse the unit-twiddle steps around the spectral product (BH_FC_NOZMID=1 turns it off)
+    int pcc_norm;       // COL_PCC: BH_PCC_NORM_* of the product (`scale` multiplies it)
 };
 
 // The prefetch registers are sixteen named float4, of which ROUNDS are used (not an array: hipcc keeps a loop-carried
@@ -566,12 +581,13 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
     const int lane = tid % LPS;
     const int r0 = tid / LPS;
     const long ntiles = (long)p.nouter * p.ncoltiles;
-    constexpr bool HAS_OTF = (MODE == COL_CONV || MODE == COL_CORR || MODE == COL_FILTER || MODE == COL_CONV16);
+    constexpr bool HAS_OTF = (MODE == COL_CONV || MODE == COL_CORR || MODE == COL_FILTER || MODE == COL_CONV16 || MODE == COL_PCC);
     const int ncoltiles = p.ncoltiles, nsub = p.nsub, W_ = p.W, N_ = p.N, logN = p.logN, logW = p.logW, XP = p.XP;
     const long outer_stride = p.outer_stride, sub_stride = p.sub_stride, row_stride = p.row_stride;
     cf* const S = p.S;
     const cf* const otf = p.otf;
     const float scale = p.scale;
+    const int pcc_norm = p.pcc_norm;
     auto tile_base = [=](long tt) -> long {
         const long ou = tt / ncoltiles;
         const int ct = (int)(tt - ou * ncoltiles);
@@ -626,6 +642,10 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
             c.y = a.y * b.y;                                                                    \
             c.z = a.z * b.z;                                                                    \
             c.w = a.w * b.w;                                                                    \
+        } else if (MODE == COL_PCC) { /* b (reference) * conj(a) / norm * scale, as pcc_product_kernel */ \
+            const float2 p0 = pcc_bin(make_float2(b.x, b.y), make_float2(a.x, a.y), pcc_norm, scale);  \
+            const float2 p1 = pcc_bin(make_float2(b.z, b.w), make_float2(a.z, a.w), pcc_norm, scale);  \
+            c = make_float4(p0.x, p0.y, p1.x, p1.y);                                            \
         } else if (MODE == COL_CONV || MODE == COL_CONV16) {                                    \
             c.x = a.x * b.x - a.y * b.y;                                                        \
             c.y = a.x * b.y + a.y * b.x;                                                        \
@@ -660,7 +680,7 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
         const bool col_ok = (ct * W_ + 2 * lane) < XP;  // pad columns of a ragged last tile are never stored
         __syncthreads();
         const long tn = t + gridDim.x;
-        if (HAS_OTF && !FC_R16 && p.midfuse) {
+        if (HAS_OTF && MODE != COL_PCC && !FC_R16 && p.midfuse) {
             // This tile's OTF arrives behind the forward FFT, fetched in the order the fused middle step wants it:
             // butterfly b = tid / LPS + s * RPR (s = 0, 1) covers rows 4b .. 4b + 3 of this lane's two columns.
             // The h = 2 radix-4 steps at the end of the forward and the start of the inverse transform have unit
@@ -992,8 +1012,9 @@ static int launch_colw(bh_ctx* ctx, ColParams p, int mode) {
     }
 }
 
-static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf* S, const cf* otf, float scale) {
+static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf* S, const cf* otf, float scale, int pcc_norm = 0) {
     ColParams p;
+    p.pcc_norm = pcc_norm;
     p.S = S;
     p.otf = otf;
     p.XP = pl.d.XP;
@@ -1034,7 +1055,7 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
     const int colw_mode = getenv("BH_FC_COLW") ? atoi(getenv("BH_FC_COLW")) : 4;
     const bool colw_axis = colw_mode == 1 || (colw_mode == 2 && !zaxis) || (colw_mode == 3 && zaxis) ||
                            (colw_mode == 4 && (!zaxis || p.N == 256));
-    if (colw_tab && (long)p.N * p.row_stride < (1l << 31) && colw_axis) {
+    if (colw_tab && (long)p.N * p.row_stride < (1l << 31) && colw_axis && mode != COL_PCC) {
         p.tw = colw_tab;
         return p.N == 1024 ? launch_colw<10>(ctx, p, mode) : (p.N == 512 ? launch_colw<9>(ctx, p, mode) : launch_colw<8>(ctx, p, mode));
     }
@@ -1063,6 +1084,7 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
         case COL_CONV: return run(col_pass_kernel<COL_CONV, R, RDX>);      \
         case COL_FILTER: return run(col_pass_kernel<COL_FILTER, R, RDX>);  \
         case COL_CONV16: return run(col_pass_kernel<COL_CONV16, R, RDX>);  \
+        case COL_PCC: return run(col_pass_kernel<COL_PCC, R, RDX>);        \
         default: return run(col_pass_kernel<COL_CORR, R, RDX>);            \
     }
 #define BH_COL_DISPATCH(R)                                 \
@@ -1397,6 +1419,19 @@ int fftconv_inverse(bh_ctx* ctx, const ConvPlan& pl, cf* spec, float* out) {
     BH_TRY(launch_col(ctx, pl, COL_INV, true, spec, nullptr, 1.f));
     BH_TRY(launch_col(ctx, pl, COL_INV, false, spec, nullptr, 1.f));
     BH_TRY(launch_x(ctx, pl, true, XE_STORE, nullptr, spec, out, nullptr, 0.f));
+    return BH_OK;
+}
+
+// corr = irfft( rfft(ref) * conj(rfft(mov)) / norm ) with the product inside the Z pass of `mov`'s transform: 7 passes for the two
+// forward transforms, the product and the inverse transform instead of 10 (spectrum layout and scaling as fftconv_forward /
+// fftconv_inverse: scale = 2 / V)
+int fftconv_pcc(bh_ctx* ctx, const ConvPlan& pl, const float* ref, const float* mov, cf* s1, cf* s2, int norm, float scale, float* corr) {
+    BH_TRY(fftconv_forward(ctx, pl, ref, s1));
+    BH_TRY(launch_x(ctx, pl, false, 0, mov, s2, nullptr, nullptr, 0.f));
+    BH_TRY(launch_col(ctx, pl, COL_FWD, false, s2, nullptr, 1.f));
+    BH_TRY(launch_col(ctx, pl, COL_PCC, true, s2, s1, scale, norm));
+    BH_TRY(launch_col(ctx, pl, COL_INV, false, s2, nullptr, 1.f));
+    BH_TRY(launch_x(ctx, pl, true, XE_STORE, nullptr, s2, corr, nullptr, 0.f));
     return BH_OK;
 }
 
