@@ -815,6 +815,7 @@ struct ConvPlan {
     int* xw_col = nullptr;
     // register-stage column passes (fftconv_colw.inc) for columns of 256 / 512 / 1024 points: their twiddle tables
     cf *colw_y = nullptr, *colw_z = nullptr;
+    cf* colz = nullptr;  // radix-8 register-stage Z pass of 512-point columns (fftconv_colz.inc)
 };
 
 // The X passes exist for two tile heights: 16 rows (M = X/2 up to 1024) and 8 rows (M up to 1536: a 3072-voxel row, for which
@@ -836,6 +837,7 @@ namespace xr8 {
 
 #include "fftconv_xw.inc"
 #include "fftconv_colw.inc"
+#include "fftconv_colz.inc"
 
 // ================================================================================================
 // host side
@@ -968,6 +970,10 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     };
     BH_TRY(colw_tables(Y / 2, &pl.colw_y));
     BH_TRY(colw_tables(Z, &pl.colw_z));
+    if (Z == colz::N && pl.d.XP >= colz::W) {
+        colz::make_tables(h);
+        BH_TRY(upload(h, &pl.colz));
+    }
     if (xw_on) {
         std::vector<int> col;
         if (X == 2048) xw::make_tables<10>(h, col); else xw::make_tables<9>(h, col);
@@ -1045,6 +1051,29 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
         p.sub_stride = 0;
         p.nsub = 1;
         p.nouter = pl.d.Y;
+    }
+    // 512-point Z passes with a spectral product: radix-8 register stages (BH_FC_COLZ=0 keeps the radix-4 LDS steps: A/B switch)
+    if (zaxis && pl.colz && p.N == colz::N && (mode == COL_CONV || mode == COL_CORR || mode == COL_FILTER || mode == COL_CONV16 || mode == COL_PCC) &&
+        !(getenv("BH_FC_COLZ") && atoi(getenv("BH_FC_COLZ")) == 0)) {
+        p.W = colz::W;
+        p.tw = pl.colz;
+        p.ncoltiles = (int)ceil_div(p.XP, p.W);
+        const long ntiles = (long)p.nouter * p.ncoltiles;
+        const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
+        auto run = [&](auto kern) -> int {
+            BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)colz::LDS_BYTES));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(colz::NT), colz::LDS_BYTES, ctx->stream, p);
+            BH_CHECK_HIP(hipGetLastError());
+            return BH_OK;
+        };
+        switch (mode) {
+            case COL_CONV: return run(colz::colz_kernel<COL_CONV>);
+            case COL_CORR: return run(colz::colz_kernel<COL_CORR>);
+            case COL_FILTER: return run(colz::colz_kernel<COL_FILTER>);
+            case COL_CONV16: return run(colz::colz_kernel<COL_CONV16>);
+            default: return run(colz::colz_kernel<COL_PCC>);
+        }
     }
     // columns of 256 / 512 / 1024 points: the register-stage kernels (BH_FC_COLW=0 keeps the LDS-stepped ones: A/B switch)
     const cf* colw_tab = zaxis ? pl.colw_z : pl.colw_y;

@@ -1396,6 +1396,53 @@ def test_register_stage_column_passes(gpu, shape, pshape, monkeypatch):
     assert tuple(float(s) for s in shift) == (-1.0, 5.0, -9.0)
 
 
+@pytest.mark.parametrize("shape,pshape", [((512, 32, 64), (7, 3, 5)), ((512, 64, 192), (9, 5, 5))])
+def test_radix8_z_pass(gpu, shape, pshape, monkeypatch):
+    """512-point Z passes with a spectral product run radix-8 register stages (csrc/fftconv_colz.inc: four LDS round trips).
+    Every mode — real transfer function (symmetric PSF, Tikhonov), complex convolution / correlation (asymmetric PSF), the
+    complex inverse filter in float32 and bfloat16, the phase-correlation product — agrees with the oracle and with the radix-4
+    kernel (BH_FC_COLZ=0) on the same inputs, including a ragged last column tile."""
+    from biahub_amd.apply_inverse_transfer_function import apply_inverse_transfer_function_zyx
+    from biahub_amd.deconvolve import compute_tranfser_function, deconvolve, richardson_lucy
+    from biahub_amd.estimate_stabilization import phase_cross_corr
+
+    vol = O.synthetic_volume(shape, seed=57, n_blobs=16)
+    vol[3, :, :] += 250.0
+    v = torch.from_numpy(vol).to(gpu)
+    sym = O.gaussian_psf(pshape, tuple(max(q / 4.0, 0.8) for q in pshape))
+    asym = sym.copy()
+    asym[0, 0, 0] += 0.02
+    rng = np.random.default_rng(5)
+    tfc = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64) * 0.3 + 1.0
+    mov = np.roll(vol, (2, -3, 7), axis=(0, 1, 2))
+
+    def run():
+        out = {}
+        for name, psf in (("rl_real", sym), ("rl_complex", asym)):
+            out[name] = richardson_lucy(v, torch.from_numpy(psf).to(gpu), 3, 1e-6).cpu().numpy()
+        tf = compute_tranfser_function(sym, shape)
+        out["tikhonov"] = deconvolve(vol[None], transfer_function=tf.copy(), regularization_strength=1e-2)[0]
+        out["inv_f32"] = apply_inverse_transfer_function_zyx(v, tfc, 0, 1e-2, False, "f32").cpu().numpy()
+        out["inv_bf16"] = apply_inverse_transfer_function_zyx(v, tfc, 0, 1e-2, False, "bf16").cpu().numpy()
+        for norm in (None, "magnitude"):
+            sh, corr = phase_cross_corr(vol, mov, normalization=norm)
+            assert tuple(float(x) for x in sh) == (-2.0, 3.0, -7.0)
+            out[f"pcc_{norm}"] = corr
+        return out
+
+    monkeypatch.delenv("BH_FC_COLZ", raising=False)
+    new = run()
+    monkeypatch.setenv("BH_FC_COLZ", "0")
+    old = run()
+    monkeypatch.delenv("BH_FC_COLZ", raising=False)
+    for k in new:
+        assert rel_err(new[k], old[k]) <= 2e-5, (k, rel_err(new[k], old[k]))
+    assert rel_err(new["rl_real"], O.richardson_lucy_zyx(vol, sym, iterations=3, eps=1e-6)) <= FFT_TOL
+    assert rel_err(new["rl_complex"], O.richardson_lucy_zyx(vol, asym, iterations=3, eps=1e-6)) <= FFT_TOL
+    assert rel_err(new["tikhonov"], O.deconvolve_czyx(vol[None], compute_tranfser_function(sym, shape), 1e-2)[0]) <= FFT_TOL
+    assert rel_err(new["pcc_magnitude"], O.phase_cross_corr(vol, mov, "magnitude")[1]) <= 1e-3
+
+
 @pytest.mark.parametrize("shape,pshape", [((32, 64, 128), (9, 7, 5)), ((256, 64, 1024), (5, 5, 9))])
 def test_richardson_lucy_real_otf_of_symmetric_psf(gpu, shape, pshape, monkeypatch):
     """A PSF with odd extents that equals its point mirror has a real transfer function: the Z passes then read one float
