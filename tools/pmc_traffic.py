@@ -50,7 +50,7 @@ def per_iteration(sub):
 
 n_it = rows[[k for k in rows if "xw_kernel<10, 4>" in k][0]][0]  # one fused-ratio launch per iteration
 it = moved("xw_kernel<10, 4>") + moved("xw_kernel<10, 5>")
-col = {k: v for k, v in rows.items() if "col_pass_kernel<" in k or "colw_kernel<" in k}
+col = {k: v for k, v in rows.items() if "col_pass_kernel<" in k or "colw_kernel<" in k or "colz_kernel<" in k}
 for k, v in col.items():
     per_it = round(v[0] / n_it)          # launches of this kernel per iteration (the OTF build adds a stray call or two)
     it += per_it * (v[1] + v[2]) * 1e9
