@@ -556,11 +556,12 @@ extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, 
         p.lds_floats = nb < (double)cap ? (int)nb : cap;
     }
     p.zslot = 0;
-    if (p.x4 && getenv("BH_ZW_NOLDS") == nullptr) {
+    if ((p.x4 || p.x8) && getenv("BH_ZW_NOLDS") == nullptr) {
         // the largest source box of a wave's 64 x RY outputs (as for lds_floats above), whole 16-B quads; 4 KiB at most
+        const double E = p.x4 ? 4.0 : 8.0, size = p.x4 ? 4.0 : 2.0;
         const double ey = std::floor((std::fabs(matrix[5]) * (zw::RY - 1) + std::fabs(matrix[6]) * 63.0) * (1.0 + 1e-6)) + 3.0;
         const double ex = std::floor((std::fabs(matrix[9]) * (zw::RY - 1) + std::fabs(matrix[10]) * 63.0) * (1.0 + 1e-6)) + 3.0;
-        const double bytes = ey * (std::floor((ex + 6.0) / 4.0) * 4.0) * 4.0;
+        const double bytes = ey * (std::floor((ex + 2.0 * (E - 1.0)) / E) * E) * size;
         if (bytes <= 4096.0) p.zslot = ((int)bytes + 15) & ~15;
     }
     ScopedTimer timer(ctx, T_AFFINE);
