@@ -95,6 +95,7 @@ struct bh_ctx {
     bool otf_valid = false;
     unsigned long long otf_hash = 0;
     int otf_tag = 0;  // spectrum layout of the plan that built it (fftconv_plan_tag)
+    void* spec_tuned = nullptr;  // the "fc_spec" allocation fftconv_tune_spectrum chose (or accepted) for this context
     int64_t otf_dims[6] = {0, 0, 0, 0, 0, 0};
 };
 

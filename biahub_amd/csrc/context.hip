@@ -1,6 +1,9 @@
 // Context, error string, workspace and hipFFT plan cache of libbhcore.
 #include "common.hpp"
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <cstring>
 
 namespace bh {
@@ -25,6 +28,8 @@ int get_scratch(bh_ctx* ctx, const char* name, size_t bytes, void** out) {
         }
         BH_CHECK_HIP(hipMalloc(&s.ptr, bytes));
         s.bytes = bytes;
+        if (std::strcmp(name, "fc_spec") == 0) ctx->spec_tuned = nullptr;  // new pages: fftconv_tune_spectrum auditions them
+        if (getenv("BH_DEBUG_SCRATCH")) fprintf(stderr, "[bh scratch] %-14s %p  %zu bytes\n", name, s.ptr, bytes);
     }
     *out = s.ptr;
     return BH_OK;
@@ -225,6 +230,7 @@ int bh_ctx_release_workspace(bh_ctx* ctx) {
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     ctx->scratch.clear();
     ctx->otf_valid = false;
+    ctx->spec_tuned = nullptr;
     return BH_OK;
 }
 

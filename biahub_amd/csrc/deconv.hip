@@ -460,6 +460,7 @@ int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, const float* es
                                 cf* spec, float eps, float* corr_p);
 int fftconv_forward(bh_ctx* ctx, const ConvPlan& pl, const float* in, cf* spec);
 int fftconv_inverse(bh_ctx* ctx, const ConvPlan& pl, cf* spec, float* out);
+int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t bytes, cf** spec);
 int fftconv_pcc(bh_ctx* ctx, const ConvPlan& pl, const float* ref, const float* mov, cf* s1, cf* s2, int norm, float scale, float* corr);
 int fftconv_tikhonov(bh_ctx* ctx, const ConvPlan& pl, const float* in, const float* tf_full, float reg, cf* spec,
                      float* filt, float* out);
@@ -541,6 +542,12 @@ static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, 
     cf *spec, *otf;
     double* psum;
     BH_TRY(get_scratch(ctx, "fc_spec", NS * sizeof(cf), (void**)&spec));
+    if (spec != ctx->spec_tuned && iterations > 0) {  // a new allocation: audition it (fftconv_tune_spectrum)
+        Scratch& sc = ctx->scratch["fc_spec"];
+        BH_TRY(fftconv_tune_spectrum(ctx, *pl, out, sc.bytes, &spec));
+        sc.ptr = spec;
+        ctx->spec_tuned = spec;
+    }
     BH_TRY(get_scratch(ctx, "fc_otf", NS * sizeof(cf), (void**)&otf));
     BH_TRY(get_scratch(ctx, "rl_psum", 64, (void**)&psum));
     hipStream_t s = ctx->stream;

@@ -20,6 +20,8 @@
 // registers prefetch tile t+1 from HBM while the FFT of tile t runs out of LDS.
 #include "common.hpp"
 
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 
 #include <cmath>
@@ -1412,6 +1414,56 @@ int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, con
         BH_TRY(launch_x(ctx, pl, true, XE_UPDATE, nullptr, spec, est, est, eps, it + 1 < iterations));
     }
     return BH_OK;
+}
+
+// Where the driver puts the spectrum matters to ONE kernel: the fused update X pass (S read and written, the estimate read and
+// written: four streams) takes 6.0 to 7.1 ms depending on the physical pages behind `spec` — the same virtual address
+// re-allocated gives 35.0 to 36.2 ms per iteration at config 2, offsets inside one allocation give the same time to
+// +-0.05 ms, every other kernel is indifferent (tools/ctx_probe.py).  So a new spectrum allocation of a large
+// volume is auditioned once: the pass is timed on it and on up to two more allocations held at the same time, and the fastest
+// stays (40-60 ms and 17 GB of transient memory once per context and shape; BH_FC_TUNE_ALLOC=0 skips it).
+// `est` is any V-float buffer the caller is about to overwrite (the pass reads and writes it), `bytes` the allocation size.
+int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t bytes, cf** spec) {
+    const double V = (double)pl.d.Z * pl.d.Y * pl.d.X;
+    if (!pl.xw || V < (double)(1u << 28) || (getenv("BH_FC_TUNE_ALLOC") && atoi(getenv("BH_FC_TUNE_ALLOC")) == 0)) return BH_OK;
+    hipEvent_t e0, e1;
+    BH_CHECK_HIP(hipEventCreate(&e0));
+    BH_CHECK_HIP(hipEventCreate(&e1));
+    auto audition = [&](cf* s, float* ms) -> int {
+        for (int rep = 0; rep < 2; ++rep) {  // the second launch is the measurement
+            BH_CHECK_HIP(hipEventRecord(e0, ctx->stream));
+            BH_TRY(launch_x(ctx, pl, true, XE_UPDATE, nullptr, s, est, est, 1e-6f, true));
+            BH_CHECK_HIP(hipEventRecord(e1, ctx->stream));
+            BH_CHECK_HIP(hipEventSynchronize(e1));
+            BH_CHECK_HIP(hipEventElapsedTime(ms, e0, e1));
+        }
+        return BH_OK;
+    };
+    cf* cand[3] = {*spec, nullptr, nullptr};
+    float ms[3] = {0.f, 0.f, 0.f};
+    int n = 1, best = 0, rc = audition(cand[0], &ms[0]);
+    for (; rc == BH_OK && n < 3; ++n) {
+        if (hipMalloc((void**)&cand[n], bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            cand[n] = nullptr;
+            break;
+        }
+        rc = audition(cand[n], &ms[n]);
+        if (rc != BH_OK) {
+            ++n;
+            break;
+        }
+    }
+    for (int i = 1; i < n; ++i)
+        if (cand[i] && ms[i] < ms[best]) best = i;
+    if (getenv("BH_DEBUG_SCRATCH"))
+        fprintf(stderr, "[bh tune] fused update pass on %d spectrum allocation(s): %.3f %.3f %.3f ms -> #%d\n", n, ms[0], ms[1], ms[2], best);
+    for (int i = 0; i < n; ++i)
+        if (i != best && cand[i]) (void)hipFree(cand[i]);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *spec = cand[best];
+    return rc;
 }
 
 // The transform passes of one Richardson-Lucy iteration on a volume the CALLER keeps padded (deconv.hip:
