@@ -187,6 +187,7 @@ def ops_suite(vol, psf, dev, ctx):
         56 * V, "stage the filter (reads the transfer function twice) + apply + release, per call")
     del tf
     mov = torch.roll(vol, (1, -3, 17), (0, 1, 2))
+    phase_cross_corr_device(vol, mov, "magnitude", want_corr=False)  # untimed: allocates the second spectrum and the correlation volume
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(3):

@@ -1208,9 +1208,23 @@ int fftconv_apply(bh_ctx* ctx, const ConvPlan& pl, const float* in, const cf* ot
 __global__ __launch_bounds__(256) void tikhonov_filter_rows_kernel(const float* __restrict__ tf, float* __restrict__ filt,
                                                                    ConvDims d, float reg, float scale,
                                                                    const int* __restrict__ xcol) {
-    extern __shared__ float rowbuf[];  // [XP]
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];  // [XP]
+    constexpr int PT = 8;  // columns per thread: XP <= 2048 (X <= 3072: XP = 1552)
     const int Yh = d.Y / 2;
-    for (long row = blockIdx.x; row < (long)d.Z * d.Y; row += gridDim.x) {
+    // a thread's columns kx = tid + 256 j and where they go in the stored row do not depend on the row
+    int ps[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int kx = threadIdx.x + 256 * j;
+        int q = kx;  // Nyquist and pad columns keep their place
+        if (kx < d.M) {
+            const int rx = d.M / d.Lm, jx = kx / rx, tx = kx - rx * jx;
+            q = tx * d.Lm + (int)(__brev((unsigned)jx) >> (32 - d.logM));
+            if (xcol) q = xcol[q];  // the wave-private X passes store position q in column xcol[q]
+        }
+        ps[j] = kx < d.XP ? q : -1;
+    }
+    auto source_row = [&](long row) -> const float* {
         const int zs = (int)(row / d.Y), ys = (int)(row - (long)zs * d.Y);
         // stored position -> frequency: a 3 * 2^k column holds X[3 j + t] in third t at the bit-reversed j
         const int tz = zs / d.Lz, rz = zs - tz * d.Lz;
@@ -1220,23 +1234,27 @@ __global__ __launch_bounds__(256) void tikhonov_filter_rows_kernel(const float* 
         const int ty = r / d.Lyh, ry = r - ty * d.Lyh;
         const int jy = (int)(__brev((unsigned)ry) >> (32 - d.logYh));
         const int ky = 2 * ((Yh / d.Lyh) * jy + ty) + half;
-        const float* src = tf + ((long)kz * d.Y + ky) * d.X;
-        for (int kx = threadIdx.x; kx < d.XP; kx += 256) {
-            float f = 0.0f;
-            if (kx <= d.M) {
-                const float h = src[kx];
-                f = (h / (h * h + reg)) * scale;
-            }
-            int ps = kx;  // Nyquist and pad columns keep their place
-            if (kx < d.M) {
-                const int rx = d.M / d.Lm, jx = kx / rx, tx = kx - rx * jx;
-                ps = tx * d.Lm + (int)(__brev((unsigned)jx) >> (32 - d.logM));
-                if (xcol) ps = xcol[ps];  // the wave-private X passes store position ps in column xcol[ps]
-            }
-            rowbuf[ps] = f;
+        return tf + ((long)kz * d.Y + ky) * d.X;
+    };
+    const long nrows = (long)d.Z * d.Y;
+    float h[PT];
+    auto load_row = [&](long row) {  // unconditional, clamped: the values of columns past M are not used
+        const float* src = source_row(row < nrows ? row : nrows - 1);
+#pragma unroll
+        for (int j = 0; j < PT; ++j) h[j] = src[min((int)threadIdx.x + 256 * j, d.M)];
+    };
+    long row = blockIdx.x;
+    if (row < nrows) load_row(row);
+    for (; row < nrows; row += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int kx = threadIdx.x + 256 * j;
+            if (ps[j] >= 0) rowbuf[ps[j]] = kx <= d.M ? (h[j] / (h[j] * h[j] + reg)) * scale : 0.0f;
         }
+        load_row(row + gridDim.x);  // the next row travels behind this row's permutation and store
         __syncthreads();
-        for (int ps = threadIdx.x; ps < d.XP; ps += 256) filt[row * d.XP + ps] = rowbuf[ps];
+        float4* dst = reinterpret_cast<float4*>(filt + row * d.XP);  // XP % 4 == 0, rows 16-B aligned
+        for (int q = threadIdx.x; q < d.XP / 4; q += 256) dst[q] = reinterpret_cast<const float4*>(rowbuf)[q];
         __syncthreads();
     }
 }
