@@ -1,0 +1,81 @@
+"""Overlap of the three legs of a plate job on one GPU: upload of unit i + 1, compute of unit i, download of unit i - 1.
+
+The reference's worker (biahub/deskew.py:578-579, deconvolve.py:52-66) uploads a volume, computes and takes the result back,
+one after the other; across PCIe that is most of the time of a unit (bench.py ``end_to_end``: 75 ms up, 358 ms compute,
+297 ms down for a 512 x 2048 x 2048 uint16 stack whose deskewed float32 result is 17 GB).  The three legs use different
+engines — the two DMA directions and the compute units — so a plate's units can be pipelined: three HIP streams, events in
+between, pinned host blocks at both ends; nothing here blocks the host until a result is handed out.  ``libbhcore`` runs on
+torch's current stream (device.Context.bind_stream), so ``compute`` is any function of this package on device tensors.
+"""
+from __future__ import annotations
+
+from collections import deque
+from typing import Callable, Iterable, Iterator
+
+import torch
+
+from .device import resolve_device
+
+
+def run_overlapped(items: Iterable, upload: Callable, compute: Callable, download: Callable, device="cuda",
+                   depth: int = 2) -> Iterator:
+    """Yield ``download(compute(upload(item)))`` for every item, in order, with the legs of neighbouring items overlapped.
+
+    ``upload(item)`` returns device tensor(s) and must only enqueue work (``tensor.to(dev, non_blocking=True)`` from pinned
+    memory); ``compute(uploaded)`` returns device tensor(s); ``download(result)`` enqueues the copy back
+    (``pinned.copy_(t, non_blocking=True)``) and returns whatever the caller wants to receive — it is handed out only after
+    the copy has finished.  ``depth`` bounds the units in flight per leg (device memory: ``depth`` inputs and results).
+    Each callable runs with its own stream current; tensors crossing from one leg to the next are ordered by events and
+    kept alive for the consuming stream.
+    """
+    dev = resolve_device(device)
+    s_in, s_c, s_out = (torch.cuda.Stream(dev) for _ in range(3))
+    staged: deque = deque()   # (uploaded, event): waiting for compute
+    landing: deque = deque()  # (handed, event): waiting for the copy back to finish
+
+    def _record(obj, stream):
+        for t in (obj if isinstance(obj, (tuple, list)) else (obj,)):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(stream)
+
+    def _compute_and_download():
+        up, ev = staged.popleft()
+        s_c.wait_event(ev)
+        with torch.cuda.stream(s_c):
+            _record(up, s_c)
+            res = compute(up)
+            computed = torch.cuda.Event()
+            computed.record(s_c)
+        del up
+        s_out.wait_event(computed)
+        with torch.cuda.stream(s_out):
+            _record(res, s_out)
+            handed = download(res)
+            done = torch.cuda.Event()
+            done.record(s_out)
+        del res
+        landing.append((handed, done))
+
+    def _hand_out():
+        handed, ev = landing.popleft()
+        ev.synchronize()
+        return handed
+
+    with torch.cuda.device(dev):
+        # per item: upload(i) is queued BEFORE compute(i - 1) and download(i - 1), so a host-side wait inside `compute`
+        # (hipFFT planning, a first-use allocation) never keeps the next upload from starting
+        for item in items:
+            with torch.cuda.stream(s_in):
+                up = upload(item)
+                ev = torch.cuda.Event()
+                ev.record(s_in)
+            staged.append((up, ev))
+            del up
+            if len(staged) > 1:
+                _compute_and_download()
+            while len(landing) > max(1, depth) - 1:
+                yield _hand_out()
+        while staged:
+            _compute_and_download()
+        while landing:
+            yield _hand_out()

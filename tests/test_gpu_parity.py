@@ -1467,3 +1467,34 @@ def test_richardson_lucy_real_otf_of_symmetric_psf(gpu, shape, pshape, monkeypat
     assert rel_err(got, O.richardson_lucy_zyx(vol, psf2, 5, 1e-6)) <= FFT_TOL
     again = richardson_lucy(v, pt, 5, 1e-6).cpu().numpy()
     assert np.array_equal(again, real)
+
+
+def test_overlapped_pipeline_equals_serial(gpu):
+    """biahub_amd.pipeline.run_overlapped: results of the three-stream pipeline (upload i + 1 / compute i / download i - 1)
+    equal the serial chain, in order, for more units than pipeline stages and for 0, 1 and 2 units."""
+    from biahub_amd.deconvolve import richardson_lucy
+    from biahub_amd.deskew import fast_deskew_zyx
+    from biahub_amd.pipeline import run_overlapped
+
+    rng = np.random.default_rng(3)
+    psf = torch.from_numpy(O.gaussian_psf((5, 5, 5), (1.0, 1.0, 1.0))).to(gpu)
+    vols = [torch.from_numpy(rng.integers(100, 4000, (32, 64, 96)).astype(np.uint16)).pin_memory() for _ in range(5)]
+
+    def compute(d):
+        return fast_deskew_zyx(richardson_lucy(d, psf, 3, 1e-6), ls_angle_deg=36.0, px_to_scan_ratio=0.4, keep_overhang=False, average_n_slices=1)
+
+    want = [compute(v.to(gpu)).cpu() for v in vols]
+    for n in (0, 1, 2, 5):
+        landing = [torch.empty(want[0].shape, dtype=torch.float32, pin_memory=True) for _ in range(n)]
+        k = [0]
+
+        def download(t):
+            buf = landing[k[0]]
+            k[0] += 1
+            buf.copy_(t, non_blocking=True)
+            return buf
+
+        got = list(run_overlapped(vols[:n], lambda h: h.to(gpu, non_blocking=True), compute, download, gpu))
+        assert len(got) == n
+        for g, w in zip(got, want):
+            assert torch.equal(g, w)
