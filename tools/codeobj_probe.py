@@ -7,14 +7,13 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np, torch
 from biahub_amd import _lib
 from biahub_amd.device import ptr
-from bench import synthetic_position
-from oracle import oracle_np as O
+from bench import PSF_SHAPE, PSF_SIGMA, gaussian_psf, synthetic_position
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 shape = (512, 2048, 2048)
 d = synthetic_position(shape, 1, dev)
 out = torch.empty_like(d)
-psf = torch.from_numpy(O.gaussian_psf((33, 17, 17), (4.0, 2.0, 2.0))).to(dev)
+psf = gaussian_psf(PSF_SHAPE, PSF_SIGMA, dev)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 tmp = Path(tempfile.mkdtemp())
 for i in range(n):

@@ -4,12 +4,11 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np, torch
 from biahub_amd import _lib
 from biahub_amd.device import ptr
-from bench import synthetic_position
-from oracle import oracle_np as O
+from bench import PSF_SHAPE, PSF_SIGMA, gaussian_psf, synthetic_position
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 shape = (512, 2048, 2048)
 d = synthetic_position(shape, 1, dev)
-psf = torch.from_numpy(O.gaussian_psf((33, 17, 17), (4.0, 2.0, 2.0))).to(dev)
+psf = gaussian_psf(PSF_SHAPE, PSF_SIGMA, dev)
 lib = _lib.load()
 h = C.c_void_p(); assert lib.bh_ctx_create(0, None, C.byref(h)) == 0
 lib.bh_ctx_set_stream(h, C.c_void_p(torch.cuda.current_stream(0).cuda_stream)); lib.bh_ctx_set_timing(h, 1)

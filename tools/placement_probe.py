@@ -6,14 +6,13 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np, torch
 from biahub_amd import _lib
 from biahub_amd.device import get_context, ptr
-from bench import synthetic_position
-from oracle import oracle_np as O
+from bench import PSF_SHAPE, PSF_SIGMA, gaussian_psf, synthetic_position
 dev = torch.device("cuda", 0)
 ctx = get_context(dev); ctx.set_timing(True)
 shape = (512, 2048, 2048)
 V = int(np.prod(shape))
 d = synthetic_position(shape, 1, dev)
-psf = torch.from_numpy(O.gaussian_psf((33, 17, 17), (4.0, 2.0, 2.0))).to(dev)
+psf = gaussian_psf(PSF_SHAPE, PSF_SIGMA, dev)
 slack = 64 << 20
 big_out = torch.empty(V + slack // 4, dtype=torch.float32, device=dev)
 big_in = torch.empty(V + slack // 4, dtype=torch.float32, device=dev)
