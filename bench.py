@@ -156,7 +156,8 @@ def ops_suite(vol, psf, dev, ctx):
     Mo[:3, :3] = 1.02 * (np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K)
     Mo[:3, 3] = (3.5, -12.25, 20.75)
     rec("affine_linear_f32_oblique", lambda: affine_device(vol, Mo, shape, "linear"), _lib.T_AFFINE, 8 * V,
-        "the same 2 deg / 1.02x similarity about an oblique axis: z couples with y and x, the staged-tile kernel")
+        "the same 2 deg / 1.02x similarity about an oblique axis: z couples weakly with y and x — the z walk with per-lane source "
+        "planes (csrc/affine_zoblique.inc); stronger couplings run the staged-tile kernel")
     x = torch.empty_like(vol)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for _ in range(3):

@@ -514,6 +514,49 @@ def test_affine_z_walk_equals_staged_tiles(gpu, monkeypatch):
                            rtol=2e-5, atol=2e-3)
 
 
+def test_affine_oblique_walk_equals_staged_tiles(gpu, monkeypatch):
+    """Linear warps with a weak z coupling (a small out-of-plane rotation) take the z walk with per-lane source planes
+    (csrc/affine_zoblique.inc: a ring of four LDS plane slots per wave); stronger couplings stay on the staged tiles.  Every
+    voxel must be BIT-identical to the staged-tile kernel's (BH_AFFINE_NOZWALK=1): interior planes, planes whose window leaves
+    the volume, waves whose box does, crops, both edge rules, NaN / inf taps."""
+    from biahub_amd import _lib
+    from biahub_amd.register import affine_device
+
+    rng = np.random.default_rng(78)
+    vol = rng.random((70, 90, 264), dtype=np.float32) * 1000 - 200
+    vol[30, 44, 100] = np.nan
+    vol[31, 50, 64] = np.inf
+    vol[5, 7, 128] = -np.inf
+    vol[0, 0, 0] = np.inf
+    vol[69, 89, 263] = np.nan
+
+    def rot(axis, deg, s, t):
+        ax = np.asarray(axis, dtype=np.float64)
+        ax /= np.linalg.norm(ax)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        th = np.deg2rad(deg)
+        m = np.eye(4)
+        m[:3, :3] = s * (np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K)
+        m[:3, 3] = t
+        return m
+
+    mats = [rot((1.0, 0.4, 0.3), 2.0, 1.02, (3.5, -12.25, 20.75)), rot((1.0, 0.2, -0.1), -3.0, 0.97, (-2.0, 4.5, 1.25)),
+            rot((1.0, 0.0, 0.05), 5.0, 1.0, (0.5, 0.5, 0.5)), rot((0.3, 1.0, 0.0), 0.5, 1.1, (6.0, -3.0, 2.0)),
+            rot((0.0, 1.0, 0.0), 2.0, 1.0, (0.0, 0.0, 0.0)),          # z couples with x too strongly: staged tiles
+            np.array([[1.0, 0.004, 0.002, 1.5], [0.03, 1.0, 0.0, -2.0], [-0.02, 0.0, 1.0, 3.0], [0, 0, 0, 1.0]])]
+    t = torch.from_numpy(vol).to(gpu)
+    for M in mats:
+        for boundary in (_lib.BOUNDARY_ITK, _lib.BOUNDARY_SCIPY_CONSTANT):
+            for shape, lo, cs in (((70, 90, 264), (0, 0, 0), None), ((75, 100, 200), (3, 5, 66), (60, 80, 130))):
+                monkeypatch.delenv("BH_AFFINE_NOZWALK", raising=False)
+                got = affine_device(t, M, shape, "linear", boundary, -3.5, lo, cs)
+                monkeypatch.setenv("BH_AFFINE_NOZWALK", "1")
+                want = affine_device(t, M, shape, "linear", boundary, -3.5, lo, cs)
+                assert torch.isfinite(got).all()
+                assert torch.equal(got, want), (M.tolist(), boundary, shape)
+    monkeypatch.delenv("BH_AFFINE_NOZWALK", raising=False)
+
+
 def test_affine_scipy_mode_golden(gpu):
     from biahub_amd.core.transform import Transform
 
