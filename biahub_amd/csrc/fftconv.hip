@@ -1438,8 +1438,9 @@ int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, con
 // written: four streams) takes 6.0 to 7.1 ms depending on the physical pages behind `spec` — the same virtual address
 // re-allocated gives 35.0 to 36.2 ms per iteration at config 2, offsets inside one allocation give the same time to
 // +-0.05 ms, every other kernel is indifferent (tools/ctx_probe.py).  So a new spectrum allocation of a large
-// volume is auditioned once: the pass is timed on it and on up to two more allocations held at the same time, and the fastest
-// stays (40-60 ms and 17 GB of transient memory once per context and shape; BH_FC_TUNE_ALLOC=0 skips it).
+// volume is auditioned once: the pass is timed on it and on up to four more allocations held at the same time, until a fast and a
+// slow one have both been seen, and the fastest stays (30-70 ms and up to 35 GB of transient memory once per context and shape;
+// BH_FC_TUNE_ALLOC=0 skips it).
 // `est` is any V-float buffer the caller is about to overwrite (the pass reads and writes it), `bytes` the allocation size.
 int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t bytes, cf** spec) {
     const double V = (double)pl.d.Z * pl.d.Y * pl.d.X;
@@ -1457,10 +1458,13 @@ int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t by
         }
         return BH_OK;
     };
-    cf* cand[3] = {*spec, nullptr, nullptr};
-    float ms[3] = {0.f, 0.f, 0.f};
+    constexpr int NC = 5;  // four of six simultaneous allocations measured slow: five tries leave ~13 % of the draws without a fast one
+    cf* cand[NC] = {*spec, nullptr, nullptr, nullptr, nullptr};
+    float ms[NC] = {0.f, 0.f, 0.f, 0.f, 0.f};
     int n = 1, best = 0, rc = audition(cand[0], &ms[0]);
-    for (; rc == BH_OK && n < 3; ++n) {
+    float slowest = ms[0];
+    for (; rc == BH_OK && n < NC; ++n) {
+        if (ms[best] < 0.93f * slowest) break;  // both levels seen: the fast one is in hand
         if (hipMalloc((void**)&cand[n], bytes) != hipSuccess) {
             (void)hipGetLastError();
             cand[n] = nullptr;
@@ -1471,11 +1475,12 @@ int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t by
             ++n;
             break;
         }
+        if (ms[n] < ms[best]) best = n;
+        if (ms[n] > slowest) slowest = ms[n];
     }
-    for (int i = 1; i < n; ++i)
-        if (cand[i] && ms[i] < ms[best]) best = i;
     if (getenv("BH_DEBUG_SCRATCH"))
-        fprintf(stderr, "[bh tune] fused update pass on %d spectrum allocation(s): %.3f %.3f %.3f ms -> #%d\n", n, ms[0], ms[1], ms[2], best);
+        fprintf(stderr, "[bh tune] fused update pass on %d spectrum allocation(s): %.3f %.3f %.3f %.3f %.3f ms -> #%d\n", n, ms[0], ms[1],
+                ms[2], ms[3], ms[4], best);
     for (int i = 0; i < n; ++i)
         if (i != best && cand[i]) (void)hipFree(cand[i]);
     (void)hipEventDestroy(e0);
