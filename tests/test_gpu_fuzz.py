@@ -159,3 +159,89 @@ def test_fuzz_round2_engine_kernels_vs_oracle(gpu):
         got = apply_inverse_transfer_function_zyx(vol, H, 0, 1e-2, True).cpu().numpy()
         assert rel_err(got, O.wo_apply_inverse_transfer_function(volh, H, 0, 1e-2, True)) <= 1e-4, (Z, Y, X)
     assert real_otf >= 3 and colw >= 3
+
+
+def test_fuzz_affine_walks_equal_staged_tiles(gpu, monkeypatch):
+    """Random matrices, shapes, crops and dtypes through the z walks of csrc/affine_zwalk.inc / affine_zoblique.inc: every result
+    bit-identical to the staged-tile kernel's (BH_AFFINE_NOZWALK=1).  Matrices: random similarity about z (any angle), random
+    z scale and shear-free shifts, and small random rotations about oblique axes (weak z coupling)."""
+    from biahub_amd import _lib
+    from biahub_amd.register import affine_device
+
+    rng = np.random.default_rng(2024)
+
+    def rot(axis, deg):
+        ax = np.asarray(axis, dtype=np.float64)
+        ax /= np.linalg.norm(ax)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        th = np.deg2rad(deg)
+        return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+    for case in range(24):
+        Zi, Yi = int(rng.integers(5, 80)), int(rng.integers(6, 150))
+        Xi = int(rng.integers(2, 40)) * (8 if case % 3 else 1) + (0 if case % 3 else int(rng.integers(0, 7)))
+        dt = [np.float32, np.uint16, np.int16, np.uint8][case % 4]
+        if dt == np.float32:
+            src = (rng.random((Zi, Yi, Xi), dtype=np.float32) * 2000 - 500)
+            for _ in range(3):
+                src[rng.integers(0, Zi), rng.integers(0, Yi), rng.integers(0, Xi)] = rng.choice([np.nan, np.inf, -np.inf])
+        else:
+            info = np.iinfo(dt)
+            src = rng.integers(info.min, info.max, (Zi, Yi, Xi), endpoint=True).astype(dt)
+        M = np.eye(4)
+        if case % 2 == 0:   # z-separable
+            s = rng.uniform(0.5, 1.6)
+            M[:3, :3] = s * rot((1, 0, 0), rng.uniform(-180, 180))
+            M[0, 0] = rng.choice([0.0, rng.uniform(0.3, 2.5)])
+            M[0, 1] = M[0, 2] = M[1, 0] = M[2, 0] = 0.0
+        else:               # weakly oblique
+            M[:3, :3] = rng.uniform(0.8, 1.25) * rot((1.0, rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5)), rng.uniform(-4, 4))
+        M[:3, 3] = rng.uniform(-12, 12, 3) * [1, 2, 3]
+        if case % 5 == 0:
+            M[:3, 3] = np.round(M[:3, 3] * 2) / 2   # integer / half-integer shifts: the ties of the inside rule
+        Zo, Yo, Xo = (int(rng.integers(1, 90)), int(rng.integers(1, 160)), int(rng.integers(1, 300)))
+        lo = tuple(int(rng.integers(0, n // 2 + 1)) for n in (Zo, Yo, Xo))
+        cs = tuple(int(rng.integers(1, n - l + 1)) for n, l in zip((Zo, Yo, Xo), lo))
+        t = torch.from_numpy(src).to(gpu)
+        for interp in ("linear", "nearestneighbor"):
+            for boundary in (_lib.BOUNDARY_ITK, _lib.BOUNDARY_SCIPY_CONSTANT):
+                monkeypatch.delenv("BH_AFFINE_NOZWALK", raising=False)
+                got = affine_device(t, M, (Zo, Yo, Xo), interp, boundary, 7.5, lo, cs)
+                monkeypatch.setenv("BH_AFFINE_NOZWALK", "1")
+                want = affine_device(t, M, (Zo, Yo, Xo), interp, boundary, 7.5, lo, cs)
+                assert torch.equal(got, want), (case, src.shape, str(dt), M.tolist(), (Zo, Yo, Xo), lo, cs, interp, boundary)
+    monkeypatch.delenv("BH_AFFINE_NOZWALK", raising=False)
+
+
+def test_fuzz_radix8_z_pass_equals_radix4(gpu, monkeypatch):
+    """512-plane volumes of random y / x extents (2^k and 3 * 2^k, ragged last column tiles) and random PSFs through the radix-8
+    Z pass (csrc/fftconv_colz.inc) and the radix-4 one (BH_FC_COLZ=0): R-L with a real and a complex transfer function,
+    Tikhonov, phase cross-correlation."""
+    from biahub_amd.deconvolve import richardson_lucy, tikhonov_zyx, transfer_function_device
+    from biahub_amd.estimate_stabilization import phase_cross_corr_device
+
+    rng = np.random.default_rng(77)
+    for case in range(5):
+        Y = int(rng.choice([32, 48, 64, 96, 128]))
+        X = int(rng.choice([64, 96, 128, 192, 256]))
+        shape = (512, Y, X)
+        volh = (rng.random(shape, dtype=np.float32) * rng.choice([1.0, 300.0, 6e4])).astype(np.float32)
+        pshape = tuple(int(rng.integers(1, 6)) * 2 + 1 for _ in range(3))
+        sym = O.gaussian_psf(pshape, tuple(max(q / 4.0, 0.7) for q in pshape))
+        asym = (rng.random(tuple(int(rng.integers(1, 9)) for _ in range(3))) + 0.05).astype(np.float32)
+        vol = torch.from_numpy(volh).to(gpu)
+        mov = torch.roll(vol, (3, -2, 5), (0, 1, 2))
+        res = {}
+        for tag in ("1", "0"):
+            monkeypatch.setenv("BH_FC_COLZ", tag)
+            out = [richardson_lucy(vol, torch.from_numpy(p).to(gpu), 2, 1e-6).cpu().numpy() for p in (sym, asym)]
+            tf = transfer_function_device(torch.from_numpy(sym).to(gpu), shape, gpu)
+            out.append(tikhonov_zyx(vol, tf, 1e-2).cpu().numpy())
+            sh, corr = phase_cross_corr_device(vol, mov, "magnitude")
+            assert tuple(float(v) for v in sh) == (-3.0, 2.0, -5.0)
+            out.append(corr.cpu().numpy())
+            res[tag] = out
+        monkeypatch.delenv("BH_FC_COLZ", raising=False)
+        for a, b in zip(res["1"], res["0"]):
+            assert rel_err(a, b) <= 2e-5, (shape, pshape, rel_err(a, b))
+        assert rel_err(res["1"][0], O.richardson_lucy_zyx(volh, sym, iterations=2, eps=1e-6)) <= 1e-4, shape
