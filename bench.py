@@ -364,8 +364,8 @@ def main():
             },
             "roofline": {
                 "kernel": "one Richardson-Lucy iteration = 8 in-place passes of csrc/fftconv.hip: 2 x (colw_kernel Y fwd "
-                          "[register stages, csrc/fftconv_colw.inc], col_pass_kernel Z fwd*OTF*inv [real OTF: the Gaussian PSF is "
-                          "point-symmetric], colw_kernel Y inv, xw_kernel<FUSED_*>: inverse X + RL epilogue + next forward X in "
+                          "[register stages, csrc/fftconv_colw.inc], colz_kernel Z fwd*OTF*inv [radix-8 register stages, "
+                          "csrc/fftconv_colz.inc; real OTF: the Gaussian PSF is point-symmetric], colw_kernel Y inv, xw_kernel<FUSED_*>: inverse X + RL epilogue + next forward X in "
                           "registers, csrc/fftconv_xw.inc)",
                 "bound": "hbm",
                 "achieved": rl_bytes / rl_iter_s / 1e9,
