@@ -575,10 +575,13 @@ extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, 
             default: BH_REQUIRE(false, "unsupported input dtype code %d", in_dtype);
         }
     }
-    if (in_dtype == BH_DT_F32) {  // weak z coupling: the z walk with per-lane source planes (affine_zoblique.inc)
+    if (in_dtype == BH_DT_F32 || in_dtype == BH_DT_U16 || in_dtype == BH_DT_I16) {
+        // weak z coupling: the z walk with per-lane source planes (affine_zoblique.inc)
         int64_t zchunk = 0;
         const int slot = zo::plan(p, &zchunk);
-        if (slot) return zo::launch(ctx, (const float*)in, out, p, slot, zchunk);
+        if (slot && in_dtype == BH_DT_F32) return zo::launch(ctx, (const float*)in, out, p, slot, zchunk);
+        if (slot && in_dtype == BH_DT_U16) return zo::launch(ctx, (const uint16_t*)in, out, p, slot, zchunk);
+        if (slot) return zo::launch(ctx, (const int16_t*)in, out, p, slot, zchunk);
     }
     switch (in_dtype) {
         case BH_DT_F32: return launch_affine(ctx, (const float*)in, out, p);

@@ -544,16 +544,18 @@ def test_affine_oblique_walk_equals_staged_tiles(gpu, monkeypatch):
             rot((1.0, 0.0, 0.05), 5.0, 1.0, (0.5, 0.5, 0.5)), rot((0.3, 1.0, 0.0), 0.5, 1.1, (6.0, -3.0, 2.0)),
             rot((0.0, 1.0, 0.0), 2.0, 1.0, (0.0, 0.0, 0.0)),          # z couples with x too strongly: staged tiles
             np.array([[1.0, 0.004, 0.002, 1.5], [0.03, 1.0, 0.0, -2.0], [-0.02, 0.0, 1.0, 3.0], [0, 0, 0, 1.0]])]
-    t = torch.from_numpy(vol).to(gpu)
-    for M in mats:
-        for boundary in (_lib.BOUNDARY_ITK, _lib.BOUNDARY_SCIPY_CONSTANT):
-            for shape, lo, cs in (((70, 90, 264), (0, 0, 0), None), ((75, 100, 200), (3, 5, 66), (60, 80, 130))):
-                monkeypatch.delenv("BH_AFFINE_NOZWALK", raising=False)
-                got = affine_device(t, M, shape, "linear", boundary, -3.5, lo, cs)
-                monkeypatch.setenv("BH_AFFINE_NOZWALK", "1")
-                want = affine_device(t, M, shape, "linear", boundary, -3.5, lo, cs)
-                assert torch.isfinite(got).all()
-                assert torch.equal(got, want), (M.tolist(), boundary, shape)
+    srcs = [vol, rng.integers(0, 60000, vol.shape).astype(np.uint16), (rng.integers(0, 60000, vol.shape) - 30000).astype(np.int16)]
+    for src in srcs:  # 16-bit volumes: the same ring with 8 samples per quad
+        t = torch.from_numpy(src).to(gpu)
+        for M in mats:
+            for boundary in (_lib.BOUNDARY_ITK, _lib.BOUNDARY_SCIPY_CONSTANT):
+                for shape, lo, cs in (((70, 90, 264), (0, 0, 0), None), ((75, 100, 200), (3, 5, 66), (60, 80, 130))):
+                    monkeypatch.delenv("BH_AFFINE_NOZWALK", raising=False)
+                    got = affine_device(t, M, shape, "linear", boundary, -3.5, lo, cs)
+                    monkeypatch.setenv("BH_AFFINE_NOZWALK", "1")
+                    want = affine_device(t, M, shape, "linear", boundary, -3.5, lo, cs)
+                    assert torch.isfinite(got).all()
+                    assert torch.equal(got, want), (src.dtype, M.tolist(), boundary, shape)
     monkeypatch.delenv("BH_AFFINE_NOZWALK", raising=False)
 
 
