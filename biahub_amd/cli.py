@@ -81,10 +81,11 @@ def _create_plate_once(*args, **kwargs):
     """Rank 0 lays the output plate out, the other ranks wait for it: ``create_empty_plate`` rewrites plate / row / well
     metadata, which concurrent ranks would race on (the reference creates the plate once, in the submitting process,
     before any job starts: biahub/deskew.py:668-676)."""
-    rank, _ = parallel.init()
-    if rank == 0:
-        create_empty_plate(*args, **kwargs)
-    parallel.barrier()
+    parallel.init()
+    try:
+        parallel.rank0_first(create_empty_plate, *args, **kwargs)  # every rank reaches the collective, also when rank 0 fails
+    except parallel.Rank0Error as e:
+        raise click.ClickException(str(e)) from e
 
 
 def _run_positions(step: str, inputs, outputs, make_job, out_parent: Path):
@@ -327,8 +328,13 @@ def _apply_inverse_transfer_function(input_position_dirpaths, transfer_function_
     with open_ome_zarr(input_position_dirpaths[0]) as ds:
         input_shape = ds.data.shape
     meta = get_reconstruction_output_metadata(input_position_dirpaths[0], config_filepath)
+    from .utils.paths import PROVENANCE_METADATA_KEYS
+
+    # per-position provenance (biahub-*, waveorder, cytoland attributes) travels from the input plate into the reconstruction
+    # (biahub/apply_inverse_transfer_function.py:66-72)
     _create_plate_once(output_dirpath, [p.parts[-3:] for p in input_position_dirpaths], meta["channel_names"], meta["shape"],
-                       scale=meta["scale"], dtype=np.float32, version=meta["version"], compressor=_output_compressor())
+                       scale=meta["scale"], dtype=np.float32, version=meta["version"], compressor=_output_compressor(),
+                       metadata_sources=Path(input_position_dirpaths[0]).parents[2], metadata_keys=PROVENANCE_METADATA_KEYS)
     num_cpus, mem_per_cpu = wo_estimate(list(input_shape), settings, 16)
     T, C, Z, Y, X = input_shape
     minutes, _, _ = estimate_resources((T, len(settings.input_channel_names), Z, Y, X), time_multiplier=3.0, max_num_cpus=16)
@@ -339,7 +345,7 @@ def _apply_inverse_transfer_function(input_position_dirpaths, transfer_function_
         return
     try:
         _refuse_unsupported(settings)
-    except NotImplementedError as e:
+    except (NotImplementedError, ValueError) as e:
         raise click.UsageError(str(e)) from e
     if sbatch_filepath:
         sbatch_to_submitit(sbatch_filepath)
@@ -381,12 +387,13 @@ def compute_tf_cli(input_position_dirpaths, config_filepath, output_dirpath):
     (reference: ``biahub compute-tf``, compute_transfer_function.py:16-38)."""
     from .compute_transfer_function import compute_transfer_function_cli
 
-    try:
-        if parallel.init()[0] == 0:  # one writer; the store is shared by every rank of a later apply-inv-tf
-            compute_transfer_function_cli(input_position_dirpaths[0], config_filepath, output_dirpath)
-        parallel.barrier()
-    except NotImplementedError as e:
+    parallel.init()
+    try:  # one writer; the store is shared by every rank of a later apply-inv-tf
+        parallel.rank0_first(compute_transfer_function_cli, input_position_dirpaths[0], config_filepath, output_dirpath)
+    except (NotImplementedError, ValueError) as e:
         raise click.UsageError(str(e)) from e
+    except parallel.Rank0Error as e:
+        raise click.ClickException(str(e)) from e
     click.echo(f"Transfer function computed and saved to {output_dirpath}.")
 
 
@@ -401,12 +408,13 @@ def reconstruct_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, mo
     from .compute_transfer_function import compute_transfer_function_cli
 
     tf_path = Path(output_dirpath).parent / ("transfer_function_" + Path(config_filepath).stem + ".zarr")
+    parallel.init()
     try:
-        if parallel.init()[0] == 0:
-            compute_transfer_function_cli(input_position_dirpaths[0], config_filepath, tf_path)
-        parallel.barrier()
-    except NotImplementedError as e:
+        parallel.rank0_first(compute_transfer_function_cli, input_position_dirpaths[0], config_filepath, tf_path)
+    except (NotImplementedError, ValueError) as e:
         raise click.UsageError(str(e)) from e
+    except parallel.Rank0Error as e:
+        raise click.ClickException(str(e)) from e
     _apply_inverse_transfer_function(input_position_dirpaths, tf_path, config_filepath, output_dirpath, sbatch_filepath,
                                      cluster)
 

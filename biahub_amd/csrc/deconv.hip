@@ -544,9 +544,12 @@ static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, 
     BH_TRY(get_scratch(ctx, "fc_spec", NS * sizeof(cf), (void**)&spec));
     if (spec != ctx->spec_tuned && iterations > 0) {  // a new allocation: audition it (fftconv_tune_spectrum)
         Scratch& sc = ctx->scratch["fc_spec"];
-        BH_TRY(fftconv_tune_spectrum(ctx, *pl, out, sc.bytes, &spec));
+        // the audition may free the allocation it was handed and keep another one: the scratch table must follow it on the
+        // error path too, or the next get_scratch("fc_spec") hands out a freed pointer
+        const int tune_rc = fftconv_tune_spectrum(ctx, *pl, out, sc.bytes, &spec);
         sc.ptr = spec;
         ctx->spec_tuned = spec;
+        BH_TRY(tune_rc);
     }
     BH_TRY(get_scratch(ctx, "fc_otf", NS * sizeof(cf), (void**)&otf));
     BH_TRY(get_scratch(ctx, "rl_psum", 64, (void**)&psum));

@@ -889,7 +889,7 @@ static int upload(const std::vector<cf>& h, cf** dptr) {
 int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     std::lock_guard<std::mutex> lock(g_plans_mu);
     // BH_FC_XW=0 keeps the tile-based X passes for every shape (A/B switch, read per call: plans of both kinds can coexist)
-    const bool xw_on = !(getenv("BH_FC_XW") && atoi(getenv("BH_FC_XW")) == 0) && (X == 1024 || X == 2048) && ((Y / 2) % 4) == 0;
+    const bool xw_on = !(getenv("BH_FC_XW") && atoi(getenv("BH_FC_XW")) == 0) && (X == 512 || X == 1024 || X == 2048) && ((Y / 2) % 4) == 0;
     auto key = std::make_tuple(ctx->device * 2 + (xw_on ? 1 : 0), Z, Y, X);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) {
@@ -978,7 +978,7 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     }
     if (xw_on) {
         std::vector<int> col;
-        if (X == 2048) xw::make_tables<10>(h, col); else xw::make_tables<9>(h, col);
+        if (X == 2048) xw::make_tables<10>(h, col); else if (X == 1024) xw::make_tables<9>(h, col); else xw::make_tables<8>(h, col);
         BH_TRY(upload(h, &pl.xw_tab));
         BH_CHECK_HIP(hipMalloc(&pl.xw_col, col.size() * sizeof(int)));
         BH_CHECK_HIP(hipMemcpy(pl.xw_col, col.data(), col.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1171,7 +1171,7 @@ static int launch_xw(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, con
                      : epi == XE_STORE ? xw::INV_STORE
                      : epi == XE_RATIO ? (fuse_fwd ? xw::FUSED_RATIO : xw::INV_RATIO)
                                        : (fuse_fwd ? xw::FUSED_UPDATE : xw::INV_UPDATE);
-    return pl.d.M == 1024 ? launch_xw_m<10>(ctx, p, mode) : launch_xw_m<9>(ctx, p, mode);
+    return pl.d.M == 1024 ? launch_xw_m<10>(ctx, p, mode) : (pl.d.M == 512 ? launch_xw_m<9>(ctx, p, mode) : launch_xw_m<8>(ctx, p, mode));
 }
 
 static int launch_x(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, const float* in, cf* S, float* out,

@@ -76,16 +76,25 @@ __global__ void sum_finish_kernel(double* part, int nblocks, int64_t n) {
         part[nblocks] = t / (double)n;  // mean
     }
 }
-// padded[z + pad] = normalise ? x / mean - 1 : x ; the padding planes are 0 (the mean, after normalisation)
+// padded[z + pad] = n(x)[z], n(x) = normalise ? x / mean - 1 : x.  The padding planes follow waveorder 3.0.5's
+// util.pad_zyx_along_z (recalled; parity unpinned): with z_padding < Z they mirror the volume's own edge planes (plane pad - 1 - z
+// below, plane Z - 1 - k for the k-th plane above), otherwise they are constant 0.
 __global__ __launch_bounds__(256) void normalize_pad_kernel(const float* __restrict__ x, float* __restrict__ padded, int64_t nin,
                                                             int64_t plane, int64_t pad, int64_t ntotal,
                                                             const double* __restrict__ mean, int normalize) {
     const float inv = normalize ? (float)(1.0 / *mean) : 1.0f;
     const float sub = normalize ? 1.0f : 0.0f;
-    const int64_t off = pad * plane;
+    const int64_t Z = nin / plane;
+    const bool mirror = pad < Z;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ntotal; i += (int64_t)gridDim.x * 256) {
-        const int64_t j = i - off;
-        padded[i] = (j >= 0 && j < nin) ? x[j] * inv - sub : 0.0f;
+        const int64_t zp = i / plane, r = i - zp * plane;
+        int64_t z = zp - pad;
+        bool inside = z >= 0 && z < Z;
+        if (!inside && mirror) {
+            z = z < 0 ? -1 - z : 2 * Z - 1 - z;
+            inside = true;
+        }
+        padded[i] = inside ? x[z * plane + r] * inv - sub : 0.0f;
     }
 }
 

@@ -68,6 +68,9 @@ def tikhonov_zyx(zyx, transfer_function, regularization_strength: float = 1e-3) 
 # every (t, c) unit of a plate the same transfer function (biahub/deconvolve.py:183-191; each worker re-reads it from zarr,
 # :52-54); here it is uploaded and staged once (bh_inverse_filter_create) and every later call only runs the five passes.
 # Keyed by the identity of the object that was passed (kept alive by the entry), its shape, the regularisation and the device.
+# The in-place-edit guard samples ~4096 strided elements: editing a transfer function in place between calls is NOT supported
+# (pass a new array); the sample only catches the common whole-array rewrites.  The oldest entry is evicted first, so two
+# transfer functions used in alternation both stay staged.
 _PREPARED: "dict[tuple, tuple]" = {}
 _PREPARED_MAX = 2
 
@@ -84,7 +87,7 @@ def _prepared_filter(transfer_function, regularization_strength: float, dev):
     if hit is not None and hit[0] is transfer_function:
         return hit[1]
     while len(_PREPARED) >= _PREPARED_MAX:
-        _, old = _PREPARED.popitem()
+        old = _PREPARED.pop(next(iter(_PREPARED)))  # dicts keep insertion order: the oldest entry goes
         old[1].close()
     H, _ = _f32_device(transfer_function, dev)
     prep = PreparedInverseFilter(H, shape, 0, regularization_strength, "f32", dev)

@@ -80,6 +80,7 @@ class Context:
 
     def release_workspace(self):
         _lib.check(self.lib.bh_ctx_release_workspace(self.handle))
+        _lib.check(self.lib.bh_inverse_filter_trim())  # the pool of released staged-filter blocks (gigabytes each) goes too
 
     def fft_plans_replaced(self) -> int:
         """hipFFT 3-D plans that failed their creation-time round trip and were rebuilt decomposed."""

@@ -821,9 +821,24 @@ def _create_array(apath: Path, shape, chunks, dt, fmt: int, compressor, shards_r
 
 
 def create_empty_plate(store_path, position_keys, channel_names, shape, chunks=None, scale=(1, 1, 1, 1, 1),
-                       dtype=np.float32, version="0.4", compressor=None, metadata=None, shards_ratio=None) -> None:
+                       dtype=np.float32, version="0.4", compressor=None, metadata=None, shards_ratio=None,
+                       metadata_sources=None, metadata_keys=None) -> None:
     """HCS plate with empty positions — argument names follow iohub's ``create_empty_plate`` as the reference calls
-    it (biahub/deskew.py:629-640, register.py:488-504)."""
+    it (biahub/deskew.py:629-640, register.py:488-504).  ``metadata_sources`` (a plate holding the same row/col/fov
+    positions) and ``metadata_keys`` (names or ``fnmatch`` patterns, e.g. ``PROVENANCE_METADATA_KEYS``) copy the matching
+    per-position attributes of the source into the new positions, as the reference's apply-inv-tf asks for
+    (biahub/apply_inverse_transfer_function.py:66-72)."""
+    from fnmatch import fnmatchcase
+
+    def carried(key):
+        if not (metadata_sources and metadata_keys):
+            return metadata
+        src = Path(metadata_sources).joinpath(*(str(k) for k in key))
+        if _group_format(src) is None:
+            return metadata
+        found = {k: v for k, v in _read_group_attrs(src).items() if any(fnmatchcase(k, pat) for pat in metadata_keys)}
+        return {**found, **(metadata or {})} if found else metadata
+
     store = Path(store_path)
     version = str(version)
     fmt = _group_format(store) or (2 if version == "0.4" else 3)
@@ -854,7 +869,7 @@ def create_empty_plate(store_path, position_keys, channel_names, shape, chunks=N
             wmeta["images"].append({"path": fov})
         wattrs["well"] = wmeta
         _write_group(well, fmt, wattrs, version)
-        create_empty_position(well / fov, channel_names, shape, chunks, scale, dtype, version, compressor, metadata,
+        create_empty_position(well / fov, channel_names, shape, chunks, scale, dtype, version, compressor, carried(key),
                               shards_ratio)
     attrs["plate"] = plate
     _write_group(store, fmt, attrs, version)

@@ -104,6 +104,34 @@ def barrier(device=None):
             dist.barrier()
 
 
+class Rank0Error(RuntimeError):
+    """Raised on ranks > 0 when the work rank 0 does for everybody (plate lay-out, transfer function) failed there."""
+
+
+def rank0_first(fn, *args, **kwargs):
+    """Run ``fn`` on rank 0 only, then let every rank learn whether it worked: rank 0 re-raises its own exception, the
+    others raise :class:`Rank0Error` with its text.  Every rank reaches the collective on both paths — a plain
+    ``if rank == 0: fn(); barrier()`` leaves the other ranks in the barrier until the collective times out (about ten
+    minutes, GPUs held) when rank 0 raises before it gets there."""
+    rank, _, _ = world_info()
+    err: BaseException | None = None
+    result = None
+    if rank == 0:
+        try:
+            result = fn(*args, **kwargs)
+        except BaseException as e:  # noqa: BLE001 - re-raised below, after the collective
+            err = e
+    if dist.is_initialized():
+        box = [None if err is None else f"{type(err).__name__}: {err}"]
+        dev = _comm_device(None)
+        dist.broadcast_object_list(box, src=0, device=None if dev == "cpu" else torch.device(dev))
+        if rank != 0 and box[0] is not None:
+            raise Rank0Error(f"rank 0 failed: {box[0]}")
+    if err is not None:
+        raise err
+    return result
+
+
 def max_over_ranks(value: float, device=None) -> float:
     """The slowest rank's value (bench.py's timing contract)."""
     if not dist.is_initialized():

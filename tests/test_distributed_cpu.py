@@ -157,3 +157,44 @@ def test_single_process_defaults():
     st = parallel.process_positions(range(3), lambda p: 10, 0, 1)
     assert (st.n_done, st.n_failed, st.voxels) == (3, 0, 30.0)
     assert parallel.gather_stats(st)[0].n_done == 3
+
+
+def _rank0_fail_worker(rank, world, port, q, tmp):
+    """Rank 0's plate lay-out fails: every rank must leave the collective promptly with an error, none may hang."""
+    import time
+
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), BH_DIST_BACKEND="gloo")
+    parallel.init()
+    t0 = time.perf_counter()
+    ok = parallel.rank0_first(lambda: "laid out")  # the good path returns rank 0's value there, None elsewhere
+    outcome = "no error"
+    try:
+        from biahub_amd.io import create_empty_plate
+
+        bad = os.path.join(tmp, "not_a_dir")  # a regular file where the store should go
+        parallel.rank0_first(create_empty_plate, bad, [("A", "1", "0")], ["c"], (1, 1, 2, 4, 4))
+    except parallel.Rank0Error as e:
+        outcome = f"Rank0Error: {e}"
+    except Exception as e:  # noqa: BLE001 - rank 0 re-raises its own exception
+        outcome = f"own: {type(e).__name__}"
+    q.put((rank, ok, outcome, time.perf_counter() - t0))
+    torch.distributed.destroy_process_group()
+
+
+def test_rank0_failure_reaches_every_rank(tmp_path):
+    (tmp_path / "not_a_dir").write_text("occupied")
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank0_fail_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out[0][1] == "laid out" and out[1][1] is None
+    assert out[0][2].startswith("own: ")                       # rank 0 sees its own exception
+    assert out[1][2].startswith("Rank0Error: rank 0 failed")   # rank 1 is told, instead of waiting in a barrier
+    assert all(o[3] < 30 for o in out)

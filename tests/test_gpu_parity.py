@@ -1175,6 +1175,7 @@ def test_zarr_device_volume_io(gpu, tmp_path, version, shards_ratio, shuffle):
 @pytest.mark.parametrize("shape,pshape", [
     ((8, 32, 2048), (5, 5, 9)),      # M = 1024: one row pair per wavefront, radix 8 x 16 x 8
     ((4, 64, 1024), (3, 7, 7)),      # M = 512: two row pairs per wavefront, radix 8 x 8 x 8
+    ((8, 64, 512), (3, 5, 7)),       # M = 256: four row pairs per wavefront, radix 8 x 4 x 8
     ((24, 96, 1024), (5, 5, 5)),     # Z, Y of 3 * 2^k: radix-3 column passes around the new X passes
     ((12, 40, 2048), (3, 5, 11)),    # Z, Y too short for the engine as they are: the wrap-padded box (plain inverse with store)
 ])
@@ -1249,7 +1250,8 @@ def test_fluorescence_transfer_function_vs_oracle(gpu, shape, yx, dz, pad):
     ((16, 32, 64), 0),     # the fused engine, filter multiplied in its Z pass
     ((12, 32, 64), 2),     # padded to 16 planes: engine, z crop
     ((15, 21, 25), 0),     # library transforms
-    ((10, 21, 25), 3),     # library transforms, z padding
+    ((10, 21, 25), 3),     # library transforms, z padding (mirrored edge planes, as waveorder's pad_zyx_along_z)
+    ((3, 21, 25), 5),      # z_padding >= Z: the pad planes stay zero
     ((8, 64, 1024), 0),    # rows of 1024 voxels: wave-private X passes, the filter staged through their column order
 ])
 def test_apply_inverse_transfer_function_vs_oracle(gpu, shape, pad):

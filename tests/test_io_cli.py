@@ -595,7 +595,7 @@ def test_apply_inv_tf_cli_init_only(tmp_path):
     for key in (("A", "1", "0"), ("B", "1", "0")):  # make_plate names channels ch0..: the config asks for "BF"
         pos = io.open_ome_zarr(src.joinpath(*key))
         pos.zattrs["omero"]["channels"][0]["label"] = "BF"
-        pos.update_zattrs({})
+        pos.update_zattrs({"biahub-deskew": {"angle": 30.0, "fov": key[0]}, "waveorder": {"v": 1}, "unrelated": 7})
     cfg = tmp_path / "reconstruct.yml"
     cfg.write_text(yaml.dump(RECON_YML))
     out = tmp_path / "output.zarr"
@@ -606,6 +606,10 @@ def test_apply_inv_tf_cli_init_only(tmp_path):
     pos = io.open_ome_zarr(out / "B/1/0")
     assert pos.channel_names == ["Phase3D"] and pos.data.shape == (1, 1, 5, 8, 8) and pos.data.dtype == np.float32
     assert pos.scale == [1.0, 1.0, 0.25, 0.1, 0.1]
+    # per-position provenance follows the position (metadata_sources / PROVENANCE_METADATA_KEYS:
+    # biahub/apply_inverse_transfer_function.py:66-72); other attributes do not
+    assert pos.zattrs["biahub-deskew"] == {"angle": 30.0, "fov": "B"} and pos.zattrs["waveorder"] == {"v": 1}
+    assert "unrelated" not in pos.zattrs
     res = CliRunner().invoke(cli, ["apply-inv-tf", "-i", str(src / "A/1/0"), "-c", str(cfg), "-o", str(out)])
     assert res.exit_code != 0 and "--transfer-function-dirpath / -t is required unless using --init." in res.output
 

@@ -297,3 +297,21 @@ def test_register_stage_column_pass_model():
             assert all(c == i for c, i in tot.values()), (logn, tot)
     finally:
         sys.path.remove(str(tools))
+
+
+def test_oracle_inverse_filter_z_padding_mirrors_edge_planes():
+    """waveorder's util.pad_zyx_along_z (recalled; parity unpinned): pad planes are the flipped first / last z_padding planes
+    when z_padding < Z, zeros otherwise.  With H = 1 and reg = 0 the filter is the identity, so the cropped output is the
+    input whatever the padding; a delta transfer function along z that shifts by one plane exposes the pad planes."""
+    rng = np.random.default_rng(3)
+    x = rng.random((4, 3, 5)).astype(np.float32)
+    for pad in (2, 6):
+        Zp = 4 + 2 * pad
+        shift = np.zeros((Zp, 3, 5))
+        shift[1, 0, 0] = 1.0                                  # convolution kernel: out[z] = in[z - 1]
+        H = np.fft.fftn(shift)
+        # inverse filter conj(H) / |H|^2 undoes the shift: out[z] = in[z + 1]; the last kept plane shows the first pad plane
+        got = O.wo_apply_inverse_transfer_function(x, H, pad, 0.0, False)
+        assert np.allclose(got[:-1], x[1:], atol=1e-5)
+        want_last = x[-1] if pad < 4 else np.zeros_like(x[-1])   # mirrored edge plane, or the zero fallback
+        assert np.allclose(got[-1], want_last, atol=1e-5), pad
