@@ -29,7 +29,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 from biahub_amd import _lib, parallel  # noqa: E402
-from biahub_amd.deconvolve import richardson_lucy  # noqa: E402
+from biahub_amd.deconvolve import PreparedRichardsonLucy, richardson_lucy  # noqa: E402
 from biahub_amd.deskew import fast_deskew_zyx, get_deskewed_data_shape  # noqa: E402
 from biahub_amd.device import get_context  # noqa: E402
 
@@ -200,10 +200,77 @@ def ops_suite(vol, psf, dev, ctx):
                                "note": "wall clock incl. the argmax read-back; 3 FFTs (72 V) + product (8 V) by the model; the product runs inside the Z pass of the second transform"}
     del mov
     ctx.release_workspace()
+    # Richardson-Lucy on DESKEWED volumes — BASELINE config 4 in its literal order (deskew -> deconvolve), and what the
+    # reference's own pipeline does with its FFT reconstruction (nextflow/mantis-v2.nf:116-125): awkward row lengths, the
+    # engine at a wrap-padded box.  Prepared handle, per-volume wall time of the third call.
+    for name, dshape in (("rl10_deskewed_config4_volume", (342, 1024, 1517)), ("rl10_deskewed_config2_volume", (683, 2048, 3034))):
+        try:
+            g = torch.Generator(device=dev).manual_seed(5)
+            dvol = torch.empty(dshape, dtype=torch.float32, device=dev).uniform_(90.0, 400.0, generator=g)
+            with PreparedRichardsonLucy(psf, dshape, dev) as h:
+                Vd = float(np.prod(dshape))
+                Vb = float(np.prod(h.box))
+                res = torch.empty_like(dvol)
+                for _ in range(3):
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    h(dvol, 10, 1e-6, out=res)
+                    torch.cuda.synchronize(dev)
+                    ms = (time.perf_counter() - t0) * 1e3
+                out[name] = {"ms": ms, "shape": list(dshape), "box": list(h.box), "backend": h.backend, "voxels_per_s": Vd / ms * 1e3,
+                             "algorithmic_bytes": 1120 * Vd, "GBps": 1120 * Vd / ms / 1e6, "frac": 1120 * Vd / ms / 1e6 / HBM_PEAK_GBS,
+                             "frac_of_box": 1120 * Vb / ms / 1e6 / HBM_PEAK_GBS,
+                             "note": "10 iterations incl. wrap-padding in and crop out; bytes by the 112 V model on the volume's own "
+                                     "voxels (frac) and on the padded box the transforms run at (frac_of_box)"}
+            del dvol, res
+        except RuntimeError as e:  # not enough free HBM beside the resident position
+            out[name] = {"skipped": str(e)[:200]}
+        ctx.release_workspace()
     return out
 
 
-def end_to_end(vol_host_u16, psf, iterations, dev):
+def overlapped_units(vol_host_u16, rl, iterations, dev, ctx, n_units=8):
+    """`n_units` positions through biahub_amd.pipeline.run_overlapped: upload of unit i + 1 (pinned uint16), compute of unit i
+    (prepared R-L handle: nothing in the compute leg waits on the host) and download of unit i - 1 (float32 deskewed volume
+    into one of two pinned landing blocks) on three streams.  Returns ms per unit and the per-leg timeline of the measured run."""
+    from biahub_amd.pipeline import run_overlapped, timeline_ms
+
+    probe = fast_deskew_zyx(rl(vol_host_u16.to(dev), 0, 1e-6), **DESKEW)
+    landing = [torch.empty(probe.shape, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+    del probe
+    count = [0]
+
+    def download(t):
+        buf = landing[count[0] % 2]
+        count[0] += 1
+        buf.copy_(t, non_blocking=True)
+        return buf
+
+    def run(rows):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in run_overlapped(range(n_units), lambda i: vol_host_u16.to(dev, non_blocking=True),
+                                lambda d: fast_deskew_zyx(rl(d, iterations, 1e-6), **DESKEW), download, dev, timeline=rows):
+            pass
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n_units
+
+    was_timing = ctx.timing
+    ctx.set_timing(False)  # the library's event timing reads its events back on the host: a stall inside the compute leg
+    try:
+        run(None)
+        rows = []
+        per_unit = run(rows)
+        tl = timeline_ms(rows)
+    finally:
+        ctx.set_timing(was_timing)
+    del landing
+    legs = {"h2d_ms": float(np.mean([r[1] - r[0] for r in tl])), "compute_ms": float(np.mean([r[3] - r[2] for r in tl])),
+            "d2h_ms": float(np.mean([r[5] - r[4] for r in tl]))}
+    return per_unit, tl, legs
+
+
+def end_to_end(vol_host_u16, psf, rl, iterations, dev, ctx):
     """What the reference's operator boundary costs beside the resident figure (biahub/deskew.py:578-579: the worker uploads
     the volume and takes the result back): uint16 camera stack in pinned host memory -> H2D -> R-L + deskew -> float32
     result D2H into a pinned block, through the adapters' own transfer helpers.  PCIe-bound, never `value`."""
@@ -215,7 +282,7 @@ def end_to_end(vol_host_u16, psf, iterations, dev):
         d = vol_host_u16.to(dev, non_blocking=False)           # 2 B/voxel across PCIe
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
-        out = fast_deskew_zyx(richardson_lucy(d, psf, iterations, 1e-6), **DESKEW)
+        out = fast_deskew_zyx(rl(d, iterations, 1e-6), **DESKEW)
         torch.cuda.synchronize(dev)
         t2 = time.perf_counter()
         host = to_host(out)                                    # 4 B/voxel of the deskewed volume, pinned destination
@@ -233,38 +300,35 @@ def end_to_end(vol_host_u16, psf, iterations, dev):
     # the same units through biahub_amd.pipeline.run_overlapped: upload of unit i + 1, compute of unit i and download of unit
     # i - 1 on three streams (what a plate job on one GPU can do; the reference's worker is the serial form above)
     try:
-        from biahub_amd.pipeline import run_overlapped
-
-        probe = fast_deskew_zyx(richardson_lucy(vol_host_u16.to(dev), psf, 0, 1e-6), **DESKEW)
-        landing = [torch.empty(probe.shape, dtype=torch.float32, pin_memory=True) for _ in range(2)]
-        del probe
-        n_units = 8
-        count = [0]
-
-        def download(t):
-            buf = landing[count[0] % 2]
-            count[0] += 1
-            buf.copy_(t, non_blocking=True)
-            return buf
-
-        def run():
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in run_overlapped(range(n_units), lambda i: vol_host_u16.to(dev, non_blocking=True),
-                                    lambda d: fast_deskew_zyx(richardson_lucy(d, psf, iterations, 1e-6), **DESKEW), download, dev):
-                pass
-            torch.cuda.synchronize(dev)
-            return (time.perf_counter() - t0) / n_units
-
-        run()
-        per_unit = run()
-        res["overlapped"] = {"ms_per_unit": per_unit * 1e3, "voxels_per_s": V / per_unit, "units": n_units,
+        per_unit, tl, legs = overlapped_units(vol_host_u16, rl, iterations, dev, ctx)
+        res["overlapped"] = {"ms_per_unit": per_unit * 1e3, "voxels_per_s": V / per_unit, "units": len(tl),
+                             "legs_while_overlapped": legs, "ratio_to_compute_leg": per_unit * 1e3 / (comp * 1e3),
+                             "timeline_ms": tl,
                              "note": "biahub_amd.pipeline.run_overlapped: H2D / compute / D2H of consecutive units on three streams, "
-                                     "two pinned landing blocks; wall time of the batch / units"}
-        del landing
+                                     "two pinned landing blocks, prepared R-L handle (no host synchronisation in the compute leg); "
+                                     "wall time of the batch / units; timeline rows = [h2d0, h2d1, compute0, compute1, d2h0, d2h1] "
+                                     "per unit, ms since the first upload started"}
     except RuntimeError as e:  # pinned memory for two 17-GB landing blocks not available on this host
         res["overlapped"] = {"skipped": str(e)[:200]}
     return res
+
+
+def rccl_evidence(dev, world):
+    """Every rank's GPU as the collective library sees the job: device name and PCI bus id of each rank, all_gathered over the
+    process group bench.py runs its barrier on (RCCL at N > 1).  N ranks on fewer than N distinct GPUs is an error unless the
+    run is a declared rehearsal (BH_DIST_BACKEND=gloo wraps ranks onto the cards there are)."""
+    import torch.distributed as dist
+
+    props = torch.cuda.get_device_properties(dev)
+    total = props.total_memory  # the bus id distinguishes the cards of one node; the name alone is the same for all eight
+    bus = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+    mine = {"rank": parallel.world_info()[0], "device_index": int(dev.index), "name": props.name, "pci_bus_id": bus,
+            "uuid": str(getattr(props, "uuid", "")), "hbm_gb": round(total / 1e9, 1)}
+    rows = parallel.gather_objects(mine)
+    backend = dist.get_backend() if dist.is_initialized() else "none (single process)"
+    distinct = len({r["pci_bus_id"] for r in rows})
+    return {"world": world, "backend": "rccl (torch 'nccl')" if backend == "nccl" else backend, "devices": rows,
+            "distinct_gpus": distinct}
 
 
 def main():
@@ -277,6 +341,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-ops", action="store_true")
+    ap.add_argument("--host-fed", choices=["auto", "on", "off"], default="auto",
+                    help="after the resident measurement every rank also runs the overlapped host-fed pipeline (pinned uint16 in, "
+                         "pinned float32 out) so that host-memory / PCIe contention between ranks shows in the N>1 line; auto = on for N>1")
+    ap.add_argument("--host-fed-units", type=int, default=4)
     args = ap.parse_args()
 
     rank, local_rank, world = parallel.world_info()
@@ -286,6 +354,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     parallel.init("nccl", dev)  # RCCL; used only for the timing barrier / max-over-ranks, never on the data path
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    rccl = rccl_evidence(dev, world)  # all_gather over the process group: N ranks must sit on N distinct GPUs
+    rehearsal = os.environ.get("BH_DIST_BACKEND") == "gloo"
+    if rccl["distinct_gpus"] != world and not rehearsal:
+        if rank == 0:
+            print(json.dumps({"error": "ranks share GPUs", "rccl": rccl}), flush=True)
+        sys.exit(3)
     # one synthetic position per rank and step: position index = rank (round-robin shard of a `world`-position plate)
     my_positions = parallel.shard_positions(range(world), rank, world)
     assert my_positions == [rank]
@@ -301,11 +375,14 @@ def main():
     ctx = get_context(dev)
     ctx.set_timing(True)
     nstep = [0]
+    # the transfer function of the plate's PSF is built once (the reference: biahub/deconvolve.py:140-149), outside the timed
+    # region; every step applies it (bh_richardson_lucy_apply: no host synchronisation of its own)
+    rl_prepared = PreparedRichardsonLucy(psf, shape, dev)
 
     def step():
         vol = vols[nstep[0] % len(vols)]
         nstep[0] += 1
-        rl = richardson_lucy(vol, psf, args.iterations, 1e-6)
+        rl = rl_prepared(vol, args.iterations, 1e-6)
         return fast_deskew_zyx(rl, **DESKEW)
 
     def fence():
@@ -330,6 +407,24 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     dt = parallel.max_over_ranks(dt, dev)
+
+    # host-fed leg on EVERY rank (N > 1 by default): each rank pipelines units from its own pinned uint16 block into its own
+    # pinned float32 blocks — the one thing that can break 8-GPU scaling (8 x 57 GB/s of D2H into one host) is in the line
+    host_fed = None
+    if args.host_fed == "on" or (args.host_fed == "auto" and world > 1):
+        try:
+            host = torch.empty(shape, dtype=torch.uint16, pin_memory=True)
+            host.copy_(vols[0].to(torch.uint16))
+            fence()
+            per_unit, tl, legs = overlapped_units(host, rl_prepared, args.iterations, dev, ctx, n_units=args.host_fed_units)
+            del host
+            slowest = parallel.max_over_ranks(per_unit, dev)
+            host_fed = {"ms_per_unit_slowest_rank": slowest * 1e3, "voxels_per_s": world * V / slowest,
+                        "units_per_rank": args.host_fed_units, "legs_while_overlapped_rank0": legs,
+                        "note": "every rank: pinned uint16 H2D -> R-L + deskew -> float32 D2H into pinned blocks, three streams "
+                                "(biahub_amd.pipeline.run_overlapped); all ranks at once, max over ranks; never `value`"}
+        except RuntimeError as e:
+            host_fed = {"skipped": str(e)[:200]}
 
     if rank == 0:
         rl_iter_s = float(np.mean(rl_ms)) / 1e3
@@ -356,8 +451,8 @@ def main():
             "config": {
                 "workload": f"1 position/GPU: R-L {args.iterations} it (PSF {PSF_SHAPE}) then deskew "
                             f"{shape}->{tuple(out_shape)} (36.17 deg, 0.371, N=3, fill mean), input resident in HBM; two "
-                            "distinct positions alternate over the steps; the OTF is cached across positions of one PSF "
-                            "(built once, in warm-up: a plate shares its PSF), so it is outside the timed region",
+                            "distinct positions alternate over the steps; the transfer function of the plate's PSF is prepared "
+                            "once before the timed region (bh_richardson_lucy_create, as the reference computes it once per plate)",
                 "raw_shape_zyx": list(shape),
                 "deskewed_shape_zyx": list(out_shape),
                 "positions_per_step": world,
@@ -396,7 +491,12 @@ def main():
                 "fill_passes_ms": fill_s * 1e3,
             },
             "workspace_gb": ctx.workspace_bytes() / 1e9,
+            "rl_handle": {"backend": rl_prepared.backend, "box": list(rl_prepared.box), "otf_is_real": rl_prepared.otf_is_real,
+                          "otf_gb": rl_prepared.otf_bytes / 1e9},
+            "rccl": rccl,
         }
+        if host_fed is not None:
+            result["end_to_end_per_rank"] = host_fed
         if not args.no_ops and world == 1:
             del vols[1:]
             ctx.release_workspace()
@@ -405,7 +505,7 @@ def main():
             del vols[1:]
             host = torch.empty(shape, dtype=torch.uint16, pin_memory=True)
             host.copy_(vols[0].to(torch.uint16))
-            result["end_to_end"] = end_to_end(host, psf, args.iterations, dev)
+            result["end_to_end"] = end_to_end(host, psf, rl_prepared, args.iterations, dev, ctx)
             del host
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             result["cpu_baseline"] = cpu_baseline(args.iterations)

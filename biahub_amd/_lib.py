@@ -69,6 +69,10 @@ SIGNATURES = {
     "bh_fluorescence_transfer_function_3d": (_int, [_vp, _i64, _i64, _i64, _f64, _f64, _f64, _i64, _f64, _f64, _vp]),
     "bh_fourier_central_cuboid": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64]),
     "bh_richardson_lucy": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _f32, _vp]),
+    "bh_richardson_lucy_create": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, C.POINTER(_vp)]),
+    "bh_richardson_lucy_apply": (_int, [_vp, _vp, _vp, _int, _f32, _vp]),
+    "bh_richardson_lucy_destroy": (_int, [_vp]),
+    "bh_richardson_lucy_info": (_int, [_vp, C.POINTER(_i64), C.POINTER(_int), C.POINTER(_int), C.POINTER(C.c_uint64)]),
     "bh_phase_cross_corr": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, C.POINTER(_f32), _vp]),
     "bh_image_stats": (_int, [_vp, _vp, _i64, _i64, _i64, C.POINTER(_f64)]),
     "bh_smooth_shrink": (_int, [_vp, _vp, _i64, _i64, _i64, C.POINTER(_f64), C.POINTER(_int), _vp, C.POINTER(_i64),

@@ -128,4 +128,9 @@ struct ScopedTimer {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Gigabyte blocks that prepared handles own (staged inverse filters, Richardson-Lucy transfer functions): released blocks are
+// kept per (device, size) for the next handle of that size, bh_inverse_filter_trim() returns them to the driver (invtf.hip).
+void* filter_pool_take(int device, size_t bytes);
+void filter_pool_give(int device, size_t bytes, void* p);
+
 }  // namespace bh

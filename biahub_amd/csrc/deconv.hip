@@ -457,7 +457,7 @@ int fftconv_apply(bh_ctx* ctx, const ConvPlan& pl, const float* in, const cf* ot
 int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, const cf* otf, bool otf_real, cf* spec, int iterations,
                             float eps, float* est);
 int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, const float* est_p, const float* d_p, const cf* otf,
-                                cf* spec, float eps, float* corr_p);
+                                bool otf_real, cf* spec, float eps, float* corr_p);
 int fftconv_forward(bh_ctx* ctx, const ConvPlan& pl, const float* in, cf* spec);
 int fftconv_inverse(bh_ctx* ctx, const ConvPlan& pl, cf* spec, float* out);
 int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t bytes, cf** spec);
@@ -525,8 +525,47 @@ static int stage_rl_psf(bh_ctx* ctx, const float* psf, int64_t pz, int64_t py, i
     return BH_OK;
 }
 
+// The iterations of Richardson-Lucy on the fused engine with the transfer function in hand (`otf`: NS complex, or NS floats
+// when `otf_real`): spectrum scratch (auditioned once per allocation), optional event timing, no host synchronisation
+// otherwise.  Shared by the one-shot entry and the prepared handle.
+static int rl_engine_run(bh_ctx* ctx, ConvPlan* pl, const float* d, const void* otf, bool otf_real, int iterations, float eps,
+                         float* out) {
+    const size_t NS = fftconv_spectrum_elems(*pl);
+    cf* spec;
+    BH_TRY(get_scratch(ctx, "fc_spec", NS * sizeof(cf), (void**)&spec));
+    if (spec != ctx->spec_tuned) {  // a new allocation: audition it (fftconv_tune_spectrum)
+        Scratch& sc = ctx->scratch["fc_spec"];
+        // the audition may free the allocation it was handed and keep another one: the scratch table must follow it on the
+        // error path too, or the next get_scratch("fc_spec") hands out a freed pointer
+        const int tune_rc = fftconv_tune_spectrum(ctx, *pl, out, sc.bytes, &spec);
+        sc.ptr = spec;
+        ctx->spec_tuned = spec;
+        BH_TRY(tune_rc);
+    }
+    hipStream_t s = ctx->stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+        BH_CHECK_HIP(hipEventCreate(&e0));
+        BH_CHECK_HIP(hipEventCreate(&e1));
+        BH_CHECK_HIP(hipEventRecord(e0, s));
+    }
+    BH_TRY(fftconv_richardson_lucy(ctx, *pl, d, reinterpret_cast<const cf*>(otf), otf_real, spec, iterations, eps, out));
+    if (e0) {
+        BH_CHECK_HIP(hipEventRecord(e1, s));
+        BH_CHECK_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        BH_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ctx->ms_override[T_RL_ITER] = ms / iterations;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    return BH_OK;
+}
+
 // Richardson-Lucy on the fused engine: per iteration two 5-pass convolutions, the divide and the
-// multiply/clip ride in the inverse X passes.
+// multiply/clip ride in the inverse X passes.  One-shot form: the transfer function is cached in the context and validated
+// against the PSF's bytes on every call (one small kernel, a 24-byte read-back and a stream synchronisation);
+// bh_richardson_lucy_create / _apply is the form without that per-call stall.
 static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, int64_t pz, int64_t py, int64_t px,
                                  int64_t Z, int64_t Y, int64_t X, int iterations, float eps, float* out) {
     const int64_t V = Z * Y * X;
@@ -539,18 +578,8 @@ static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, 
     BH_TRY(fftconv_plan(ctx, Z, Y, X, &pl));
     const size_t NS = fftconv_spectrum_elems(*pl);
     float* real = nullptr;
-    cf *spec, *otf;
+    cf* otf;
     double* psum;
-    BH_TRY(get_scratch(ctx, "fc_spec", NS * sizeof(cf), (void**)&spec));
-    if (spec != ctx->spec_tuned && iterations > 0) {  // a new allocation: audition it (fftconv_tune_spectrum)
-        Scratch& sc = ctx->scratch["fc_spec"];
-        // the audition may free the allocation it was handed and keep another one: the scratch table must follow it on the
-        // error path too, or the next get_scratch("fc_spec") hands out a freed pointer
-        const int tune_rc = fftconv_tune_spectrum(ctx, *pl, out, sc.bytes, &spec);
-        sc.ptr = spec;
-        ctx->spec_tuned = spec;
-        BH_TRY(tune_rc);
-    }
     BH_TRY(get_scratch(ctx, "fc_otf", NS * sizeof(cf), (void**)&otf));
     BH_TRY(get_scratch(ctx, "rl_psum", 64, (void**)&psum));
     hipStream_t s = ctx->stream;
@@ -599,25 +628,7 @@ static int richardson_lucy_fused(bh_ctx* ctx, const float* d, const float* psf, 
         for (int i = 0; i < 6; ++i) ctx->otf_dims[i] = dims[i];
         ctx->otf_valid = true;
     }
-    if (iterations <= 0) hipLaunchKernelGGL(clip_copy_kernel, grid_for(ctx, V), dim3(256), 0, s, d, out, V);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->timing && iterations > 0) {
-        BH_CHECK_HIP(hipEventCreate(&e0));
-        BH_CHECK_HIP(hipEventCreate(&e1));
-        BH_CHECK_HIP(hipEventRecord(e0, s));
-    }
-    BH_TRY(fftconv_richardson_lucy(ctx, *pl, d, real_otf ? reinterpret_cast<const cf*>(otf_real) : otf, real_otf, spec, iterations,
-                                   eps, out));
-    if (e0) {
-        BH_CHECK_HIP(hipEventRecord(e1, s));
-        BH_CHECK_HIP(hipEventSynchronize(e1));
-        float ms = 0;
-        BH_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
-        ctx->ms_override[T_RL_ITER] = ms / iterations;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-    }
-    return BH_OK;
+    return rl_engine_run(ctx, pl, d, real_otf ? (const void*)otf_real : (const void*)otf, real_otf, iterations, eps, out);
 }
 
 static bool is_smooth(int64_t n) {  // only the radices hipFFT has native kernels for
@@ -664,35 +675,20 @@ static bool engine_pad_box(const int64_t N[3], const int64_t K[3], int64_t P[3])
 // ratio is too, and the correlation that follows is the LINEAR correlation of the zero-padded ratio; its tails (off below,
 // K/2 above, inside the box because P >= N + K - 1) are folded back — the circular correlation at size N the definition
 // asks for — by the kernel that also multiplies, clips and rebuilds the wrap-extension for the next iteration.
-static int richardson_lucy_engine_padded(bh_ctx* ctx, const float* d, const float* psf, int64_t pz, int64_t py, int64_t px,
-                                         int64_t Z, int64_t Y, int64_t X, const int64_t P[3], int iterations, float eps,
-                                         float* out) {
-    const int64_t N[3] = {Z, Y, X}, K[3] = {pz, py, px};
-    const int64_t V = Z * Y * X, VP = P[0] * P[1] * P[2];
+// rl_padded_run: the iterations with the transfer function of the box in hand (NS complex, or NS floats when `otf_real`); no
+// host synchronisation unless the context is timing.
+static int rl_padded_run(bh_ctx* ctx, ConvPlan* pl, const float* d, const void* otf, bool otf_real, const int64_t N[3],
+                         const int64_t K[3], const int64_t P[3], int iterations, float eps, float* out) {
+    const int64_t VP = P[0] * P[1] * P[2];
     hipStream_t s = ctx->stream;
-    if (iterations == 0) {
-        hipLaunchKernelGGL(clip_copy_kernel, grid_for(ctx, V), dim3(256), 0, s, d, out, V);
-        BH_CHECK_HIP(hipGetLastError());
-        return BH_OK;
-    }
-    ConvPlan* pl;
-    BH_TRY(fftconv_plan(ctx, P[0], P[1], P[2], &pl));
     const size_t NS = fftconv_spectrum_elems(*pl);
     float *a, *b, *c, *dp;
-    cf *spec, *otf;
-    double* psum;
+    cf* spec;
     BH_TRY(get_scratch(ctx, "fft_real", VP * sizeof(float), (void**)&a));
     BH_TRY(get_scratch(ctx, "rl_real2", VP * sizeof(float), (void**)&b));
     BH_TRY(get_scratch(ctx, "rl_corr_p", VP * sizeof(float), (void**)&c));
     BH_TRY(get_scratch(ctx, "rl_data_p", VP * sizeof(float), (void**)&dp));
     BH_TRY(get_scratch(ctx, "fc_spec", NS * sizeof(cf), (void**)&spec));
-    BH_TRY(get_scratch(ctx, "fc_otf", NS * sizeof(cf), (void**)&otf));
-    BH_TRY(get_scratch(ctx, "rl_psum", 64, (void**)&psum));
-    ctx->otf_valid = false;  // fc_otf is overwritten: the cache of richardson_lucy_fused no longer holds
-    ScopedTimer timer(ctx, T_RL_TOTAL);
-    BH_TRY(stage_rl_psf(ctx, psf, pz, py, px, P[0], P[1], P[2], a, psum));
-    BH_TRY(fftconv_make_otf(ctx, *pl, a, otf));
-
     RemapDims pad, crop;
     FoldBox fold;
     for (int i = 0; i < 3; ++i) {
@@ -722,7 +718,7 @@ static int richardson_lucy_engine_padded(bh_ctx* ctx, const float* d, const floa
     }
     float *cur = a, *nxt = b;
     for (int it = 0; it < iterations; ++it) {
-        BH_TRY(fftconv_rl_iteration_padded(ctx, *pl, cur, dp, otf, spec, eps, c));
+        BH_TRY(fftconv_rl_iteration_padded(ctx, *pl, cur, dp, reinterpret_cast<const cf*>(otf), otf_real, spec, eps, c));
         hipLaunchKernelGGL(fold_update_rewrap_kernel, grid2(fold.P), dim3(256), 0, s, (const float*)c, (const float*)cur, nxt, fold);
         std::swap(cur, nxt);
     }
@@ -738,6 +734,33 @@ static int richardson_lucy_engine_padded(bh_ctx* ctx, const float* d, const floa
         (void)hipEventDestroy(e1);
     }
     return BH_OK;
+}
+
+static int richardson_lucy_engine_padded(bh_ctx* ctx, const float* d, const float* psf, int64_t pz, int64_t py, int64_t px,
+                                         int64_t Z, int64_t Y, int64_t X, const int64_t P[3], int iterations, float eps,
+                                         float* out) {
+    const int64_t N[3] = {Z, Y, X}, K[3] = {pz, py, px};
+    const int64_t V = Z * Y * X, VP = P[0] * P[1] * P[2];
+    hipStream_t s = ctx->stream;
+    if (iterations == 0) {
+        hipLaunchKernelGGL(clip_copy_kernel, grid_for(ctx, V), dim3(256), 0, s, d, out, V);
+        BH_CHECK_HIP(hipGetLastError());
+        return BH_OK;
+    }
+    ConvPlan* pl;
+    BH_TRY(fftconv_plan(ctx, P[0], P[1], P[2], &pl));
+    const size_t NS = fftconv_spectrum_elems(*pl);
+    float* a;
+    cf* otf;
+    double* psum;
+    BH_TRY(get_scratch(ctx, "fft_real", VP * sizeof(float), (void**)&a));
+    BH_TRY(get_scratch(ctx, "fc_otf", NS * sizeof(cf), (void**)&otf));
+    BH_TRY(get_scratch(ctx, "rl_psum", 64, (void**)&psum));
+    ctx->otf_valid = false;  // fc_otf is overwritten: the cache of richardson_lucy_fused no longer holds
+    ScopedTimer timer(ctx, T_RL_TOTAL);
+    BH_TRY(stage_rl_psf(ctx, psf, pz, py, px, P[0], P[1], P[2], a, psum));
+    BH_TRY(fftconv_make_otf(ctx, *pl, a, otf));
+    return rl_padded_run(ctx, pl, d, otf, false, N, K, P, iterations, eps, out);
 }
 
 // Which transform box and back-end Richardson-Lucy uses for a shape (host logic only; bh_richardson_lucy_plan exports it).
@@ -982,6 +1005,130 @@ int bh_richardson_lucy_plan(int64_t pz, int64_t py, int64_t px, int64_t Z, int64
     BH_REQUIRE(box != nullptr && backend != nullptr, "NULL argument");
     BH_REQUIRE(pz > 0 && py > 0 && px > 0 && pz <= Z && py <= Y && px <= X, "PSF must fit inside the volume");
     *backend = rl_plan(pz, py, px, Z, Y, X, box);
+    return BH_OK;
+}
+
+// ---- prepared Richardson-Lucy: the transfer function built once, applied to any number of volumes ----
+// The reference computes the transfer function once per plate and hands it to every (position, t, c) unit
+// (biahub/deconvolve.py:140-149, 183-191).  `create` does that part — normalise, pad, centre and transform the PSF at the box
+// bh_richardson_lucy_plan picks, decide whether the transfer function is real — and may synchronise; `apply` only enqueues
+// kernels on the context's stream (no read-back, no host synchronisation unless the context is timing), so the legs of an
+// upload / compute / download pipeline overlap.
+struct bh_rl {
+    int device = 0;
+    int backend = 0;
+    int64_t K[3] = {0, 0, 0}, N[3] = {0, 0, 0}, box[3] = {0, 0, 0};
+    bh::ConvPlan* plan = nullptr;
+    void* otf = nullptr;       // engine back-ends: NS complex, or NS floats when otf_real (owned, pooled on destroy)
+    size_t otf_bytes = 0;
+    bool otf_real = false;
+    float* psf = nullptr;      // library back-end: the PSF itself (the one-shot path rebuilds its library transfer function)
+};
+
+int bh_richardson_lucy_create(bh_ctx* ctx, const float* psf, int64_t pz, int64_t py, int64_t px, int64_t Z, int64_t Y,
+                              int64_t X, bh_rl** out) {
+    BH_REQUIRE(ctx && psf && out, "NULL argument");
+    BH_REQUIRE(pz > 0 && py > 0 && px > 0 && pz <= Z && py <= Y && px <= X, "PSF must fit inside the volume");
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    *out = nullptr;
+    bh_rl* h = new bh_rl();
+    h->device = ctx->device;
+    h->K[0] = pz, h->K[1] = py, h->K[2] = px;
+    h->N[0] = Z, h->N[1] = Y, h->N[2] = X;
+    h->backend = rl_plan(pz, py, px, Z, Y, X, h->box);
+    hipStream_t s = ctx->stream;
+    auto fail = [&](int rc) {
+        (void)bh_richardson_lucy_destroy(h);
+        return rc;
+    };
+    const size_t psf_bytes = (size_t)(pz * py * px) * sizeof(float);
+    if (h->backend == BH_RL_LIBRARY) {
+        if (hipMalloc((void**)&h->psf, psf_bytes) != hipSuccess) return (set_error("out of device memory (PSF copy)"), fail(BH_ERR_HIP));
+        if (hipMemcpyAsync(h->psf, psf, psf_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return (set_error("PSF copy failed"), fail(BH_ERR_HIP));
+        *out = h;
+        return BH_OK;
+    }
+    int rc = fftconv_plan(ctx, h->box[0], h->box[1], h->box[2], &h->plan);
+    if (rc != BH_OK) return fail(rc);
+    const size_t NS = fftconv_spectrum_elems(*h->plan);
+    const int64_t VP = h->box[0] * h->box[1] * h->box[2];
+    // real transfer function?  (a PSF with odd extents that equals its point mirror bit for bit: richardson_lucy_fused)
+    double* psum;
+    if ((rc = get_scratch(ctx, "rl_psum", 64, (void**)&psum)) != BH_OK) return fail(rc);
+    unsigned long long* dhash = reinterpret_cast<unsigned long long*>(psum) + 1;
+    unsigned long long hv[3] = {0, 0, 0};
+    hipLaunchKernelGGL(content_hash_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(psf), pz * py * px,
+                       (const uint32_t*)nullptr, dhash);
+    if (hipMemcpyAsync(hv, dhash, sizeof(hv), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return (set_error("PSF symmetry check failed"), fail(BH_ERR_HIP));
+    h->otf_real = (pz & 1) && (py & 1) && (px & 1) && hv[2] == 1ull && getenv("BH_RL_COMPLEX_OTF") == nullptr;
+    h->otf_bytes = NS * (h->otf_real ? sizeof(float) : sizeof(cf));
+    if ((h->otf = filter_pool_take(ctx->device, h->otf_bytes)) == nullptr &&
+        hipMalloc(&h->otf, h->otf_bytes) != hipSuccess) {
+        h->otf = nullptr;
+        (void)hipGetLastError();
+        return (set_error("out of device memory (%zu bytes for the transfer function)", h->otf_bytes), fail(BH_ERR_HIP));
+    }
+    // the padded PSF and (for the real form) the complex transfer function are transients in the context's scratch
+    float* real;
+    cf* otf_c = reinterpret_cast<cf*>(h->otf);
+    if ((rc = get_scratch(ctx, "fft_real", VP * sizeof(float), (void**)&real)) != BH_OK) return fail(rc);
+    if (h->otf_real) {
+        if ((rc = get_scratch(ctx, "fc_otf", NS * sizeof(cf), (void**)&otf_c)) != BH_OK) return fail(rc);
+        ctx->otf_valid = false;  // fc_otf is overwritten: the one-shot path's cache no longer holds
+    }
+    if ((rc = stage_rl_psf(ctx, psf, pz, py, px, h->box[0], h->box[1], h->box[2], real, psum)) != BH_OK) return fail(rc);
+    if ((rc = fftconv_make_otf(ctx, *h->plan, real, otf_c)) != BH_OK) return fail(rc);
+    if (h->otf_real) {
+        hipLaunchKernelGGL(real_part_kernel, grid_for(ctx, (int64_t)NS), dim3(256), 0, s, otf_c, reinterpret_cast<float*>(h->otf),
+                           (int64_t)NS);
+        if (hipGetLastError() != hipSuccess) return (set_error("real_part_kernel launch failed"), fail(BH_ERR_HIP));
+    }
+    *out = h;
+    return BH_OK;
+}
+
+int bh_richardson_lucy_apply(bh_ctx* ctx, const bh_rl* h, const float* in, int iterations, float eps, float* out) {
+    BH_REQUIRE(ctx && h && in && out, "NULL argument");
+    BH_REQUIRE(iterations >= 0, "iterations must be >= 0");
+    BH_REQUIRE(ctx->device == h->device, "the handle belongs to device %d, the context to device %d", h->device, ctx->device);
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    const int64_t Z = h->N[0], Y = h->N[1], X = h->N[2], V = Z * Y * X;
+    hipStream_t s = ctx->stream;
+    const float* d = in;
+    if (in == out) {  // the estimate overwrites `out`; keep the data term
+        float* dcopy;
+        BH_TRY(get_scratch(ctx, "rl_data", V * sizeof(float), (void**)&dcopy));
+        BH_CHECK_HIP(hipMemcpyAsync(dcopy, in, V * sizeof(float), hipMemcpyDeviceToDevice, s));
+        d = dcopy;
+    }
+    if (h->backend == BH_RL_LIBRARY)
+        return bh_richardson_lucy(ctx, d, h->psf, h->K[0], h->K[1], h->K[2], Z, Y, X, iterations, eps, out);
+    if (iterations == 0) {
+        hipLaunchKernelGGL(clip_copy_kernel, grid_for(ctx, V), dim3(256), 0, s, d, out, V);
+        BH_CHECK_HIP(hipGetLastError());
+        return BH_OK;
+    }
+    ScopedTimer timer(ctx, T_RL_TOTAL);
+    if (h->backend == BH_RL_ENGINE) return rl_engine_run(ctx, h->plan, d, h->otf, h->otf_real, iterations, eps, out);
+    return rl_padded_run(ctx, h->plan, d, h->otf, h->otf_real, h->N, h->K, h->box, iterations, eps, out);
+}
+
+int bh_richardson_lucy_destroy(bh_rl* h) {
+    if (!h) return BH_OK;
+    if (h->otf) filter_pool_give(h->device, h->otf_bytes, h->otf);
+    if (h->psf) (void)hipFree(h->psf);
+    delete h;
+    return BH_OK;
+}
+
+int bh_richardson_lucy_info(const bh_rl* h, int64_t box[3], int* backend, int* otf_is_real, uint64_t* otf_bytes) {
+    BH_REQUIRE(h != nullptr, "NULL argument");
+    if (box)
+        for (int a = 0; a < 3; ++a) box[a] = h->box[a];
+    if (backend) *backend = h->backend;
+    if (otf_is_real) *otf_is_real = h->otf_real ? 1 : 0;
+    if (otf_bytes) *otf_bytes = (uint64_t)h->otf_bytes;
     return BH_OK;
 }
 

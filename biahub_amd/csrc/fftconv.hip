@@ -813,6 +813,7 @@ struct ConvPlan {
     // wave-private X passes (fftconv_xw.inc) for rows of 1024 / 2048 voxels: their tables, and the stored column of every
     // bit-reversed position (they keep the spectrum row in their own column order)
     bool xw = false;
+    bool x3 = false;  // rows of 1536 / 3072 voxels: the radix-3 kernels of fftconv_x3.inc (same role, tables and column map)
     cf* xw_tab = nullptr;
     int* xw_col = nullptr;
     // register-stage column passes (fftconv_colw.inc) for columns of 256 / 512 / 1024 points: their twiddle tables
@@ -838,6 +839,7 @@ namespace xr8 {
 }  // namespace xr8
 
 #include "fftconv_xw.inc"
+#include "fftconv_x3.inc"
 #include "fftconv_colw.inc"
 #include "fftconv_colz.inc"
 
@@ -889,7 +891,9 @@ static int upload(const std::vector<cf>& h, cf** dptr) {
 int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     std::lock_guard<std::mutex> lock(g_plans_mu);
     // BH_FC_XW=0 keeps the tile-based X passes for every shape (A/B switch, read per call: plans of both kinds can coexist)
-    const bool xw_on = !(getenv("BH_FC_XW") && atoi(getenv("BH_FC_XW")) == 0) && (X == 512 || X == 1024 || X == 2048) && ((Y / 2) % 4) == 0;
+    // rows of 512 / 1024 / 2048 voxels: fftconv_xw.inc; of 1536 / 3072: fftconv_x3.inc (BH_FC_X3=0 keeps those on the tile kernels)
+    const bool x3_rows = (X == 1536 || X == 3072) && !(getenv("BH_FC_X3") && atoi(getenv("BH_FC_X3")) == 0);
+    const bool xw_on = !(getenv("BH_FC_XW") && atoi(getenv("BH_FC_XW")) == 0) && (X == 512 || X == 1024 || X == 2048 || x3_rows) && ((Y / 2) % 4) == 0;
     auto key = std::make_tuple(ctx->device * 2 + (xw_on ? 1 : 0), Z, Y, X);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) {
@@ -978,7 +982,12 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     }
     if (xw_on) {
         std::vector<int> col;
-        if (X == 2048) xw::make_tables<10>(h, col); else if (X == 1024) xw::make_tables<9>(h, col); else xw::make_tables<8>(h, col);
+        if (X == 3072) x3::make_tables<9>(h, col);
+        else if (X == 1536) x3::make_tables<8>(h, col);
+        else if (X == 2048) xw::make_tables<10>(h, col);
+        else if (X == 1024) xw::make_tables<9>(h, col);
+        else xw::make_tables<8>(h, col);
+        pl.x3 = X == 3072 || X == 1536;
         BH_TRY(upload(h, &pl.xw_tab));
         BH_CHECK_HIP(hipMalloc(&pl.xw_col, col.size() * sizeof(int)));
         BH_CHECK_HIP(hipMemcpy(pl.xw_col, col.data(), col.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1153,6 +1162,28 @@ static int launch_xw_m(bh_ctx* ctx, const xw::Params& p, int mode) {
     }
 }
 
+template <int LOGL>
+static int launch_x3_m(bh_ctx* ctx, const xw::Params& p, int mode) {
+    using G = x3::Geo<LOGL>;
+    const long npairs = (long)p.Z * (p.Y / 2);
+    const int grid = (int)std::min<long>(ceil_div(npairs, (long)x3::NW * G::PAIRS), ctx->num_cus);
+    auto run = [&](auto kern) -> int {
+        BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)G::LDS_BYTES));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(x3::NT), G::LDS_BYTES, ctx->stream, p);
+        BH_CHECK_HIP(hipGetLastError());
+        return BH_OK;
+    };
+    switch (mode) {
+        case xw::FWD: return run(x3::x3_kernel<LOGL, xw::FWD>);
+        case xw::INV_STORE: return run(x3::x3_kernel<LOGL, xw::INV_STORE>);
+        case xw::INV_RATIO: return run(x3::x3_kernel<LOGL, xw::INV_RATIO>);
+        case xw::INV_UPDATE: return run(x3::x3_kernel<LOGL, xw::INV_UPDATE>);
+        case xw::FUSED_RATIO: return run(x3::x3_kernel<LOGL, xw::FUSED_RATIO>);
+        default: return run(x3::x3_kernel<LOGL, xw::FUSED_UPDATE>);
+    }
+}
+
 static int launch_xw(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, const float* in, cf* S, float* out,
                      const float* aux, float eps, bool fuse_fwd, const double* norm_mean = nullptr) {
     xw::Params p;
@@ -1171,6 +1202,7 @@ static int launch_xw(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, con
                      : epi == XE_STORE ? xw::INV_STORE
                      : epi == XE_RATIO ? (fuse_fwd ? xw::FUSED_RATIO : xw::INV_RATIO)
                                        : (fuse_fwd ? xw::FUSED_UPDATE : xw::INV_UPDATE);
+    if (pl.x3) return pl.d.M == 1536 ? launch_x3_m<9>(ctx, p, mode) : launch_x3_m<8>(ctx, p, mode);
     return pl.d.M == 1024 ? launch_xw_m<10>(ctx, p, mode) : (pl.d.M == 512 ? launch_xw_m<9>(ctx, p, mode) : launch_xw_m<8>(ctx, p, mode));
 }
 
@@ -1496,7 +1528,8 @@ int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t by
 // the caller folds its wrapped-around tails back, multiplies, and rebuilds est_p.  9 transform passes (8 when nothing is
 // padded and update -> forward can stay fused).
 int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, const float* est_p, const float* d_p, const cf* otf,
-                                cf* spec, float eps, float* corr_p) {
+                                bool otf_real, cf* spec, float eps, float* corr_p) {
+    const int COL_CONV = otf_real ? bh::COL_FILTER : bh::COL_CONV, COL_CORR = otf_real ? bh::COL_FILTER : bh::COL_CORR;
     BH_TRY(launch_x(ctx, pl, false, 0, est_p, spec, nullptr, nullptr, 0.f));
     BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec, nullptr, 1.f));
     BH_TRY(launch_col(ctx, pl, COL_CONV, true, spec, otf, 1.f));

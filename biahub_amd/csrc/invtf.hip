@@ -122,7 +122,7 @@ namespace bh {
 // they live until the process ends or bh_inverse_filter_trim() is called.
 static std::mutex g_filter_pool_mu;
 static std::map<std::pair<int, size_t>, std::vector<void*>> g_filter_pool;
-static void* filter_pool_take(int device, size_t bytes) {
+void* filter_pool_take(int device, size_t bytes) {
     std::lock_guard<std::mutex> lock(g_filter_pool_mu);
     auto it = g_filter_pool.find({device, bytes});
     if (it == g_filter_pool.end() || it->second.empty()) return nullptr;
@@ -130,7 +130,7 @@ static void* filter_pool_take(int device, size_t bytes) {
     it->second.pop_back();
     return p;
 }
-static void filter_pool_give(int device, size_t bytes, void* p) {
+void filter_pool_give(int device, size_t bytes, void* p) {
     std::lock_guard<std::mutex> lock(g_filter_pool_mu);
     g_filter_pool[{device, bytes}].push_back(p);
 }

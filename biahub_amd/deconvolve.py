@@ -142,6 +142,67 @@ def richardson_lucy(zyx, psf_zyx, iterations: int = 10, eps: float = 1e-6) -> to
     return out
 
 
+class PreparedRichardsonLucy:
+    """Richardson-Lucy with the transfer function of one PSF built once for one volume shape (``bh_richardson_lucy_create``)
+    and applied to any number of volumes — the shape of the reference's deconvolve, which computes the transfer function
+    once per plate and hands it to every (position, t, c) unit (biahub/deconvolve.py:140-149, 183-191).  A call only
+    enqueues kernels on the current stream: no read-back, no host synchronisation (the one-shot ``richardson_lucy`` validates
+    its cached transfer function against the PSF's bytes on every call), so an upload / compute / download pipeline overlaps.
+    """
+
+    def __init__(self, psf_zyx, zyx_shape, device="cuda"):
+        import ctypes
+
+        self.device = resolve_device(device)
+        psf, _ = _f32_device(psf_zyx, self.device)
+        if psf.ndim != 3 or len(zyx_shape) != 3:
+            raise ValueError("volume and psf must be 3-D")
+        self.shape = tuple(int(n) for n in zyx_shape)
+        self._ctx = get_context(self.device)
+        self._handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._ctx.lib.bh_richardson_lucy_create(self._ctx.handle, ptr(psf), *(int(k) for k in psf.shape),
+                                                               *self.shape, ctypes.byref(self._handle)))
+            torch.cuda.current_stream(self.device).synchronize()  # the PSF may be dropped by the caller from here on
+        box = (ctypes.c_int64 * 3)()
+        backend, is_real, nbytes = ctypes.c_int(), ctypes.c_int(), ctypes.c_uint64()
+        _lib.check(self._ctx.lib.bh_richardson_lucy_info(self._handle, box, ctypes.byref(backend), ctypes.byref(is_real),
+                                                         ctypes.byref(nbytes)))
+        self.box = tuple(int(b) for b in box)
+        self.backend = ("engine", "engine-padded", "library")[backend.value]
+        self.otf_is_real = bool(is_real.value)
+        self.otf_bytes = int(nbytes.value)
+
+    def __call__(self, zyx, iterations: int = 10, eps: float = 1e-6, out: torch.Tensor | None = None) -> torch.Tensor:
+        d, _ = _f32_device(zyx, self.device)
+        if tuple(d.shape) != self.shape:
+            raise ValueError(f"volume shape {tuple(d.shape)} != the shape this handle was prepared for {self.shape}")
+        ctx = get_context(self.device)
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty_like(d)
+            _lib.check(ctx.lib.bh_richardson_lucy_apply(ctx.handle, self._handle, ptr(d), int(iterations), float(eps), ptr(out)))
+        return out
+
+    def close(self) -> None:
+        if self._handle:
+            torch.cuda.synchronize(self.device)
+            _lib.check(self._ctx.lib.bh_richardson_lucy_destroy(self._handle))
+            self._handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 def richardson_lucy_plan(psf_shape_zyx, volume_shape_zyx) -> tuple[tuple[int, int, int], str]:
     """(transform box, back-end) ``richardson_lucy`` uses for a shape — "engine" (fused FFT engine at the volume's shape),
     "engine-padded" (the engine at a larger wrap-padded box) or "library" (hipFFT, 7-smooth pad-and-fold box if needed).
@@ -160,8 +221,25 @@ def richardson_lucy_czyx(czyx_raw_data: np.ndarray, psf_zyx: np.ndarray, iterati
                          device="cuda") -> np.ndarray:
     """CZYX numpy adapter with the reference's operator signature ``func(czyx, **kwargs)``."""
     dev = resolve_device(device)
-    psf, _ = _f32_device(psf_zyx, dev)
-    return np.stack([
-        to_host(richardson_lucy(_f32_device(zyx, dev)[0], psf, iterations, eps))
-        for zyx in np.asarray(czyx_raw_data)
-    ])
+    czyx = np.asarray(czyx_raw_data)
+    prep = _prepared_rl(psf_zyx, tuple(czyx.shape[-3:]), dev)
+    return np.stack([to_host(prep(_f32_device(zyx, dev)[0], iterations, eps)) for zyx in czyx])
+
+
+# The prepared handle of the PSF `richardson_lucy_czyx` was last called with (a plate job calls it once per (t, c) unit with
+# the same PSF array): keyed like _PREPARED by the identity of the object, its bytes' hash, the volume shape and the device.
+_PREPARED_RL: "dict[tuple, tuple]" = {}
+
+
+def _prepared_rl(psf_zyx, shape, dev) -> PreparedRichardsonLucy:
+    host = psf_zyx.cpu().numpy() if isinstance(psf_zyx, torch.Tensor) else np.asarray(psf_zyx)
+    key = (id(psf_zyx), tuple(host.shape), shape, str(dev), hash(host.tobytes()))
+    hit = _PREPARED_RL.get(key)
+    if hit is not None and hit[0] is psf_zyx:
+        return hit[1]
+    while len(_PREPARED_RL) >= _PREPARED_MAX:
+        old = _PREPARED_RL.pop(next(iter(_PREPARED_RL)))
+        old[1].close()
+    prep = PreparedRichardsonLucy(psf_zyx, shape, dev)
+    _PREPARED_RL[key] = (psf_zyx, prep)
+    return prep

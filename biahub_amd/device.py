@@ -55,6 +55,7 @@ class Context:
         _lib.check(self.lib.bh_ctx_create(index, None, C.byref(h)))
         self.handle = h
         self._stream = 0
+        self.timing = False
 
     def bind_stream(self):
         s = torch.cuda.current_stream(self.index).cuda_stream
@@ -66,7 +67,10 @@ class Context:
         _lib.check(self.lib.bh_ctx_synchronize(self.handle))
 
     def set_timing(self, on: bool):
+        """Per-operator HIP-event timing (``elapsed_ms``).  While it is on, Richardson-Lucy reads its per-iteration events back on
+        the host inside the call — turn it off for anything that overlaps streams."""
         _lib.check(self.lib.bh_ctx_set_timing(self.handle, int(on)))
+        self.timing = bool(on)
 
     def elapsed_ms(self, what: int) -> float:
         ms = C.c_float()

@@ -141,6 +141,16 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def gather_objects(obj):
+    """Every rank's (picklable) ``obj`` on every rank, in rank order — bench.py's evidence of which GPU each rank sits on
+    (device name + PCI bus id over the job's own process group: RCCL at N > 1)."""
+    if not dist.is_initialized():
+        return [obj]
+    rows = [None] * dist.get_world_size()
+    dist.all_gather_object(rows, obj)
+    return rows
+
+
 def gather_stats(stats: RankStats, device=None):
     """all_gather of 4 doubles per rank; every rank gets the list (rank 0 writes the plate metadata)."""
     mine = torch.tensor([stats.n_done, stats.n_failed, stats.seconds, stats.voxels], dtype=torch.float64,

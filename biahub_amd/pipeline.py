@@ -18,7 +18,7 @@ from .device import resolve_device
 
 
 def run_overlapped(items: Iterable, upload: Callable, compute: Callable, download: Callable, device="cuda",
-                   depth: int = 2) -> Iterator:
+                   depth: int = 2, timeline: list | None = None) -> Iterator:
     """Yield ``download(compute(upload(item)))`` for every item, in order, with the legs of neighbouring items overlapped.
 
     ``upload(item)`` returns device tensor(s) and must only enqueue work (``tensor.to(dev, non_blocking=True)`` from pinned
@@ -26,7 +26,8 @@ def run_overlapped(items: Iterable, upload: Callable, compute: Callable, downloa
     (``pinned.copy_(t, non_blocking=True)``) and returns whatever the caller wants to receive — it is handed out only after
     the copy has finished.  ``depth`` bounds the units in flight per leg (device memory: ``depth`` inputs and results).
     Each callable runs with its own stream current; tensors crossing from one leg to the next are ordered by events and
-    kept alive for the consuming stream.
+    kept alive for the consuming stream.  ``timeline`` (a list) receives one ``[h2d0, h2d1, c0, c1, d2h0, d2h1]`` row of
+    timing events per unit — ``timeline_ms`` turns them into milliseconds once everything has finished.
     """
     dev = resolve_device(device)
     s_in, s_c, s_out = (torch.cuda.Stream(dev) for _ in range(3))
@@ -38,22 +39,34 @@ def run_overlapped(items: Iterable, upload: Callable, compute: Callable, downloa
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(stream)
 
+    timed = timeline is not None
+
+    def _mark(stream):
+        ev = torch.cuda.Event(enable_timing=timed)
+        ev.record(stream)
+        return ev
+
     def _compute_and_download():
-        up, ev = staged.popleft()
+        up, ev, row = staged.popleft()
         s_c.wait_event(ev)
         with torch.cuda.stream(s_c):
             _record(up, s_c)
+            if timed:
+                row.append(_mark(s_c))
             res = compute(up)
-            computed = torch.cuda.Event()
-            computed.record(s_c)
+            computed = _mark(s_c)
         del up
         s_out.wait_event(computed)
         with torch.cuda.stream(s_out):
             _record(res, s_out)
+            if timed:
+                row += [computed, _mark(s_out)]
             handed = download(res)
-            done = torch.cuda.Event()
-            done.record(s_out)
+            done = _mark(s_out)
         del res
+        if timed:
+            row.append(done)
+            timeline.append(row)
         landing.append((handed, done))
 
     def _hand_out():
@@ -66,10 +79,12 @@ def run_overlapped(items: Iterable, upload: Callable, compute: Callable, downloa
         # (hipFFT planning, a first-use allocation) never keeps the next upload from starting
         for item in items:
             with torch.cuda.stream(s_in):
+                row = [_mark(s_in)] if timed else None
                 up = upload(item)
-                ev = torch.cuda.Event()
-                ev.record(s_in)
-            staged.append((up, ev))
+                ev = _mark(s_in)
+            if timed:
+                row.append(ev)
+            staged.append((up, ev, row))
             del up
             if len(staged) > 1:
                 _compute_and_download()
@@ -79,3 +94,12 @@ def run_overlapped(items: Iterable, upload: Callable, compute: Callable, downloa
             _compute_and_download()
         while landing:
             yield _hand_out()
+
+
+def timeline_ms(timeline: list) -> list:
+    """Rows of ``run_overlapped(..., timeline=rows)`` as milliseconds since the first upload started:
+    ``[h2d_start, h2d_end, compute_start, compute_end, d2h_start, d2h_end]`` per unit (call after the run has finished)."""
+    if not timeline:
+        return []
+    t0 = timeline[0][0]
+    return [[round(t0.elapsed_time(ev), 2) for ev in row] for row in timeline]

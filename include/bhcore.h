@@ -257,6 +257,23 @@ int bh_richardson_lucy_plan(int64_t pz, int64_t py, int64_t px, int64_t Z, int64
 int bh_richardson_lucy(bh_ctx* ctx, const float* in, const float* psf, int64_t pz, int64_t py,
                        int64_t px, int64_t Z, int64_t Y, int64_t X, int iterations, float eps,
                        float* out);
+/* The same in two steps, for the volumes of a plate that share one PSF — the shape of the reference's deconvolve: the
+ * transfer function is computed once (biahub/deconvolve.py:140-149) and handed to every (position, t, c) unit
+ * (:183-191, :52-66).  `create` builds the transfer function at the box bh_richardson_lucy_plan picks (it may synchronise
+ * the stream once); `apply` runs `iterations` on one volume (in / out float32 (Z, Y, X), may alias) and only enqueues work
+ * on the context's stream: no read-back and no host synchronisation, so uploads and downloads of neighbouring units on
+ * other streams overlap it (the one-shot entry above validates its cached transfer function against the PSF's bytes on
+ * every call, which is a host stall).  The handle owns the transfer function (the size bh_richardson_lucy_info reports;
+ * released blocks are pooled like staged inverse filters, bh_inverse_filter_trim returns them), belongs to the device of
+ * the context that created it and may be used from any context of that device. */
+typedef struct bh_rl bh_rl;
+int bh_richardson_lucy_create(bh_ctx* ctx, const float* psf, int64_t pz, int64_t py, int64_t px, int64_t Z, int64_t Y,
+                              int64_t X, bh_rl** out);
+int bh_richardson_lucy_apply(bh_ctx* ctx, const bh_rl* handle, const float* in, int iterations, float eps, float* out);
+int bh_richardson_lucy_destroy(bh_rl* handle);
+/* box / backend as bh_richardson_lucy_plan; otf_is_real: the PSF is point-symmetric, one float per bin is kept; any
+ * output pointer may be NULL. */
+int bh_richardson_lucy_info(const bh_rl* handle, int64_t box[3], int* backend, int* otf_is_real, uint64_t* otf_bytes);
 
 /* Phase cross-correlation of two equally shaped float32 volumes (biahub/estimate_stabilization.py:199-256
  * phase_cross_corr): corr = irfftn(F1 conj(F2) / norm), norm = 1 | max(|F1 conj F2|, eps) | |F1||F2|.

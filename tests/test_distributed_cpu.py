@@ -31,6 +31,8 @@ def _worker(rank, world, port, q):
     parallel.barrier()
     slowest = parallel.max_over_ranks(float(rank + 1))
     rows = parallel.gather_stats(st)
+    cards = parallel.gather_objects({"rank": rank, "pci_bus_id": f"0000:{rank:02x}:00.0"})  # bench.py's "rccl" block
+    assert [c["rank"] for c in cards] == list(range(world)) and len({c["pci_bus_id"] for c in cards}) == world
     q.put((rank, parallel.shard_positions(positions, r, w), st.n_done, st.n_failed, slowest,
            [(x.n_done, x.n_failed, x.voxels) for x in rows]))
     torch.distributed.destroy_process_group()

@@ -1176,11 +1176,15 @@ def test_zarr_device_volume_io(gpu, tmp_path, version, shards_ratio, shuffle):
     ((8, 32, 2048), (5, 5, 9)),      # M = 1024: one row pair per wavefront, radix 8 x 16 x 8
     ((4, 64, 1024), (3, 7, 7)),      # M = 512: two row pairs per wavefront, radix 8 x 8 x 8
     ((8, 64, 512), (3, 5, 7)),       # M = 256: four row pairs per wavefront, radix 8 x 4 x 8
+    ((8, 32, 1536), (3, 5, 9)),      # M = 768 = 3 x 256: the radix-3 kernels (csrc/fftconv_x3.inc), two row pairs per wavefront
+    ((4, 64, 3072), (3, 3, 11)),     # M = 1536 = 3 x 512: one row pair per wavefront
+    ((12, 40, 1500), (3, 5, 9)),     # wrap-padded box (16, 64, 1536): forward, fused ratio and plain inverse of the radix-3 kernels
     ((24, 96, 1024), (5, 5, 5)),     # Z, Y of 3 * 2^k: radix-3 column passes around the new X passes
     ((12, 40, 2048), (3, 5, 11)),    # Z, Y too short for the engine as they are: the wrap-padded box (plain inverse with store)
 ])
 def test_wave_private_x_passes(gpu, shape, pshape, monkeypatch):
-    """Rows of 1024 / 2048 voxels run the wave-private X passes (register FFT stages + two wave-local LDS exchanges, own
+    """Rows of 512 / 1024 / 2048 voxels (csrc/fftconv_xw.inc) and of 1536 / 3072 voxels (radix-3 first step across the thirds of
+    a row, csrc/fftconv_x3.inc) run the wave-private X passes (register FFT stages + two wave-local LDS exchanges, own
     column order of the spectrum).  Richardson-Lucy (fused ratio / update kernels, forward, plain inverse), Tikhonov (filter
     staged through the column map) and phase cross-correlation agree with the oracle and with the tile-based X passes
     (BH_FC_XW=0) on the same inputs."""
@@ -1545,3 +1549,97 @@ def test_overlapped_pipeline_equals_serial(gpu):
         assert len(got) == n
         for g, w in zip(got, want):
             assert torch.equal(g, w)
+
+
+# ----------------------------------------------------------------------------- prepared Richardson-Lucy handle
+@pytest.mark.parametrize("shape,pshape,backend", [
+    ((16, 64, 128), (5, 5, 7), "engine"),            # the fused engine at the volume's own shape
+    ((8, 64, 1024), (3, 3, 9), "engine"),            # wave-private X passes
+    ((21, 64, 150), (7, 5, 9), "engine-padded"),     # wrap-padded engine box
+    ((15, 21, 25), (5, 3, 3), "library"),            # hipFFT
+])
+def test_prepared_richardson_lucy_handle(gpu, shape, pshape, backend, monkeypatch):
+    """bh_richardson_lucy_create / _apply / _destroy: the transfer function is built once, every apply agrees with the
+    one-shot entry and the oracle — for a point-symmetric PSF (real transfer function kept) and an asymmetric one, for
+    several volumes and iteration counts through one handle, in place, and with iterations = 0."""
+    from biahub_amd.deconvolve import PreparedRichardsonLucy, richardson_lucy, richardson_lucy_czyx
+
+    sym = O.gaussian_psf(pshape, tuple(max(p / 4.0, 0.8) for p in pshape))
+    asym = sym.copy()
+    asym[0, 0, 0] += 0.02
+    vols = [O.synthetic_volume(shape, seed=s, n_blobs=8) for s in (31, 32)]
+    vols[1][0, :, 0] += 300.0
+    for psf, want_real in ((sym, backend != "library"), (asym, False)):
+        with PreparedRichardsonLucy(psf, shape, gpu) as h:
+            assert h.backend == backend and h.otf_is_real == want_real
+            for vol, it in ((vols[0], 4), (vols[1], 2), (vols[0], 4)):
+                want = O.richardson_lucy_zyx(vol, psf, iterations=it, eps=1e-6)
+                v = torch.from_numpy(vol).to(gpu)
+                got = h(v, it, 1e-6)
+                assert rel_err(got.cpu().numpy(), want) <= FFT_TOL, (backend, it)
+                one = richardson_lucy(v, torch.from_numpy(psf).to(gpu), it, 1e-6)
+                assert rel_err(got.cpu().numpy(), one.cpu().numpy()) <= 2e-5
+            inplace = torch.from_numpy(vols[1]).to(gpu)
+            assert h(inplace, 2, 1e-6, out=inplace) is inplace                      # in == out: the data term is kept aside
+            assert rel_err(inplace.cpu().numpy(), O.richardson_lucy_zyx(vols[1], psf, iterations=2, eps=1e-6)) <= FFT_TOL
+            assert np.array_equal(h(torch.from_numpy(vols[0]).to(gpu), 0).cpu().numpy(), np.maximum(vols[0], 0))
+            with pytest.raises(ValueError):
+                h(torch.zeros((4, 32, 64), device=gpu), 1)
+    # the numpy operator adapter keeps one handle per PSF object across its calls
+    c = richardson_lucy_czyx(np.stack(vols), sym, iterations=3)
+    assert rel_err(c[1], O.richardson_lucy_zyx(vols[1], sym, iterations=3, eps=1e-6)) <= FFT_TOL
+
+
+# ----------------------------------------------------------------------------- oracle parity at the bench size
+def test_config2_full_size_oracle_parity(gpu):
+    """BASELINE config 2 at its own size against the oracle — the exact kernel instantiations bench.py runs
+    (colz_kernel<5>, colw_kernel<10, .>, xw_kernel<10, 4 | 5>, deskew_kernel<float, ...>), not small stand-ins:
+    Richardson-Lucy, 2 iterations on (512, 2048, 2048) (scipy.fft on all host cores, about a minute), <= 1e-4; deskew of that
+    estimate against the oracle on three x-slabs (first, middle, the ragged last columns), <= 1e-5, with fill 0 and with
+    fill "mean" (the fill value read from the full HIP result, whose statistics the slab oracle cannot know)."""
+    from biahub_amd.deconvolve import PreparedRichardsonLucy
+    from biahub_amd.deskew import fast_deskew_zyx
+
+    shape = (512, 2048, 2048)
+    g = torch.Generator(device=gpu).manual_seed(23)
+    vol_d = (torch.rand(shape, generator=g, device=gpu) * 300 + 100).round_()
+    zz = torch.randint(4, shape[0] - 4, (4096,), generator=g, device=gpu)
+    yy = torch.randint(4, shape[1] - 4, (4096,), generator=g, device=gpu)
+    xx = torch.randint(4, shape[2] - 4, (4096,), generator=g, device=gpu)
+    vol_d.index_put_((zz, yy, xx), torch.full((4096,), 3000.0, device=gpu), accumulate=True)    # beads on a noisy background
+    psf = O.gaussian_psf((33, 17, 17), (3.0, 1.5, 1.5))
+    with PreparedRichardsonLucy(psf, shape, gpu) as h:
+        assert h.backend == "engine" and h.otf_is_real
+        est_d = h(vol_d, 2, 1e-6)
+    vol = vol_d.cpu().numpy()
+    del vol_d
+    want = O.richardson_lucy_zyx(vol, psf, iterations=2, eps=1e-6)
+    del vol
+    est = est_d.cpu().numpy()
+    scale = float(np.abs(want).max())
+    err = 0.0
+    for z0 in range(0, shape[0], 64):   # blockwise: no 8-GB temporaries
+        err = max(err, float(np.abs(est[z0:z0 + 64] - want[z0:z0 + 64]).max()))
+    assert err / scale <= FFT_TOL, err / scale
+    del want
+
+    kw = dict(ls_angle_deg=36.17, px_to_scan_ratio=0.371, keep_overhang=True, average_n_slices=3)
+    X = shape[2]
+    zero = fast_deskew_zyx(est_d, overhang_fill=0, **kw).cpu().numpy()
+    mean = fast_deskew_zyx(est_d, overhang_fill="mean", **kw).cpu().numpy()
+    del est_d
+    # the fill value the kernel used: a voxel deep in the overhang (exact zero before the fill)
+    assert zero[0, 0, 0] == 0.0 and zero[-1, -1, -1] == 0.0
+    fill = float(mean[0, 0, 0])
+    assert fill > 0 and float(mean[-1, -1, -1]) == fill
+    dscale = float(np.abs(zero).max())
+    for x0, x1 in ((0, 48), (1000, 1064), (X - 37, X)):
+        slab = est[:, :, x0:x1]
+        rows = slice(X - x1, X - x0)                                # out[a, yo, xo] reads in[:, :, X - 1 - yo]
+        w0 = O.fast_deskew_zyx(slab, overhang_fill=0, **kw)
+        assert np.abs(zero[:, rows] - w0).max() <= DESKEW_TOL * dscale, (x0, x1)
+        w1 = O.fast_deskew_zyx(slab, overhang_fill=fill, **kw)
+        # the 26-connected dilation of the zero mask crosses the slab's y faces: compare the rows it cannot reach from outside
+        inner = slice(3, (x1 - x0) - 3)
+        got = mean[:, rows][:, inner]
+        assert np.abs(got - w1[:, inner]).max() <= DESKEW_TOL * max(dscale, fill), (x0, x1)

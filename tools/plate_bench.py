@@ -14,7 +14,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np, torch
 from biahub_amd import parallel
-from biahub_amd.deconvolve import richardson_lucy, tikhonov_zyx, transfer_function_device
+from biahub_amd.deconvolve import PreparedRichardsonLucy, tikhonov_zyx, transfer_function_device
 from biahub_amd.deskew import fast_deskew_zyx, _fast_deskew_czyx
 from biahub_amd.estimate_stabilization import phase_cross_corr_device
 from biahub_amd.flat_field import flat_field_device
@@ -46,6 +46,18 @@ tf = transfer_function_device(psf, shape, dev) if args.deconv == "tikhonov" else
 shifts = [np.eye(4)] * args.T
 for t in range(args.T):
     m = np.eye(4); m[:3, 3] = (0.25 * t, -1.5 * t, 2.25 * t); shifts[t] = m
+
+_rl = {}
+
+
+def richardson_lucy(vol, psf_, iterations, eps):
+    """The plate's PSF is prepared once per volume shape (bh_richardson_lucy_create), as the reference computes its transfer
+    function once per plate (biahub/deconvolve.py:140-149); every unit applies it."""
+    key = tuple(vol.shape)
+    if key not in _rl:
+        _rl[key] = PreparedRichardsonLucy(psf_, key, dev)
+    return _rl[key](vol, iterations, eps)
+
 
 stage = {"flat_field": 0.0, "deconvolve": 0.0, "deskew": 0.0, "estimate_shift": 0.0, "stabilize": 0.0}
 

@@ -27,7 +27,7 @@ class XW:
         self.R2 = 1 << self.midbits
         self.nrep = 16 // self.R2       # middle-stage groups per lane (1, 2, 4)
         self.blk = self.M // 8          # elements per top-3-bit block
-        self.pad = 8                    # complex words of padding per block
+        self.pad = 0 if logm == 8 else 8  # complex words of padding per block (M = 256: 64 row buffers per workgroup, no room)
         self.bstride = self.blk + self.pad
 
     # ---- array index <-> (lane, reg) in the three distributions ----
