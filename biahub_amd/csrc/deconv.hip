@@ -458,6 +458,10 @@ int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, con
                             float eps, float* est);
 int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, const float* est_p, const float* d_p, const cf* otf,
                                 bool otf_real, cf* spec, float eps, float* corr_p);
+bool fftconv_rl_wrap_supported(const ConvPlan& pl, const int64_t N[3], const int64_t P[3]);
+int fftconv_richardson_lucy_wrap(bh_ctx* ctx, const ConvPlan& pl, const float* d_p, const cf* otf, bool otf_real, cf* spec_a,
+                                 cf* spec_b, float* est_a, float* est_b, const int64_t N[3], const int64_t K[3], int iterations,
+                                 float eps, float** result);
 int fftconv_forward(bh_ctx* ctx, const ConvPlan& pl, const float* in, cf* spec);
 int fftconv_inverse(bh_ctx* ctx, const ConvPlan& pl, cf* spec, float* out);
 int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t bytes, cf** spec);
@@ -532,8 +536,11 @@ static int rl_engine_run(bh_ctx* ctx, ConvPlan* pl, const float* d, const void* 
                          float* out) {
     const size_t NS = fftconv_spectrum_elems(*pl);
     cf* spec;
-    BH_TRY(get_scratch(ctx, "fc_spec", NS * sizeof(cf), (void**)&spec));
-    if (spec != ctx->spec_tuned) {  // a new allocation: audition it (fftconv_tune_spectrum)
+    // BH_FC_SPEC_X2=1: the spectrum as the first half of an allocation of twice its size (experiment: sub-ranges of larger
+    // allocations never showed the slow state of the fused update pass) — no audition then
+    static const bool spec_x2 = getenv("BH_FC_SPEC_X2") && atoi(getenv("BH_FC_SPEC_X2")) != 0;
+    BH_TRY(get_scratch(ctx, "fc_spec", (spec_x2 ? 2 : 1) * NS * sizeof(cf), (void**)&spec));
+    if (spec != ctx->spec_tuned && !spec_x2) {  // a new allocation: audition it (fftconv_tune_spectrum)
         Scratch& sc = ctx->scratch["fc_spec"];
         // the audition may free the allocation it was handed and keep another one: the scratch table must follow it on the
         // error path too, or the next get_scratch("fc_spec") hands out a freed pointer
@@ -682,13 +689,15 @@ static int rl_padded_run(bh_ctx* ctx, ConvPlan* pl, const float* d, const void* 
     const int64_t VP = P[0] * P[1] * P[2];
     hipStream_t s = ctx->stream;
     const size_t NS = fftconv_spectrum_elems(*pl);
-    float *a, *b, *c, *dp;
-    cf* spec;
+    const bool wrap = fftconv_rl_wrap_supported(*pl, N, P);  // no fold pass: fftconv_richardson_lucy_wrap
+    float *a, *b, *c = nullptr, *dp;
+    cf *spec, *spec_b = nullptr;
     BH_TRY(get_scratch(ctx, "fft_real", VP * sizeof(float), (void**)&a));
     BH_TRY(get_scratch(ctx, "rl_real2", VP * sizeof(float), (void**)&b));
-    BH_TRY(get_scratch(ctx, "rl_corr_p", VP * sizeof(float), (void**)&c));
+    if (!wrap) BH_TRY(get_scratch(ctx, "rl_corr_p", VP * sizeof(float), (void**)&c));
     BH_TRY(get_scratch(ctx, "rl_data_p", VP * sizeof(float), (void**)&dp));
     BH_TRY(get_scratch(ctx, "fc_spec", NS * sizeof(cf), (void**)&spec));
+    if (wrap) BH_TRY(get_scratch(ctx, "fc_spec_b", NS * sizeof(cf), (void**)&spec_b));
     RemapDims pad, crop;
     FoldBox fold;
     for (int i = 0; i < 3; ++i) {
@@ -717,6 +726,10 @@ static int rl_padded_run(bh_ctx* ctx, ConvPlan* pl, const float* d, const void* 
         BH_CHECK_HIP(hipEventRecord(e0, s));
     }
     float *cur = a, *nxt = b;
+    if (wrap) {
+        BH_TRY(fftconv_richardson_lucy_wrap(ctx, *pl, dp, reinterpret_cast<const cf*>(otf), otf_real, spec, spec_b, a, b, N, K,
+                                            iterations, eps, &cur));
+    } else
     for (int it = 0; it < iterations; ++it) {
         BH_TRY(fftconv_rl_iteration_padded(ctx, *pl, cur, dp, reinterpret_cast<const cf*>(otf), otf_real, spec, eps, c));
         hipLaunchKernelGGL(fold_update_rewrap_kernel, grid2(fold.P), dim3(256), 0, s, (const float*)c, (const float*)cur, nxt, fold);

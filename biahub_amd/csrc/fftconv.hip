@@ -1180,6 +1180,8 @@ static int launch_x3_m(bh_ctx* ctx, const xw::Params& p, int mode) {
         case xw::INV_RATIO: return run(x3::x3_kernel<LOGL, xw::INV_RATIO>);
         case xw::INV_UPDATE: return run(x3::x3_kernel<LOGL, xw::INV_UPDATE>);
         case xw::FUSED_RATIO: return run(x3::x3_kernel<LOGL, xw::FUSED_RATIO>);
+        case xw::FUSED_RATIO_WRAP: return run(x3::x3_kernel<LOGL, xw::FUSED_RATIO_WRAP>);
+        case xw::FUSED_UPDATE_WRAP: return run(x3::x3_kernel<LOGL, xw::FUSED_UPDATE_WRAP>);
         default: return run(x3::x3_kernel<LOGL, xw::FUSED_UPDATE>);
     }
 }
@@ -1188,6 +1190,8 @@ static int launch_xw(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, con
                      const float* aux, float eps, bool fuse_fwd, const double* norm_mean = nullptr) {
     xw::Params p;
     p.norm_mean = norm_mean;
+    p.S_out = nullptr;
+    p.wz = p.wx = xw::Params::Wrap{0, 0, 0, 0};
     p.in = in;
     p.S = S;
     p.out = out;
@@ -1539,6 +1543,74 @@ int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, const float* es
     BH_TRY(launch_col(ctx, pl, COL_CORR, true, spec, otf, 1.f));
     BH_TRY(launch_col(ctx, pl, COL_INV, false, spec, nullptr, 1.f));
     BH_TRY(launch_x(ctx, pl, true, XE_STORE, nullptr, spec, corr_p, nullptr, 0.f));
+    return BH_OK;
+}
+
+// Richardson-Lucy at a wrap-padded box WITHOUT a fold pass (rows of 1536 / 3072 voxels: fftconv_x3.inc; Y unpadded).
+// The estimate going into the convolution is wrap-extended by (lo below, hi above) the volume on the padded axes (z, x); the
+// ratio going into the correlation is wrap-extended too — by (hi below, lo above), the mirror image, which is what the
+// correlation's taps reach — instead of zero-padded, so the correlation is already the circular one on the volume's own box
+// and nothing has to be folded back.  Both extensions are made by the fused X pass that produces the values: along x inside
+// the row (two strips of at most K - 1 floats through LDS), along z by letting the wavefront of a margin plane re-read the
+// spectrum and the epilogue operand of the plane it mirrors and redo that plane's row — no pass over memory of its own.  Because
+// a margin plane reads what another wavefront overwrites, the X passes run out of place here (two spectrum buffers, two
+// estimate buffers).  One iteration = the 8 passes of the unpadded path instead of 9 transform passes + a fold / rewrap pass.
+bool fftconv_rl_wrap_supported(const ConvPlan& pl, const int64_t N[3], const int64_t P[3]) {
+    return pl.x3 && N[1] == P[1] && getenv("BH_RL_NOWRAP") == nullptr;
+}
+
+static int launch_x3_wrap(bh_ctx* ctx, const ConvPlan& pl, int mode, const cf* S_in, cf* S_out, float* out, const float* aux,
+                          float eps, xw::Params::Wrap wz, xw::Params::Wrap wx) {
+    xw::Params p;
+    p.norm_mean = nullptr;
+    p.in = nullptr;
+    p.S = const_cast<cf*>(S_in);
+    p.S_out = S_out;
+    p.out = out;
+    p.aux = aux;
+    p.tab = pl.xw_tab;
+    p.twy = pl.twy;
+    p.Z = pl.d.Z;
+    p.Y = pl.d.Y;
+    p.XP = pl.d.XP;
+    p.eps = eps;
+    p.wz = wz;
+    p.wx = wx;
+    return pl.d.M == 1536 ? launch_x3_m<9>(ctx, p, mode) : launch_x3_m<8>(ctx, p, mode);
+}
+
+// est_a: the wrap-extended e0 = max(d, 0) on the box (in); est_a / est_b alternate; *result receives the buffer that holds the
+// last estimate (right on the volume's own voxels).  d_p: the data on the box (anything outside the volume's voxels).
+int fftconv_richardson_lucy_wrap(bh_ctx* ctx, const ConvPlan& pl, const float* d_p, const cf* otf, bool otf_real, cf* spec_a,
+                                 cf* spec_b, float* est_a, float* est_b, const int64_t N[3], const int64_t K[3], int iterations,
+                                 float eps, float** result) {
+    const int CONV = otf_real ? COL_FILTER : COL_CONV, CORR = otf_real ? COL_FILTER : COL_CORR;
+    const int64_t P[3] = {pl.d.Z, pl.d.Y, pl.d.X};
+    xw::Params::Wrap we[3], wr[3];  // extension of the estimate (lo below, hi above) and of the ratio (hi below, lo above)
+    for (int a = 0; a < 3; ++a) {
+        const bool padded = P[a] != N[a];
+        const int lo = padded ? (int)(K[a] - 1 - K[a] / 2) : 0, hi = padded ? (int)(K[a] / 2) : 0;
+        we[a] = xw::Params::Wrap{(int)N[a], lo, lo, hi};
+        wr[a] = xw::Params::Wrap{(int)N[a], lo, hi, lo};
+    }
+    float *cur = est_a, *nxt = est_b;
+    BH_TRY(launch_x(ctx, pl, false, 0, cur, spec_a, nullptr, nullptr, 0.f));
+    for (int it = 0; it < iterations; ++it) {
+        BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec_a, nullptr, 1.f));
+        BH_TRY(launch_col(ctx, pl, CONV, true, spec_a, otf, 1.f));
+        BH_TRY(launch_col(ctx, pl, COL_INV, false, spec_a, nullptr, 1.f));
+        BH_TRY(launch_x3_wrap(ctx, pl, xw::FUSED_RATIO_WRAP, spec_a, spec_b, nullptr, d_p, eps, wr[0], wr[2]));
+        BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec_b, nullptr, 1.f));
+        BH_TRY(launch_col(ctx, pl, CORR, true, spec_b, otf, 1.f));
+        BH_TRY(launch_col(ctx, pl, COL_INV, false, spec_b, nullptr, 1.f));
+        if (it + 1 == iterations) {  // the last update is needed on the volume's own voxels only: plain, in place
+            BH_TRY(launch_x(ctx, pl, true, XE_UPDATE, nullptr, spec_b, cur, cur, eps, false));
+        } else {
+            BH_TRY(launch_x3_wrap(ctx, pl, xw::FUSED_UPDATE_WRAP, spec_b, spec_a, nxt, cur, eps, we[0], we[2]));
+            std::swap(cur, nxt);
+        }
+    }
+    *result = cur;
     return BH_OK;
 }
 

@@ -63,9 +63,9 @@ __global__ __launch_bounds__(256) void mask0_kernel(const float* __restrict__ da
 // dilate along x inside each row of W32 words by radius r (< 32)
 __global__ void dilate_x_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int64_t nwords, int W32,
                                 int r) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int wi = (int)(i % W32);
+    const unsigned int nw = (unsigned int)nwords;  // host: nwords < 2^32 (64-bit divisions are software loops on this part)
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += gridDim.x * blockDim.x) {
+        const int wi = (int)(i % (unsigned int)W32);
         const uint32_t w = src[i];
         const uint32_t l = wi > 0 ? src[i - 1] : 0u;
         const uint32_t h = wi + 1 < W32 ? src[i + 1] : 0u;
@@ -135,27 +135,33 @@ __global__ void dilate_cross_kernel(const uint32_t* __restrict__ src, uint32_t* 
     }
 }
 
-// shell sum: voxels in the dilated mask that are not exact zeros; also counts masked voxels
+// shell sum: voxels in the dilated mask that are not exact zeros; also counts masked voxels.  A thread owns a pair of mask
+// words (rows hold an even number of them): 8-byte loads and one 32-bit division per pair — the first version divided a
+// 64-bit word index per word, which is a software loop on this part and made the pass 1.2 ms for 1 GB of masks.
 __global__ __launch_bounds__(256) void shell_kernel(const float* __restrict__ data, const uint32_t* __restrict__ m0,
                                                     const uint32_t* __restrict__ md, double* __restrict__ psum,
                                                     unsigned long long* __restrict__ pcnt, int64_t nwords, int X,
                                                     int W32) {
     double s = 0.0;
     unsigned long long c = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / W32;
-        const int wi = (int)(i % W32);
-        const int x0 = wi * 32;
+    const uint2* __restrict__ m02 = reinterpret_cast<const uint2*>(m0);
+    const uint2* __restrict__ md2 = reinterpret_cast<const uint2*>(md);
+    const unsigned int np = (unsigned int)(nwords >> 1), W2 = (unsigned int)(W32 >> 1);  // host: nwords < 2^32
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
+        const unsigned int row = i / W2;
+        const int x0 = (int)(i - row * W2) * 64;
         if (x0 >= X) continue;
-        uint32_t valid = (X - x0 >= 32) ? 0xFFFFFFFFu : ((1u << (X - x0)) - 1u);
-        const uint32_t d = md[i] & valid;
-        c += __popc(d);
-        uint32_t shell = d & ~m0[i];
+        const uint2 dv = md2[i], zv = m02[i];
+        unsigned long long d = ((unsigned long long)dv.y << 32) | dv.x;
+        const unsigned long long z = ((unsigned long long)zv.y << 32) | zv.x;
+        if (X - x0 < 64) d &= (1ull << (X - x0)) - 1ull;
+        c += __popcll(d);
+        unsigned long long shell = d & ~z;
+        const float* rowp = data + (size_t)row * X + x0;
         while (shell) {
-            const int b = __ffs(shell) - 1;
+            const int b = __ffsll((long long)shell) - 1;
             shell &= shell - 1;
-            s += (double)data[row * X + x0 + b];
+            s += (double)rowp[b];
         }
     }
     __shared__ double shs[4];
@@ -175,17 +181,27 @@ __global__ __launch_bounds__(256) void shell_kernel(const float* __restrict__ da
 }
 
 // deterministic final reduction (single block) + fill value
-__global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict__ p_all, int n_all,
+constexpr int FIN_NT = 1024;  // the fused deskew hands over one partial per workgroup (262 144 at config 2): 256 threads took 0.41 ms
+__global__ __launch_bounds__(FIN_NT) void finalize_kernel(const double* __restrict__ p_all, int n_all,
                                                        const double* __restrict__ p_shell,
                                                        const unsigned long long* __restrict__ p_cnt, int n_shell,
                                                        FillStats* st, unsigned long long total, int fill_mode,
                                                        float fill_value) {
-    __shared__ double sa[256], ss[256];
-    __shared__ unsigned long long sc[256];
+    __shared__ double sa[FIN_NT], ss[FIN_NT];
+    __shared__ unsigned long long sc[FIN_NT];
     double a = 0, s = 0;
     unsigned long long c = 0;
-    for (int i = threadIdx.x; i < n_all; i += 256) a += p_all[i];
-    for (int i = threadIdx.x; i < n_shell; i += 256) {
+    {   // eight independent loads in flight per thread (fixed order: the result is reproducible)
+        double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int i = threadIdx.x;
+        for (; i + 7 * FIN_NT < n_all; i += 8 * FIN_NT) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a8[u] += p_all[i + u * FIN_NT];
+        }
+        for (; i < n_all; i += FIN_NT) a8[0] += p_all[i];
+        a = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    }
+    for (int i = threadIdx.x; i < n_shell; i += FIN_NT) {
         s += p_shell[i];
         c += p_cnt[i];
     }
@@ -193,7 +209,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict_
     ss[threadIdx.x] = s;
     sc[threadIdx.x] = c;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = FIN_NT / 2; o > 0; o >>= 1) {
         if (threadIdx.x < o) {
             sa[threadIdx.x] += sa[threadIdx.x + o];
             ss[threadIdx.x] += ss[threadIdx.x + o];
@@ -214,56 +230,62 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict_
     }
 }
 
-// the 64-bit value of lane k (k wave-uniform) in scalar registers: v_readlane, no trip through the LDS crossbar
-__device__ __forceinline__ unsigned long long bcast_lane(unsigned long long v, int k) {
-    const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)v, k);
-    const unsigned int hi = __builtin_amdgcn_readlane((unsigned int)(v >> 32), k);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-constexpr int FILL_K = 16;  // mask words per lane and region: a wavefront owns FILL_K * 64 segments (256 KiB of voxels) at a time
-
+// Fill pass: a wavefront owns 2048 voxels of one row at a time (64 mask words, one per lane) and writes the fill value in
+// 16-byte stores: lane l of step s takes the four voxels x = a0 + 4 (64 s + l) .. + 3, a0 in 0..3 chosen per row so that
+// the group is 16-B aligned in memory (rows of an (.., X) volume start at any multiple of 4 B), and fetches its four mask bits
+// from the word(s) that hold them with one or two cross-lane reads.  The first version stored 4 B per lane and segment —
+// ~20 instructions per 64 voxels, which is what bounded it (2.6 ms for 9.9 GB at config 2, a plain fill_ writes 6.9 TB/s).
+// Vector loads and stores retire through ONE in-order counter (vmcnt), so the mask words of the NEXT unit are requested
+// before this unit's stores are issued: waiting for them then never waits for a store.
 __global__ __launch_bounds__(256) void apply_fill_kernel(float* __restrict__ data, const uint32_t* __restrict__ md,
                                                          const FillStats* __restrict__ st, int64_t rows, int X,
                                                          int W32) {
-    // A wavefront walks 64-voxel segments and stores the fill value where the segment's mask word says so (one 256-B store
-    // per segment).  Vector loads and stores retire through ONE in-order counter (vmcnt): waiting for a mask load issued
-    // after stores means waiting for every one of those stores to be acknowledged.  The first version loaded 64 mask words
-    // per 16 KiB of voxels and so drained its stores every 16 KiB: 22 us per chunk per wavefront, 3 TB/s.  Here a wavefront
-    // loads the mask words of 256 KiB of voxels first (FILL_K coalesced loads, 32 registers) and then only stores: one drain
-    // per 256 KiB.
     const float fill = st->fill;
+    const float4 fill4 = make_float4(fill, fill, fill, fill);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int W64 = W32 / 2;
-    const long nseg = rows * W64;
-    const unsigned long long* __restrict__ md64 = reinterpret_cast<const unsigned long long*>(md);
-    const long region = (long)FILL_K * 64;
-    const long step = (long)gridDim.x * 4 * region;
-    for (long s0 = ((long)blockIdx.x * 4 + wave) * region; s0 < nseg; s0 += step) {
-        unsigned long long w[FILL_K];
+    const int nchunk = (X + 2047) / 2048;
+    const long nunits = rows * nchunk, step = (long)gridDim.x * 4;
+    auto load_words = [&](long u, uint32_t& m, uint32_t& mnext) {
+        const long row = u / nchunk;
+        const int c = (int)(u - row * nchunk);
+        const uint32_t* w = md + row * W32 + c * 64;
+        m = (c * 64 + lane < W32) ? w[lane] : 0u;
+        mnext = (c * 64 + 64 < W32) ? w[64] : 0u;
+    };
+    long u = (long)blockIdx.x * 4 + wave;
+    uint32_t m = 0u, mnext = 0u;
+    if (u < nunits) load_words(u, m, mnext);
+    for (; u < nunits; u += step) {
+        const uint32_t cur = m, curn = mnext;
+        if (u + step < nunits) load_words(u + step, m, mnext);
+        if (__ballot(cur != 0u) == 0ull && curn == 0u) continue;
+        const long row = u / nchunk;
+        const int c = (int)(u - row * nchunk);
+        const int x0 = c * 2048;
+        float* rowp = data + row * X;
+        const int a0 = (int)((4 - ((row * X) & 3)) & 3);
+        const uint32_t w0 = (uint32_t)__shfl((int)cur, 0, 64);
+        if (c == 0 && lane < a0 && lane < X && ((w0 >> lane) & 1u)) rowp[lane] = fill;  // the row's unaligned head
 #pragma unroll
-        for (int j = 0; j < FILL_K; ++j) {
-            const long mine = s0 + 64 * j + lane;
-            w[j] = mine < nseg ? md64[mine] : 0ull;
-        }
+        for (int s = 0; s < 8; ++s) {
+            const int xr = a0 + 256 * s + 4 * lane;  // relative to x0: 0 .. 2050
+            const int idx = xr >> 5, sh = xr & 31;
+            const uint32_t lo = (uint32_t)__shfl((int)cur, idx & 63, 64);  // every lane takes part in every cross-lane read
+            uint32_t bits = (idx < 64 ? lo : curn) >> sh;
+            if (a0 != 0) {  // (wave-uniform) a group may straddle two words
+                const uint32_t hs = (uint32_t)__shfl((int)cur, (idx + 1) & 63, 64);
+                const uint32_t hi = idx + 1 < 64 ? hs : curn;
+                if (sh > 28) bits |= hi << (32 - sh);
+            }
+            bits &= 15u;
+            const int x = x0 + xr;
+            if (bits == 15u && x + 3 < X) {
+                *reinterpret_cast<float4*>(rowp + x) = fill4;
+            } else if (bits != 0u) {
 #pragma unroll
-        for (int j = 0; j < FILL_K; ++j) {
-            if (__ballot(w[j] != 0ull) == 0ull) continue;
-            const long sj = s0 + 64 * j;
-            long row = sj / W64;
-            int wq = (int)(sj - row * W64);
-            const int cnt = (int)min((long)64, nseg - sj);
-            for (int k = 0; k < cnt; ++k) {
-                const unsigned long long m = bcast_lane(w[j], k);
-                if (m != 0ull) {
-                    const int x = wq * 64 + lane;
-                    if (x < X && ((m >> lane) & 1ull)) data[row * X + x] = fill;
-                }
-                if (++wq == W64) {
-                    wq = 0;
-                    ++row;
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (((bits >> e) & 1u) && x + e < X) rowp[x + e] = fill;
             }
         }
     }
@@ -317,7 +339,7 @@ int fill_overhang_impl(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X
         md = mA;
     }
     hipLaunchKernelGGL(shell_kernel, dim3(nblk), dim3(256), 0, s, data, m0, md, p_shell, p_cnt, nwords, (int)X, W32);
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, p_all, n_all, p_shell, p_cnt, nblk, st,
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(FIN_NT), 0, s, p_all, n_all, p_shell, p_cnt, nblk, st,
                        (unsigned long long)(rows * X), fill_mode, fill_value);
     hipLaunchKernelGGL(apply_fill_kernel, dim3(nblk), dim3(256), 0, s, data, md, st, rows, (int)X, W32);
     BH_CHECK_HIP(hipGetLastError());

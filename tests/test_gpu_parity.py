@@ -1628,10 +1628,11 @@ def test_config2_full_size_oracle_parity(gpu):
     zero = fast_deskew_zyx(est_d, overhang_fill=0, **kw).cpu().numpy()
     mean = fast_deskew_zyx(est_d, overhang_fill="mean", **kw).cpu().numpy()
     del est_d
-    # the fill value the kernel used: a voxel deep in the overhang (exact zero before the fill)
-    assert zero[0, 0, 0] == 0.0 and zero[-1, -1, -1] == 0.0
-    fill = float(mean[0, 0, 0])
-    assert fill > 0 and float(mean[-1, -1, -1]) == fill
+    # the fill value the kernel used: voxels deep in the two overhang wedges (exact zeros before the fill) — the last deskewed
+    # plane at small x', the first at large x' (ix = r x' - r cos(theta) z' + offset leaves [0, Z) there)
+    assert zero[-1, 0, 0] == 0.0 and zero[0, -1, -1] == 0.0
+    fill = float(mean[-1, 0, 0])
+    assert fill > 0 and float(mean[0, -1, -1]) == fill
     dscale = float(np.abs(zero).max())
     for x0, x1 in ((0, 48), (1000, 1064), (X - 37, X)):
         slab = est[:, :, x0:x1]
@@ -1643,3 +1644,43 @@ def test_config2_full_size_oracle_parity(gpu):
         inner = slice(3, (x1 - x0) - 3)
         got = mean[:, rows][:, inner]
         assert np.abs(got - w1[:, inner]).max() <= DESKEW_TOL * max(dscale, fill), (x0, x1)
+
+
+# ----------------------------------------------------------------------------- wrap-padded R-L without a fold pass
+@pytest.mark.parametrize("shape,pshape", [
+    ((21, 64, 1500), (7, 5, 9)),     # box (32, 64, 1536): z and x padded, two row pairs per wavefront
+    ((10, 32, 3000), (3, 3, 8)),     # box (16, 32, 3072): even PSF extent along x — the margins differ by one (hi = lo + 1)
+    ((16, 32, 1500), (5, 3, 9)),     # z a power of two: only x is padded
+    ((44, 64, 1536), (9, 5, 5)),     # x native (3 * 512), z -> 64
+    ((30, 128, 1517), (4, 5, 17)),   # even extent along z; the deskewed row length of BASELINE config 4
+])
+def test_richardson_lucy_wrap_padded_box(gpu, shape, pshape, monkeypatch):
+    """Rows of 1536 / 3072 voxels at a wrap-padded box run Richardson-Lucy in the 8 passes of the unpadded path: estimate and
+    ratio are wrap-extended by the fused X passes themselves (along x inside the row, along z by re-reading the mirrored
+    plane, out of place), so the correlation needs no fold (fftconv_richardson_lucy_wrap).  Against the oracle, the fold /
+    rewrap path (BH_RL_NOWRAP=1) and the library path."""
+    from biahub_amd.deconvolve import PreparedRichardsonLucy, richardson_lucy
+
+    vol = O.synthetic_volume(shape, seed=41, n_blobs=10)
+    vol[0, 0, :] += 500.0            # structure on every face: a wrong wrap shows up as a wrap-around error
+    vol[-1, :, -1] += 300.0
+    vol[:, -1, 0] += 200.0
+    psf = O.gaussian_psf(pshape, tuple(max(p / 4.0, 0.8) for p in pshape))
+    psf[0, 0, 0] += 0.02             # asymmetric: convolution and correlation differ
+    v, pt = torch.from_numpy(vol).to(gpu), torch.from_numpy(psf).to(gpu)
+    for it in (1, 2, 5):
+        want = O.richardson_lucy_zyx(vol, psf, iterations=it, eps=1e-6)
+        with PreparedRichardsonLucy(psf, shape, gpu) as h:
+            assert h.backend == "engine-padded"
+            got = h(v, it, 1e-6).cpu().numpy()
+        assert rel_err(got, want) <= FFT_TOL, (it, rel_err(got, want))
+        monkeypatch.setenv("BH_RL_NOWRAP", "1")
+        fold = richardson_lucy(v, pt, it, 1e-6).cpu().numpy()
+        monkeypatch.delenv("BH_RL_NOWRAP")
+        assert rel_err(got, fold) <= 2e-5, (it, rel_err(got, fold))
+    sym = O.gaussian_psf(pshape, tuple(max(p / 4.0, 0.8) for p in pshape))
+    if all(k % 2 for k in pshape):   # point-symmetric PSF: the real transfer function in the wrap path
+        with PreparedRichardsonLucy(sym, shape, gpu) as h:
+            assert h.otf_is_real
+            got = h(v, 3, 1e-6).cpu().numpy()
+        assert rel_err(got, O.richardson_lucy_zyx(vol, sym, iterations=3, eps=1e-6)) <= FFT_TOL
