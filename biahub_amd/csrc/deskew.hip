@@ -23,6 +23,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace bh {
 
@@ -322,6 +323,269 @@ __global__ __launch_bounds__(NT) void deskew_kernel(const TIN* __restrict__ in, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Persistent, double-buffered form of the kernel above for the common case (float32 input, X a multiple of 64): one
+// 512-thread workgroup per CU walks the (a, x'-chunk, x-tile) tiles; while the eight wavefronts sample tile t out of one LDS
+// buffer, the LDS-DMA loads of tile t + 1 are already landing in the other (the kernel above stages, waits, samples: its
+// memory pipe idles while it computes and vice versa, and only a second workgroup on the CU overlaps the two).  The
+// wavefronts are specialised: two LOADERS only issue LDS-DMA (and the zero rows of a window that leaves the volume), six
+// SAMPLERS only read LDS and store.  Loads and stores retire through one in-order counter per wavefront (vmcnt), so a
+// wavefront that did both could not wait for its tile without also waiting for every store of the previous one; a loader
+// has no stores to wait for, a sampler never waits on vmcnt at all.  One workgroup barrier per tile hands the freshly landed
+// buffer to the samplers and the drained one back to the loaders.  Overhang tiles (every sample outside the scanned range)
+// cost a handful of mask words and no LDS.
+// A lane owns FOUR CONSECUTIVE x' (one 16-byte store per row instead of four 4-byte ones); their taps fall into at most three
+// consecutive z rows per averaged slice, which are read once and selected per output — 3 N LDS reads per row instead of 8 N.
+// Same float32 sample positions, same per-output operation order as deskew_kernel: bit-identical results.
+template <int NK, bool FILL>
+__global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restrict__ in, float* __restrict__ out, DeskewGeom g,
+                                                          int ntx, int nxc) {
+#pragma clang fp contract(off)
+#ifndef BH_DK_PROBE
+#define BH_DK_PROBE 0  // timing probes with WRONG results: bit 0 = no output stores, bit 1 = no LDS reads in the sampler, bit 2 = no LDS-DMA
+#endif
+#ifndef BH_DK_NLOAD
+#define BH_DK_NLOAD 2  // loader wavefronts of the 8; 0: every wavefront loads and samples (and waits for its own stores once per tile)
+#endif
+    constexpr int TX = 64, XC = 256, PITCH = TX + 1, NT = 512, NLOAD = BH_DK_NLOAD;
+    constexpr bool SPLIT = NLOAD > 0;
+    constexpr int NLD = SPLIT ? NLOAD : NT / 64;           // wavefronts that stage
+    constexpr int NWV = SPLIT ? NT / 64 - NLOAD : NT / 64;  // wavefronts that sample
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [2][N][ZC][PITCH]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = SPLIT && wave_all < NLOAD;
+    const int wave = loader ? wave_all : wave_all - (SPLIT ? NLOAD : 0);  // index among the loaders / among the samplers
+    const int lwave = SPLIT ? wave : wave_all;                            // index among the staging wavefronts
+    constexpr int N = NK;
+    const int kstride = g.ZC * PITCH;
+    const int bufstride = N * kstride;
+    const size_t plane = (size_t)g.Y * g.X;
+    const long ntiles = (long)g.Za * nxc * ntx;
+    const float fN = (float)N, rN = 1.0f / fN;
+    double tsum = 0.0;
+
+    struct Tile {
+        int a, xo0, xt0, zlo, zcnt;
+        bool zero;
+    };
+    auto tile_of = [&](long t) {
+        Tile q;
+        const int xt = (int)(t % ntx);
+        const long r = t / ntx;
+        const int xc = (int)(r % nxc);
+        q.a = (int)(r / nxc);
+        q.xt0 = xt * TX;
+        q.xo0 = xc * XC;
+        const int xoN = min(XC, g.Xp - q.xo0);
+        const int zo0 = q.a * N;
+        const float ix_min = deskew_ix(g.px, g.pxct, g.offset, g.zm1, q.xo0, zo0 + N - 1);
+        const float ix_max = deskew_ix(g.px, g.pxct, g.offset, g.zm1, q.xo0 + xoN - 1, zo0);
+        q.zlo = (int)floorf(ix_min);
+        q.zcnt = min((int)floorf(ix_max) + 2 - q.zlo, g.ZC);
+        q.zero = q.zlo + q.zcnt <= 0 || q.zlo >= g.Z;
+        return q;
+    };
+    // an overhang tile: exact zeros everywhere
+    auto zero_tile = [&](const Tile& q) {
+        if (loader) return;
+        for (int xl = wave; xl < TX; xl += NWV) {
+            const size_t orow_i = (size_t)q.a * g.X + (g.X - 1 - (q.xt0 + xl));
+            if (FILL) {
+                // 256 x' = four 64-bit mask words: lanes 0..3 write one each
+                const int xw0 = q.xo0 + 64 * lane;
+                if (lane < 4 && xw0 < g.Xp) {
+                    const int nbits = min(64, g.Xp - xw0);
+                    const unsigned long long bits = nbits == 64 ? ~0ull : ((1ull << nbits) - 1ull);
+                    *reinterpret_cast<unsigned long long*>(g.mask0 + orow_i * g.W32 + xw0 / 32) = bits;
+                }
+            } else {
+                float* orow = out + orow_i * g.Xp;
+                const int xo = q.xo0 + 4 * lane;
+                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                if (xo + 3 < g.Xp) {
+                    *reinterpret_cast<f4u*>(orow + xo) = f4u{0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (xo + j < g.Xp) orow[xo + j] = 0.0f;
+                }
+            }
+        }
+    };
+    // LDS-DMA of a tile's z window into buffer b: one 256-byte row segment per instruction, rows outside [0, Z) zero-filled
+    auto stage = [&](const Tile& q, int b) {
+        if (SPLIT && !loader) return;
+        float* base = tile + b * bufstride;
+        const int za = max(0, -q.zlo), zb = min(q.zcnt, g.Z - q.zlo);
+        const int zo0 = q.a * N;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int yin = g.Y - 1 - min(zo0 + k, g.Y - 1);
+            float* dk = base + k * kstride;
+            for (int zz = lwave; zz < za; zz += NLD) dk[zz * PITCH + lane] = 0.0f;
+            for (int zz = max(zb, 0) + lwave; zz < q.zcnt; zz += NLD) dk[zz * PITCH + lane] = 0.0f;
+            const int z0 = za + lwave;
+            const float* src = in + (size_t)(q.zlo + z0) * plane + (size_t)yin * g.X + q.xt0 + lane;
+            unsigned lds_dst = (unsigned)(size_t)(dk + z0 * PITCH);  // LDS byte address (wave-uniform)
+            for (int zz = z0; zz < zb && !(BH_DK_PROBE & 4); zz += NLD) {
+                unsigned keep;
+                asm volatile(
+                    "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                    : "=&s"(keep)
+                    : "v"(src), "s"(lds_dst)
+                    : "memory");
+                src += (size_t)NLD * plane;
+                lds_dst += NLD * PITCH * 4;
+            }
+        }
+        // landed before this wavefront reaches the barrier that publishes the buffer (unsplit: waited for at the barrier instead,
+        // behind the sampling of the current tile)
+        if (SPLIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // next tile of this workgroup that needs staging; overhang tiles on the way are finished on the spot
+    // A workgroup walks a CONTIGUOUS range of tiles: x tiles run fastest, so 32 consecutive tiles share their (a, x'-chunk)
+    // — one interpolation plan (twelve float32 divisions per lane) serves them all, and neighbouring tiles read neighbouring
+    // 256-byte segments of the same input rows.
+    const long per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const long t_begin = (long)blockIdx.x * per_wg, t_end = min(ntiles, t_begin + per_wg);
+    auto advance = [&](long t) {
+        for (++t; t < t_end; ++t) {
+            const Tile q = tile_of(t);
+            if (!q.zero) break;
+            zero_tile(q);
+        }
+        return t;
+    };
+
+    long cur = advance(t_begin - 1);
+    int b = 0;
+    if (cur < t_end) stage(tile_of(cur), 0);
+    int plan_a = -1, plan_xo0 = -1;
+    int i0[N][4];
+    float w0[N][4], w1[N][4];
+    while (cur < t_end) {
+        const Tile q = tile_of(cur);
+        if (!SPLIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // the loaders' DMA of this tile has landed; the samplers have finished with the other buffer
+        const long nxt = advance(cur);
+        if (nxt < t_end) stage(tile_of(nxt), b ^ 1);
+        if (loader) {
+            cur = nxt;
+            b ^= 1;
+            continue;
+        }
+        // ---- sample: lane owns x' = xo0 + 4 lane .. + 3
+        const float* tb = tile + b * bufstride;
+        const int zo0 = q.a * N;
+        const int xb4 = q.xo0 + 4 * lane;
+        // interpolation plan of the lane's four outputs x N slices: LDS offset of the lower tap (the upper one is one row on:
+        // both arrive in one ds_read2_b32) and the two weights — kept in registers across the tile's 64 rows
+        if (q.a != plan_a || q.xo0 != plan_xo0) {  // (wave-uniform) the plan of this (a, x'-chunk): shared by its x tiles
+            plan_a = q.a;
+            plan_xo0 = q.xo0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float ix = deskew_ix(g.px, g.pxct, g.offset, g.zm1, xb4 + j, zo0 + k);
+                    const float fl = floorf(ix);
+                    w1[k][j] = ix - fl;
+                    w0[k][j] = (fl + 1.0f) - ix;
+                    const int rel = max(0, min((int)fl - q.zlo, g.ZC - 2));  // lanes past Xp may fall outside the window
+                    i0[k][j] = k * kstride + rel * PITCH;
+                }
+            }
+        }
+        {
+            for (int xl = wave; xl < TX; xl += NWV) {
+                const int yo = g.X - 1 - (q.xt0 + xl);
+                const size_t orow_i = (size_t)q.a * g.X + yo;
+                float* orow = out + orow_i * g.Xp;
+                const float* tcol = tb + xl;
+                float acc[4];
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float t0 = (BH_DK_PROBE & 2) ? (float)(xl + k) : tcol[i0[k][j]];
+                        const float t1 = (BH_DK_PROBE & 2) ? (float)j : tcol[i0[k][j] + PITCH];
+                        const float val = __builtin_fmaf(t1, w1[k][j], t0 * w0[k][j]);
+                        acc[j] = (k == 0) ? val : acc[j] + val;
+                    }
+                }
+                float val[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) val[j] = (N > 1) ? div_small(acc[j], fN, rN) : acc[j];
+                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                if (FILL) {
+                    // zero-mask bits of the 256 outputs: word w (x' = xo0 + 64 w .. + 63) is the nibbles of lanes 16 w .. 16 w + 15,
+                    // lane 16 w + i contributing bits 4 i .. 4 i + 3.  A DPP row is those 16 lanes: each lane places its nibble
+                    // in the low (i < 8) or high half, four row_shr steps OR the row together, lane 16 w + 15 writes the word.
+                    const unsigned nib = (unsigned)(xb4 < g.Xp && val[0] == 0.0f) | ((unsigned)(xb4 + 1 < g.Xp && val[1] == 0.0f) << 1) |
+                                         ((unsigned)(xb4 + 2 < g.Xp && val[2] == 0.0f) << 2) |
+                                         ((unsigned)(xb4 + 3 < g.Xp && val[3] == 0.0f) << 3);
+                    const int i16 = lane & 15;
+                    unsigned lo = i16 < 8 ? nib << (4 * i16) : 0u, hi = i16 < 8 ? 0u : nib << (4 * (i16 - 8));
+#define BH_ROW_OR(v, sh) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + sh, 0xF, 0xF, true)  /* row_shr:sh, 0 shifted in */
+                    BH_ROW_OR(lo, 1);
+                    BH_ROW_OR(hi, 1);
+                    BH_ROW_OR(lo, 2);
+                    BH_ROW_OR(hi, 2);
+                    BH_ROW_OR(lo, 4);
+                    BH_ROW_OR(hi, 4);
+                    BH_ROW_OR(lo, 8);
+                    BH_ROW_OR(hi, 8);
+#undef BH_ROW_OR
+                    const int xw0 = q.xo0 + 64 * (lane >> 4);
+                    if (i16 == 15 && xw0 < g.Xp)
+                        *reinterpret_cast<uint2*>(g.mask0 + orow_i * g.W32 + xw0 / 32) = make_uint2(lo, hi);
+                    // exact zeros are not stored (the fill pass overwrites every masked voxel anyway); a group without zeros
+                    // inside the row goes out as one 16-byte store
+                    if (BH_DK_PROBE & 1) {
+                        tsum += (double)(val[0] + val[1] + val[2] + val[3]);
+                    } else if (xb4 + 3 < g.Xp && nib == 0u) {
+                        *reinterpret_cast<f4u*>(orow + xb4) = f4u{val[0], val[1], val[2], val[3]};
+                        tsum += (double)val[0] + (double)val[1] + (double)val[2] + (double)val[3];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (xb4 + j < g.Xp && val[j] != 0.0f) {
+                                orow[xb4 + j] = val[j];
+                                tsum += (double)val[j];
+                            }
+                    }
+                } else {
+                    if (BH_DK_PROBE & 1) {
+                        if (val[0] + val[1] + val[2] + val[3] == -12345.0f) orow[xb4] = 1.0f;  // keeps the arithmetic alive
+                    } else if (xb4 + 3 < g.Xp) {
+                        *reinterpret_cast<f4u*>(orow + xb4) = f4u{val[0], val[1], val[2], val[3]};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (xb4 + j < g.Xp) orow[xb4 + j] = val[j];
+                    }
+                }
+            }
+        }
+        cur = nxt;
+        b ^= 1;
+    }
+    if (FILL) {
+        __shared__ double wsum[NT / 64];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tsum += __shfl_down(tsum, o, 64);
+        if (lane == 0) wsum[wave_all] = tsum;  // the loaders contribute 0
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < NT / 64; ++w) t += wsum[w];
+            g.psum[blockIdx.x] = t;
+        }
+    }
+}
+
 static int deskew_geometry(int64_t Z, int64_t Y, int64_t X, double angle, double ratio, int keep_overhang,
                            int n, DeskewGeom* g, int64_t out_shape[3]) {
     double voxel[3];
@@ -400,8 +664,53 @@ static size_t cfg_lds(const DeskewGeom& g, int TX, int J) {
     return (size_t)g.N * max_window(g, 64 * J) * (TX + 1) * sizeof(float);
 }
 
+// the persistent double-buffered kernel: float32 input, whole 64-column tiles, N <= 4, two tile buffers within 160 KiB
+template <typename TIN>
+static int launch_deskew_pers(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g, bool fill, int* nblocks, bool* taken) {
+    *taken = false;
+    return BH_OK;
+}
+template <>
+int launch_deskew_pers<float>(bh_ctx* ctx, const float* in, float* out, DeskewGeom g, bool fill, int* nblocks, bool* taken) {
+    *taken = false;
+    // BH_DESKEW_PERS: 0 never, 1 always (when the shape allows), default: with a fused fill only — measured at config 2
+    // (tools/time_deskew.py, same box): 4.96 against 5.59 ms with the fill prologue, 5.89 against 5.60 ms without
+    const int mode = getenv("BH_DESKEW_PERS") ? atoi(getenv("BH_DESKEW_PERS")) : 2;
+    if (mode == 0 || (mode == 2 && !fill)) return BH_OK;
+    if (g.N < 1 || g.N > 4 || (g.X % 64) != 0) return BH_OK;
+    constexpr int XC = 256, TX = 64;
+    g.XC = XC;
+    g.ZC = std::max(max_window(g, XC), 3);
+    g.ZS = TX + 1;
+    const size_t lds = 2 * (size_t)g.N * g.ZC * (TX + 1) * sizeof(float);
+    if (lds + 256 > 160 * 1024) return BH_OK;
+    const int ntx = g.X / TX, nxc = (int)ceil_div(g.Xp, XC);
+    const long ntiles = (long)g.Za * nxc * ntx;
+    const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
+    if (nblocks) *nblocks = grid;
+    if (fill) BH_TRY(get_scratch(ctx, "fill_pall", (size_t)grid * sizeof(double), (void**)&g.psum));
+    auto run = [&](auto kern) -> int {
+        BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, ctx->stream, in, out, g, ntx, nxc);
+        BH_CHECK_HIP(hipGetLastError());
+        return BH_OK;
+    };
+    *taken = true;
+    switch (g.N) {
+        case 1: return fill ? run(deskew_pers_kernel<1, true>) : run(deskew_pers_kernel<1, false>);
+        case 2: return fill ? run(deskew_pers_kernel<2, true>) : run(deskew_pers_kernel<2, false>);
+        case 3: return fill ? run(deskew_pers_kernel<3, true>) : run(deskew_pers_kernel<3, false>);
+        default: return fill ? run(deskew_pers_kernel<4, true>) : run(deskew_pers_kernel<4, false>);
+    }
+}
+
 template <typename TIN>
 static int launch_deskew(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g, bool fill, int* nblocks) {
+    {
+        bool taken = false;
+        BH_TRY(launch_deskew_pers<TIN>(ctx, in, out, g, fill, nblocks, &taken));
+        if (taken) return BH_OK;
+    }
     // Candidates (TX, J, threads, LDS-DMA staging) from fastest measured (profiles/, tools/tune_deskew.py:
     // 5.7 ms at 512x2048x2048 -> 683x2048x3034 for cfg 0) to smallest tile; take the first whose tile
     // lets two workgroups share a CU, else the first that fits.  BH_DESKEW_CFG=<n> forces one.

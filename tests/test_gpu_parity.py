@@ -47,6 +47,10 @@ def test_deskew_golden_vectors(gpu, deskew_cases):
     ((96, 64, 200), 2, 30.0, 0.25),
     ((40, 33, 65), 5, 20.0, 0.5),        # generic-N path
     ((31, 50, 33), 1, 45.0, 0.9),
+    ((40, 30, 128), 2, 30.0, 0.25),      # X a multiple of 64: the persistent double-buffered kernel (two x tiles)
+    ((31, 50, 64), 1, 45.0, 0.9),        # ... with a ratio at which a lane's four outputs span more than three z rows
+    ((33, 17, 192), 4, 36.17, 0.371),    # ... N = 4, ragged last slab
+    ((200, 40, 320), 3, 36.17, 0.371),   # ... several x' chunks, windows leaving the volume on both sides
 ])
 def test_deskew_vs_oracle(gpu, shape, n, angle, ratio):
     from biahub_amd.deskew import fast_deskew_zyx
@@ -105,6 +109,30 @@ def test_deskew_properties_large(gpu):
     assert torch.equal(sub, da[:, X - 164:X - 100, :])
     # splits along X reproduce the unsplit result exactly
     assert torch.equal(fast_deskew_zyx(a, **kw), da)  # deterministic
+
+
+def test_deskew_persistent_kernel_equals_tile_kernel(gpu, monkeypatch):
+    """float32 volumes whose rows are whole 64-column tiles take the persistent double-buffered kernel (loader / sampler
+    wavefronts, a lane owns four consecutive x'); BH_DESKEW_PERS=0 keeps them on the one-tile-per-workgroup kernel.  Same sample
+    positions, same operation order per output: bit-identical without fill; with a fill the two differ only in the summation
+    order of the mean.  True zeros inside the signal and a row length that is not a multiple of 4 (unaligned 16-byte stores)."""
+    from biahub_amd.deskew import fast_deskew_zyx
+
+    for shape, n, ratio in (((96, 100, 256), 3, 0.371), ((64, 33, 128), 2, 0.29), ((50, 21, 64), 1, 0.8)):
+        g = torch.Generator(device=gpu).manual_seed(sum(shape))
+        vol = (torch.rand(shape, generator=g, device=gpu) * 500 + 10).round_()
+        vol[10:20, 5:15, 20:40] = 0.0
+        for fill in (0, "mean", 7.5):
+            kw = dict(ls_angle_deg=36.17, px_to_scan_ratio=ratio, keep_overhang=True, average_n_slices=n, overhang_fill=fill)
+            monkeypatch.setenv("BH_DESKEW_PERS", "1")   # also without a fill (the default takes it only with one)
+            new = fast_deskew_zyx(vol, **kw)
+            monkeypatch.setenv("BH_DESKEW_PERS", "0")
+            old = fast_deskew_zyx(vol, **kw)
+            monkeypatch.delenv("BH_DESKEW_PERS")
+            if fill == "mean":
+                assert float((new - old).abs().max()) <= 1e-6 * float(old.abs().max()), (shape, fill)
+            else:
+                assert torch.equal(new, old), (shape, fill)
 
 
 def test_deskew_errors(gpu):
