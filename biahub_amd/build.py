@@ -24,7 +24,7 @@ def _hipcc() -> str:
 
 
 # textual includes of a translation unit (rebuild triggers)
-INCLUDES = {"fftconv.hip": ("fftconv_xpass.inc", "fftconv_xw.inc", "fftconv_x3.inc", "fftconv_colw.inc", "fftconv_colz.inc"), "affine.hip": ("affine_zwalk.inc", "affine_zoblique.inc")}
+INCLUDES = {"fftconv.hip": ("fftconv_xpass.inc", "fftconv_xw.inc", "fftconv_x3.inc", "fftconv_colw.inc", "fftconv_colz.inc", "fftconv_colz3.inc"), "affine.hip": ("affine_zwalk.inc", "affine_zoblique.inc")}
 
 
 def needs_build() -> bool:

@@ -717,8 +717,12 @@ static int rl_padded_run(bh_ctx* ctx, ConvPlan* pl, const float* d, const void* 
     auto grid2 = [&](const int64_t D[3]) {  // a block walks up to 2048 voxels of one row: the per-row index work is paid once
         return dim3((unsigned)std::min<int64_t>(ceil_div(D[2], 2048), 16), (unsigned)std::min<int64_t>(D[0] * D[1], 65535));
     };
-    hipLaunchKernelGGL(remap_kernel<false>, grid2(pad_d.D), dim3(256), 0, s, d, dp, pad_d);
-    hipLaunchKernelGGL(remap_kernel<true>, grid2(pad.D), dim3(256), 0, s, d, a, pad);  // e0 = max(d, 0), wrap-extended
+    if (wrap) {  // the data wrap-extended like the estimate: the first X pass clips it into the estimate and transforms it
+        hipLaunchKernelGGL(remap_kernel<false>, grid2(pad.D), dim3(256), 0, s, d, dp, pad);
+    } else {
+        hipLaunchKernelGGL(remap_kernel<false>, grid2(pad_d.D), dim3(256), 0, s, d, dp, pad_d);
+        hipLaunchKernelGGL(remap_kernel<true>, grid2(pad.D), dim3(256), 0, s, d, a, pad);  // e0 = max(d, 0), wrap-extended
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {
         BH_CHECK_HIP(hipEventCreate(&e0));

@@ -819,6 +819,7 @@ struct ConvPlan {
     // register-stage column passes (fftconv_colw.inc) for columns of 256 / 512 / 1024 points: their twiddle tables
     cf *colw_y = nullptr, *colw_z = nullptr;
     cf* colz = nullptr;  // radix-8 register-stage Z pass of 512-point columns (fftconv_colz.inc)
+    cf* colz3 = nullptr;  // register-stage Z pass of 384-point columns (fftconv_colz3.inc)
 };
 
 // The X passes exist for two tile heights: 16 rows (M = X/2 up to 1024) and 8 rows (M up to 1536: a 3072-voxel row, for which
@@ -842,6 +843,7 @@ namespace xr8 {
 #include "fftconv_x3.inc"
 #include "fftconv_colw.inc"
 #include "fftconv_colz.inc"
+#include "fftconv_colz3.inc"
 
 // ================================================================================================
 // host side
@@ -980,6 +982,10 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
         colz::make_tables(h);
         BH_TRY(upload(h, &pl.colz));
     }
+    if (Z == colz3::N && pl.d.XP >= colz3::W) {
+        colz3::make_tables(h);
+        BH_TRY(upload(h, &pl.colz3));
+    }
     if (xw_on) {
         std::vector<int> col;
         if (X == 3072) x3::make_tables<9>(h, col);
@@ -1084,6 +1090,27 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
             case COL_FILTER: return run(colz::colz_kernel<COL_FILTER>);
             case COL_CONV16: return run(colz::colz_kernel<COL_CONV16>);
             default: return run(colz::colz_kernel<COL_PCC>);
+        }
+    }
+    // 384-point Z passes with a spectral product (the deskewed config-4 volume's box): register stages (BH_FC_COLZ3=0: A/B switch)
+    if (zaxis && pl.colz3 && p.N == colz3::N && (mode == COL_CONV || mode == COL_CORR || mode == COL_FILTER) &&
+        !(getenv("BH_FC_COLZ3") && atoi(getenv("BH_FC_COLZ3")) == 0)) {
+        p.W = colz3::W;
+        p.tw = pl.colz3;
+        p.ncoltiles = (int)ceil_div(p.XP, p.W);
+        const long ntiles = (long)p.nouter * p.ncoltiles;
+        const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
+        auto run = [&](auto kern) -> int {
+            BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)colz3::LDS_BYTES));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(colz3::NT), colz3::LDS_BYTES, ctx->stream, p);
+            BH_CHECK_HIP(hipGetLastError());
+            return BH_OK;
+        };
+        switch (mode) {
+            case COL_CONV: return run(colz3::colz3_kernel<COL_CONV>);
+            case COL_CORR: return run(colz3::colz3_kernel<COL_CORR>);
+            default: return run(colz3::colz3_kernel<COL_FILTER>);
         }
     }
     // columns of 256 / 512 / 1024 points: the register-stage kernels (BH_FC_COLW=0 keeps the LDS-stepped ones: A/B switch)
@@ -1579,8 +1606,9 @@ static int launch_x3_wrap(bh_ctx* ctx, const ConvPlan& pl, int mode, const cf* S
     return pl.d.M == 1536 ? launch_x3_m<9>(ctx, p, mode) : launch_x3_m<8>(ctx, p, mode);
 }
 
-// est_a: the wrap-extended e0 = max(d, 0) on the box (in); est_a / est_b alternate; *result receives the buffer that holds the
-// last estimate (right on the volume's own voxels).  d_p: the data on the box (anything outside the volume's voxels).
+// d_p: the data on the box, wrap-extended like the estimate (lo below, hi above): the first pass clips it into est_a
+// (e0 = max(d, 0)) and transforms it in one go.  est_a / est_b alternate; *result receives the buffer that holds the last
+// estimate (right on the volume's own voxels).
 int fftconv_richardson_lucy_wrap(bh_ctx* ctx, const ConvPlan& pl, const float* d_p, const cf* otf, bool otf_real, cf* spec_a,
                                  cf* spec_b, float* est_a, float* est_b, const int64_t N[3], const int64_t K[3], int iterations,
                                  float eps, float** result) {
@@ -1594,7 +1622,7 @@ int fftconv_richardson_lucy_wrap(bh_ctx* ctx, const ConvPlan& pl, const float* d
         wr[a] = xw::Params::Wrap{(int)N[a], lo, hi, lo};
     }
     float *cur = est_a, *nxt = est_b;
-    BH_TRY(launch_x(ctx, pl, false, 0, cur, spec_a, nullptr, nullptr, 0.f));
+    BH_TRY(launch_x(ctx, pl, false, 0, d_p, spec_a, cur, nullptr, 0.f));  // est = max(d, 0) written by the same pass
     for (int it = 0; it < iterations; ++it) {
         BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec_a, nullptr, 1.f));
         BH_TRY(launch_col(ctx, pl, CONV, true, spec_a, otf, 1.f));

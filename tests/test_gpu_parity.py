@@ -1712,3 +1712,29 @@ def test_richardson_lucy_wrap_padded_box(gpu, shape, pshape, monkeypatch):
             assert h.otf_is_real
             got = h(v, 3, 1e-6).cpu().numpy()
         assert rel_err(got, O.richardson_lucy_zyx(vol, sym, iterations=3, eps=1e-6)) <= FFT_TOL
+
+
+@pytest.mark.parametrize("shape,pshape", [((384, 32, 64), (7, 3, 5)), ((384, 64, 160), (9, 5, 5)), ((350, 32, 1500), (9, 3, 9))])
+def test_radix3_register_z_pass(gpu, shape, pshape, monkeypatch):
+    """384-point Z passes (3 x 128: the box of the deskewed BASELINE config-4 volume) with a spectral product run register
+    stages (csrc/fftconv_colz3.inc: radix-3 + radix-2 in registers, two radix-8 steps, four LDS round trips).  Real transfer
+    function (symmetric PSF) and complex convolution / correlation (asymmetric PSF) agree with the oracle and with the LDS-step
+    kernel (BH_FC_COLZ3=0) on the same inputs, including a ragged last column tile and the wrap-padded path."""
+    from biahub_amd.deconvolve import richardson_lucy
+
+    vol = O.synthetic_volume(shape, seed=61, n_blobs=16)
+    vol[3, :, :] += 250.0
+    vol[-1, 0, :] += 100.0
+    v = torch.from_numpy(vol).to(gpu)
+    sym = O.gaussian_psf(pshape, tuple(max(q / 4.0, 0.8) for q in pshape))
+    asym = sym.copy()
+    asym[0, 0, 0] += 0.02
+    for name, psf in (("real", sym), ("complex", asym)):
+        pt = torch.from_numpy(psf).to(gpu)
+        monkeypatch.delenv("BH_FC_COLZ3", raising=False)
+        new = richardson_lucy(v, pt, 3, 1e-6).cpu().numpy()
+        monkeypatch.setenv("BH_FC_COLZ3", "0")
+        old = richardson_lucy(v, pt, 3, 1e-6).cpu().numpy()
+        monkeypatch.delenv("BH_FC_COLZ3")
+        assert rel_err(new, old) <= 2e-5, (name, rel_err(new, old))
+        assert rel_err(new, O.richardson_lucy_zyx(vol, psf, iterations=3, eps=1e-6)) <= FFT_TOL, name
