@@ -68,6 +68,7 @@ SIGNATURES = {
     "bh_phase_transfer_function_3d": (_int, [_vp, _i64, _i64, _i64, _f64, _f64, _f64, _i64, _f64, _f64, _f64, _int, _vp, _vp]),
     "bh_fluorescence_transfer_function_3d": (_int, [_vp, _i64, _i64, _i64, _f64, _f64, _f64, _i64, _f64, _f64, _vp]),
     "bh_fourier_central_cuboid": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64]),
+    "bh_host_deskew": (_int, [_vp, _int, _i64, _i64, _i64, _f64, _f64, _int, _int, _int, _f32, _vp, C.POINTER(_f32), _int]),
     "bh_richardson_lucy": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _f32, _vp]),
     "bh_richardson_lucy_create": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, C.POINTER(_vp)]),
     "bh_richardson_lucy_apply": (_int, [_vp, _vp, _vp, _int, _f32, _vp]),

@@ -181,6 +181,14 @@ int bh_deskew(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, i
               double ls_angle_deg, double px_to_scan_ratio, int keep_overhang, int average_n_slices,
               int fill_mode, float fill_value, float* out, float* mean_out);
 
+/* The same operator on HOST memory, on the calling process's CPU threads (no context, no GPU): what `--cluster debug` with
+ * the reference's default `device: cpu` needs (biahub/settings.py:348-383, biahub/deskew.py:762-766; BASELINE config 1).
+ * in / out / mean_out are host pointers; nthreads <= 0 uses every hardware thread.  Same float32 sample positions and the
+ * same per-output operation order as bh_deskew: bit-identical results (the mean of a "mean" fill to float32 rounding). */
+int bh_host_deskew(const void* in, int in_dtype, int64_t Z, int64_t Y, int64_t X, double ls_angle_deg,
+                   double px_to_scan_ratio, int keep_overhang, int average_n_slices, int fill_mode, float fill_value,
+                   float* out, float* mean_out, int nthreads);
+
 /* Stand-alone overhang fill on an already deskewed float32 volume, in place. */
 int bh_overhang_fill(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X, int fill_mode,
                      float fill_value, int dilation_iterations, float* mean_out);

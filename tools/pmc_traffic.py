@@ -55,7 +55,7 @@ for k, v in col.items():
     per_it = round(v[0] / n_it)          # launches of this kernel per iteration (the OTF build adds a stray call or two)
     it += per_it * (v[1] + v[2]) * 1e9
 rec = {"shape": shape, "unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KiB counters x1024)", "rl_iteration": it,
-       "deskew_kernel": moved("deskew_kernel<"),
+       "deskew_kernel": moved("deskew_pers_kernel<" if any("deskew_pers_kernel<" in k for k in rows) else "deskew_kernel<"),
        "per_kernel_gb": {k[:60]: round(v[1] + v[2], 3) for k, v in rows.items()},
        "source": f"{prefix}_pmc_hbm_traffic.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of "
                  "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-ops`, summed over the 8 passes of one "
