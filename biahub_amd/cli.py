@@ -77,6 +77,16 @@ def _resolve_cluster(cluster: str | None, local: bool = False) -> str:
     return resolved
 
 
+def _deskew_device(configured: str) -> str:
+    """The GPU whenever one is visible (this package is the MI355X path); on a box without one a config that says ``cpu`` —
+    the reference's default, what BASELINE config 1 runs with — takes libbhcore's host implementation of the operator."""
+    import torch
+
+    if torch.cuda.is_available():
+        return "cuda"
+    return "cpu" if str(configured).lower() == "cpu" else "cuda"  # "cuda" without a GPU fails loudly in resolve_device
+
+
 def _create_plate_once(*args, **kwargs):
     """Rank 0 lays the output plate out, the other ranks wait for it: ``create_empty_plate`` rewrites plate / row / well
     metadata, which concurrent ranks would race on (the reference creates the plate once, in the submitting process,
@@ -171,7 +181,7 @@ def deskew_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor
     _resolve_cluster(cluster)
     kw = dict(ls_angle_deg=settings.ls_angle_deg, px_to_scan_ratio=settings.px_to_scan_ratio,
               keep_overhang=settings.keep_overhang, average_n_slices=settings.average_n_slices,
-              overhang_fill=settings.overhang_fill, device="cuda",
+              overhang_fill=settings.overhang_fill, device=_deskew_device(settings.device),
               extra_metadata={"biahub-deskew": settings.model_dump()})
     outs = get_output_paths(input_position_dirpaths, output_dirpath)
     _run_positions("deskew", input_position_dirpaths, outs,

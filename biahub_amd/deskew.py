@@ -109,14 +109,42 @@ def fast_deskew_zyx(
     return out
 
 
+def _host_deskew_zyx(zyx, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices=1, overhang_fill=0,
+                     num_threads: int = 0) -> np.ndarray:
+    """``fast_deskew_zyx`` on the host's CPU threads (``bh_host_deskew``: libbhcore's own C++, no GPU and no torch device
+    involved) — what ``--cluster debug`` with ``device: cpu`` runs on a box without a GPU (BASELINE config 1; reference
+    biahub/deskew.py:762-766).  Same sample positions and operation order as the GPU kernels: bit-identical results."""
+    a = np.asarray(zyx)
+    if a.ndim != 3:
+        raise ValueError(f"raw_data must be 3-D (Z, Y, X), got shape {a.shape}")
+    if a.dtype not in (np.float32, np.uint16, np.uint8, np.int16):
+        a = a.astype(np.float32)
+    a = np.ascontiguousarray(a)
+    code = {np.dtype(np.float32): _lib.DT_F32, np.dtype(np.uint16): _lib.DT_U16, np.dtype(np.uint8): _lib.DT_U8,
+            np.dtype(np.int16): _lib.DT_I16}[a.dtype]
+    Z, Y, X = (int(n) for n in a.shape)
+    out_shape, _ = get_deskewed_data_shape((Z, Y, X), ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices)
+    mode, value = _fill_args(overhang_fill)
+    out = np.empty(out_shape, dtype=np.float32)
+    _lib.check(_lib.load().bh_host_deskew(a.ctypes.data_as(C.c_void_p), code, Z, Y, X, float(ls_angle_deg),
+                                          float(px_to_scan_ratio), int(bool(keep_overhang)), int(average_n_slices), mode, value,
+                                          out.ctypes.data_as(C.c_void_p), None, int(num_threads)))
+    return out
+
+
 def _fast_deskew_czyx(data, device="cuda", num_splits=1, **kwargs):
     """CZYX adapter, numpy in / numpy out (biahub/deskew.py:551-579).
 
     Takes channel 0 only, like the reference (:559).  ``num_splits`` > 1 splits along input X
     (independent in the transform) and concatenates in reversed order along output Y (:560-573).
     """
-    dev = resolve_device(device)
     zyx = np.asarray(data)[0]
+    if torch.device(device).type == "cpu":  # the reference's default `device: cpu` (settings.py:348-383): libbhcore's host path
+        if num_splits > 1:
+            chunks = np.array_split(zyx, num_splits, axis=2)
+            return np.concatenate([_host_deskew_zyx(np.ascontiguousarray(c), **kwargs) for c in reversed(chunks)], axis=1)[None]
+        return _host_deskew_zyx(zyx, **kwargs)[None]
+    dev = resolve_device(device)
     if num_splits > 1:
         chunks = np.array_split(zyx, num_splits, axis=2)
         results = [

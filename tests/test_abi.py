@@ -62,9 +62,10 @@ def test_ops_fail_loudly_without_gpu(lib_built):
         pytest.skip("GPU present")
     from biahub_amd.deskew import _fast_deskew_czyx
 
-    with pytest.raises(RuntimeError, match="no CPU path|no GPU visible"):
-        _fast_deskew_czyx(np.zeros((1, 4, 4, 4), np.float32), device="cpu", ls_angle_deg=30, px_to_scan_ratio=0.3,
-                          keep_overhang=True)
+    from biahub_amd.register import apply_affine_transform
+
+    with pytest.raises(RuntimeError, match="no CPU path|no GPU visible"):   # no operator but deskew has a host path
+        apply_affine_transform(np.zeros((4, 4, 4), np.float32), np.eye(4), (4, 4, 4))
     with pytest.raises(RuntimeError, match="no GPU visible"):
         _fast_deskew_czyx(np.zeros((1, 4, 4, 4), np.float32), device="cuda", ls_angle_deg=30, px_to_scan_ratio=0.3,
                           keep_overhang=True)

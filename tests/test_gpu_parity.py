@@ -135,6 +135,25 @@ def test_deskew_persistent_kernel_equals_tile_kernel(gpu, monkeypatch):
                 assert torch.equal(new, old), (shape, fill)
 
 
+def test_host_deskew_equals_gpu_deskew(gpu):
+    """libbhcore's host implementation of the operator (bh_host_deskew, what `device: cpu` runs without a GPU) restates the
+    kernels' float32 arithmetic operation by operation: bit-identical without a fill, the fill value to float32 rounding."""
+    from biahub_amd.deskew import _fast_deskew_czyx
+
+    rng = np.random.default_rng(17)
+    for shape, n, dtype in (((40, 50, 64), 3, np.float32), ((33, 21, 70), 2, np.uint16), ((25, 16, 128), 1, np.float32)):
+        vol = (rng.random(shape) * 900 + 20).astype(dtype)
+        vol[5:9, 3:8, 10:30] = 0
+        for fill in (0, "mean"):
+            kw = dict(ls_angle_deg=36.17, px_to_scan_ratio=0.371, keep_overhang=True, average_n_slices=n, overhang_fill=fill)
+            host = _fast_deskew_czyx(vol[None], device="cpu", **kw)
+            dev = _fast_deskew_czyx(vol[None], device="cuda", **kw)
+            if fill == 0:
+                assert np.array_equal(host, dev), (shape, n)
+            else:
+                assert rel_err(host, dev) <= 1e-6, (shape, n)
+
+
 def test_deskew_errors(gpu):
     from biahub_amd.deskew import fast_deskew_zyx
 

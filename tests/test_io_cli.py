@@ -9,6 +9,7 @@ from click.testing import CliRunner
 
 from biahub_amd import io
 from biahub_amd.cli import cli, expand_eat_all
+from conftest import rel_err
 from oracle import oracle_np as O
 
 DESKEW_YML = ("pixel_size_um: 0.116\nls_angle_deg: 36.17\npx_to_scan_ratio: 0.371\nscan_step_um: 0.313\n"
@@ -673,3 +674,37 @@ def test_cli_compute_tf_apply_inv_tf_reconstruct(gpu, tmp_path):
     want = O.wo_apply_inverse_transfer_function(data[("A", "1", "0", 0, 0)], otf, 0, 1e-2, False)
     g3 = io.open_ome_zarr(out3 / "A/1/0")
     assert g3.channel_names == ["ch0_Density3D"] and np.abs(g3.data[0, 0] - want).max() <= 1e-4 * np.abs(want).max()
+
+
+def test_config1_host_deskew_golden_and_cli_without_gpu(tmp_path, deskew_cases):
+    """BASELINE config 1 as it reads — `deskew ... --cluster debug` with the reference's default `device: cpu` and NO GPU: the
+    operator runs libbhcore's own host implementation (bh_host_deskew; never the test oracle).  The host path against every
+    golden vector the reference produced (shapes, N, fills, dtypes, splits), then the CLI end to end on a (64, 256, 256)
+    position with example_deskew_settings.yml's parameters, checked against the oracle."""
+    import torch
+
+    from biahub_amd.deskew import _fast_deskew_czyx
+
+    z, meta = deskew_cases
+    for m in meta:
+        kw = dict(ls_angle_deg=m["angle"], px_to_scan_ratio=m["ratio"], keep_overhang=m["keep_overhang"],
+                  average_n_slices=m["n"], overhang_fill=m["fill"])
+        got = _fast_deskew_czyx(z[m["name"] + "__in"][None], device="cpu", num_splits=m["splits"] or 1, **kw)[0]
+        ref = z[m["name"] + "__out"]
+        ref = ref[0] if ref.ndim == 4 else ref
+        assert got.shape == ref.shape and got.dtype == np.float32, m
+        assert rel_err(got, ref) <= 1e-5, (m, rel_err(got, ref))
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the CLI would (rightly) take the GPU; the host path itself is covered above")
+    src = tmp_path / "in.zarr"
+    data = make_plate(src, positions=(("A", "1", "0"),), shape=(1, 1, 64, 256, 256), dtype=np.uint16)
+    cfg = tmp_path / "deskew.yml"
+    cfg.write_text(DESKEW_YML)  # no `device:` entry: DeskewSettings defaults to "cpu" like the reference
+    out = tmp_path / "out.zarr"
+    res = CliRunner().invoke(cli, expand_eat_all(["deskew", "-i", str(src / "A/1/0"), "-c", str(cfg), "-o", str(out),
+                                                  "--cluster", "debug"]))
+    assert res.exit_code == 0, res.output
+    got = io.open_ome_zarr(out / "A/1/0").data[0, 0]
+    want = O.fast_deskew_zyx(data[("A", "1", "0", 0, 0)].astype(np.float32), 36.17, 0.371, True, 3, "mean")
+    assert got.shape == want.shape == (86, 256, 380)
+    assert rel_err(got, want) <= 1e-5
