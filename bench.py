@@ -301,12 +301,17 @@ def end_to_end(vol_host_u16, psf, rl, iterations, dev, ctx):
     # i - 1 on three streams (what a plate job on one GPU can do; the reference's worker is the serial form above)
     try:
         per_unit, tl, legs = overlapped_units(vol_host_u16, rl, iterations, dev, ctx)
+        steady = (tl[-1][5] - tl[0][5]) / (len(tl) - 1) if len(tl) > 1 else per_unit * 1e3  # cadence of finished units
         res["overlapped"] = {"ms_per_unit": per_unit * 1e3, "voxels_per_s": V / per_unit, "units": len(tl),
+                             "steady_state_ms_per_unit": steady, "steady_state_voxels_per_s": V / steady * 1e3,
                              "legs_while_overlapped": legs, "ratio_to_compute_leg": per_unit * 1e3 / (comp * 1e3),
+                             "steady_state_ratio_to_compute_leg": steady / (comp * 1e3),
                              "timeline_ms": tl,
                              "note": "biahub_amd.pipeline.run_overlapped: H2D / compute / D2H of consecutive units on three streams, "
                                      "two pinned landing blocks, prepared R-L handle (no host synchronisation in the compute leg); "
-                                     "wall time of the batch / units; timeline rows = [h2d0, h2d1, compute0, compute1, d2h0, d2h1] "
+                                     "ms_per_unit = wall time of the batch / units (includes filling and draining the pipeline: one "
+                                     "upload before the first and one download after the last compute leg); steady_state = the cadence "
+                                     "at which finished units arrive; timeline rows = [h2d0, h2d1, compute0, compute1, d2h0, d2h1] "
                                      "per unit, ms since the first upload started"}
     except RuntimeError as e:  # pinned memory for two 17-GB landing blocks not available on this host
         res["overlapped"] = {"skipped": str(e)[:200]}
@@ -419,7 +424,10 @@ def main():
             per_unit, tl, legs = overlapped_units(host, rl_prepared, args.iterations, dev, ctx, n_units=args.host_fed_units)
             del host
             slowest = parallel.max_over_ranks(per_unit, dev)
+            steady = (tl[-1][5] - tl[0][5]) / (len(tl) - 1) / 1e3 if len(tl) > 1 else per_unit
+            steady = parallel.max_over_ranks(steady, dev)
             host_fed = {"ms_per_unit_slowest_rank": slowest * 1e3, "voxels_per_s": world * V / slowest,
+                        "steady_state_ms_per_unit_slowest_rank": steady * 1e3, "steady_state_voxels_per_s": world * V / steady,
                         "units_per_rank": args.host_fed_units, "legs_while_overlapped_rank0": legs,
                         "note": "every rank: pinned uint16 H2D -> R-L + deskew -> float32 D2H into pinned blocks, three streams "
                                 "(biahub_amd.pipeline.run_overlapped); all ranks at once, max over ranks; never `value`"}
@@ -477,7 +485,8 @@ def main():
                 "frac_moved": (rl_moved / rl_iter_s / 1e9 / HBM_PEAK_GBS) if rl_moved else None,
             },
             "roofline_deskew": {
-                "kernel": "deskew_kernel (fused shear-interpolate + N-mean)",
+                "kernel": "deskew_pers_kernel (fused shear-interpolate + N-mean + fill prologue; persistent, double-buffered LDS, "
+                          "loader / sampler wavefronts)",
                 "bound": "hbm",
                 "achieved": dk_bytes / deskew_s / 1e9,
                 "peak": HBM_PEAK_GBS,

@@ -244,7 +244,7 @@ def test_wave_private_x_pass_model():
     spec = importlib.util.spec_from_file_location("xw_model", Path(__file__).resolve().parent.parent / "tools" / "xw_model.py")
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    for logm in (9, 10):
+    for logm in (8, 9, 10):
         m.check(logm)
         x = m.XW(logm)
         # lane 0 owns the two self-mirrored groups, every other lane a group and the group of the mirrored frequencies
@@ -252,6 +252,36 @@ def test_wave_private_x_pass_model():
             g0, g1 = x.group_of(lam, 0), x.group_of(lam, 1)
             assert all(x.mirror(8 * g0 + n) == 8 * g1 + 7 - n for n in range(8))
         assert (x.group_of(0, 0), x.group_of(0, 1)) == (0, 1)
+
+
+def test_radix3_wave_private_x_pass_model():
+    """tools/x3_model.py is the executable specification of csrc/fftconv_x3.inc (rows of 1536 / 3072 voxels: radix-3 across
+    the thirds of a row, three register stages per third, LDS addresses and swizzles, untangle pairing of third 0 across
+    neighbouring lanes and of thirds 1 <-> 2 inside a lane, stored column order): checked against numpy's FFT."""
+    import importlib.util
+    import sys
+    from pathlib import Path
+
+    tools = Path(__file__).resolve().parent.parent / "tools"
+    sys.path.insert(0, str(tools))
+    try:
+        spec = importlib.util.spec_from_file_location("x3_model", tools / "x3_model.py")
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+    finally:
+        sys.path.remove(str(tools))
+    for logl in (8, 9):
+        m.check(logl, verbose=False)
+        x = m.X3(logl)
+        cyc, _ = x.lds_cycles()
+        for name, (actual, ideal) in cyc.items():   # every exchange access within 2x of conflict-free, DA / DB conflict-free
+            assert actual <= 2 * ideal, (name, actual, ideal)
+            assert not name.startswith(("DA", "DB")) or actual == ideal, (name, actual, ideal)
+        # third 0: the mirrored group sits in the neighbouring lane; thirds 1 <-> 2: complementary groups in one lane
+        for l in range(2, x.lg):
+            assert all(x.mirror_pos(x.dc(0, l, n)) == x.dc(0, l ^ 1, 7 - n) for n in range(8))
+        for l in range(x.lg):
+            assert x.group(1, l) + x.group(2, l) == x.lg - 1
 
 
 def test_get_transform_matrix_golden():
