@@ -1185,6 +1185,8 @@ static int launch_xw_m(bh_ctx* ctx, const xw::Params& p, int mode) {
         case xw::INV_RATIO: return run(xw::xw_kernel<LOGM, xw::INV_RATIO>);
         case xw::INV_UPDATE: return run(xw::xw_kernel<LOGM, xw::INV_UPDATE>);
         case xw::FUSED_RATIO: return run(xw::xw_kernel<LOGM, xw::FUSED_RATIO>);
+        case xw::FUSED_RATIO_WRAP: return run(xw::xw_kernel<LOGM, xw::FUSED_RATIO_WRAP>);
+        case xw::FUSED_UPDATE_WRAP: return run(xw::xw_kernel<LOGM, xw::FUSED_UPDATE_WRAP>);
         default: return run(xw::xw_kernel<LOGM, xw::FUSED_UPDATE>);
     }
 }
@@ -1573,7 +1575,8 @@ int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, const float* es
     return BH_OK;
 }
 
-// Richardson-Lucy at a wrap-padded box WITHOUT a fold pass (rows of 1536 / 3072 voxels: fftconv_x3.inc; Y unpadded).
+// Richardson-Lucy at a wrap-padded box WITHOUT a fold pass (rows the wave-private X passes take: fftconv_xw.inc / fftconv_x3.inc;
+// Y unpadded).
 // The estimate going into the convolution is wrap-extended by (lo below, hi above) the volume on the padded axes (z, x); the
 // ratio going into the correlation is wrap-extended too — by (hi below, lo above), the mirror image, which is what the
 // correlation's taps reach — instead of zero-padded, so the correlation is already the circular one on the volume's own box
@@ -1583,7 +1586,7 @@ int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, const float* es
 // a margin plane reads what another wavefront overwrites, the X passes run out of place here (two spectrum buffers, two
 // estimate buffers).  One iteration = the 8 passes of the unpadded path instead of 9 transform passes + a fold / rewrap pass.
 bool fftconv_rl_wrap_supported(const ConvPlan& pl, const int64_t N[3], const int64_t P[3]) {
-    return pl.x3 && N[1] == P[1] && getenv("BH_RL_NOWRAP") == nullptr;
+    return pl.xw && N[1] == P[1] && getenv("BH_RL_NOWRAP") == nullptr;  // any wave-private row length, Y unpadded
 }
 
 static int launch_x3_wrap(bh_ctx* ctx, const ConvPlan& pl, int mode, const cf* S_in, cf* S_out, float* out, const float* aux,
@@ -1603,6 +1606,7 @@ static int launch_x3_wrap(bh_ctx* ctx, const ConvPlan& pl, int mode, const cf* S
     p.eps = eps;
     p.wz = wz;
     p.wx = wx;
+    if (!pl.x3) return pl.d.M == 1024 ? launch_xw_m<10>(ctx, p, mode) : (pl.d.M == 512 ? launch_xw_m<9>(ctx, p, mode) : launch_xw_m<8>(ctx, p, mode));
     return pl.d.M == 1536 ? launch_x3_m<9>(ctx, p, mode) : launch_x3_m<8>(ctx, p, mode);
 }
 

@@ -1700,6 +1700,9 @@ def test_config2_full_size_oracle_parity(gpu):
     ((16, 32, 1500), (5, 3, 9)),     # z a power of two: only x is padded
     ((44, 64, 1536), (9, 5, 5)),     # x native (3 * 512), z -> 64
     ((30, 128, 1517), (4, 5, 17)),   # even extent along z; the deskewed row length of BASELINE config 4
+    ((21, 64, 1000), (7, 5, 9)),     # box (32, 64, 1024): power-of-two rows, the wrap modes of csrc/fftconv_xw.inc (two pairs per wave)
+    ((10, 32, 2000), (3, 3, 8)),     # box (16, 32, 2048): one pair per wavefront, even extent along x
+    ((12, 32, 500), (5, 3, 7)),      # box (16, 32, 512): four pairs per wavefront
 ])
 def test_richardson_lucy_wrap_padded_box(gpu, shape, pshape, monkeypatch):
     """Rows of 1536 / 3072 voxels at a wrap-padded box run Richardson-Lucy in the 8 passes of the unpadded path: estimate and
