@@ -461,7 +461,7 @@ int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, const float* es
 bool fftconv_rl_wrap_supported(const ConvPlan& pl, const int64_t N[3], const int64_t P[3]);
 int fftconv_richardson_lucy_wrap(bh_ctx* ctx, const ConvPlan& pl, const float* d_p, const cf* otf, bool otf_real, cf* spec_a,
                                  cf* spec_b, float* est_a, float* est_b, const int64_t N[3], const int64_t K[3], int iterations,
-                                 float eps, float** result);
+                                 float eps, float* out);
 int fftconv_forward(bh_ctx* ctx, const ConvPlan& pl, const float* in, cf* spec);
 int fftconv_inverse(bh_ctx* ctx, const ConvPlan& pl, cf* spec, float* out);
 int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t bytes, cf** spec);
@@ -730,16 +730,17 @@ static int rl_padded_run(bh_ctx* ctx, ConvPlan* pl, const float* d, const void* 
         BH_CHECK_HIP(hipEventRecord(e0, s));
     }
     float *cur = a, *nxt = b;
-    if (wrap) {
+    if (wrap) {  // the last pass stores the result cropped: no crop kernel
         BH_TRY(fftconv_richardson_lucy_wrap(ctx, *pl, dp, reinterpret_cast<const cf*>(otf), otf_real, spec, spec_b, a, b, N, K,
-                                            iterations, eps, &cur));
-    } else
-    for (int it = 0; it < iterations; ++it) {
-        BH_TRY(fftconv_rl_iteration_padded(ctx, *pl, cur, dp, reinterpret_cast<const cf*>(otf), otf_real, spec, eps, c));
-        hipLaunchKernelGGL(fold_update_rewrap_kernel, grid2(fold.P), dim3(256), 0, s, (const float*)c, (const float*)cur, nxt, fold);
-        std::swap(cur, nxt);
+                                            iterations, eps, out));
+    } else {
+        for (int it = 0; it < iterations; ++it) {
+            BH_TRY(fftconv_rl_iteration_padded(ctx, *pl, cur, dp, reinterpret_cast<const cf*>(otf), otf_real, spec, eps, c));
+            hipLaunchKernelGGL(fold_update_rewrap_kernel, grid2(fold.P), dim3(256), 0, s, (const float*)c, (const float*)cur, nxt, fold);
+            std::swap(cur, nxt);
+        }
+        hipLaunchKernelGGL(remap_kernel<false>, grid2(crop.D), dim3(256), 0, s, (const float*)cur, out, crop);
     }
-    hipLaunchKernelGGL(remap_kernel<false>, grid2(crop.D), dim3(256), 0, s, (const float*)cur, out, crop);
     BH_CHECK_HIP(hipGetLastError());
     if (e0) {
         BH_CHECK_HIP(hipEventRecord(e1, s));

@@ -1187,6 +1187,7 @@ static int launch_xw_m(bh_ctx* ctx, const xw::Params& p, int mode) {
         case xw::FUSED_RATIO: return run(xw::xw_kernel<LOGM, xw::FUSED_RATIO>);
         case xw::FUSED_RATIO_WRAP: return run(xw::xw_kernel<LOGM, xw::FUSED_RATIO_WRAP>);
         case xw::FUSED_UPDATE_WRAP: return run(xw::xw_kernel<LOGM, xw::FUSED_UPDATE_WRAP>);
+        case xw::INV_UPDATE_CROP: return run(xw::xw_kernel<LOGM, xw::INV_UPDATE_CROP>);
         default: return run(xw::xw_kernel<LOGM, xw::FUSED_UPDATE>);
     }
 }
@@ -1211,6 +1212,7 @@ static int launch_x3_m(bh_ctx* ctx, const xw::Params& p, int mode) {
         case xw::FUSED_RATIO: return run(x3::x3_kernel<LOGL, xw::FUSED_RATIO>);
         case xw::FUSED_RATIO_WRAP: return run(x3::x3_kernel<LOGL, xw::FUSED_RATIO_WRAP>);
         case xw::FUSED_UPDATE_WRAP: return run(x3::x3_kernel<LOGL, xw::FUSED_UPDATE_WRAP>);
+        case xw::INV_UPDATE_CROP: return run(x3::x3_kernel<LOGL, xw::INV_UPDATE_CROP>);
         default: return run(x3::x3_kernel<LOGL, xw::FUSED_UPDATE>);
     }
 }
@@ -1611,11 +1613,11 @@ static int launch_x3_wrap(bh_ctx* ctx, const ConvPlan& pl, int mode, const cf* S
 }
 
 // d_p: the data on the box, wrap-extended like the estimate (lo below, hi above): the first pass clips it into est_a
-// (e0 = max(d, 0)) and transforms it in one go.  est_a / est_b alternate; *result receives the buffer that holds the last
-// estimate (right on the volume's own voxels).
+// (e0 = max(d, 0)) and transforms it in one go.  est_a / est_b alternate; the last update is stored straight into `out`, the
+// UNPADDED (N[0], N[1], N[2]) result volume.
 int fftconv_richardson_lucy_wrap(bh_ctx* ctx, const ConvPlan& pl, const float* d_p, const cf* otf, bool otf_real, cf* spec_a,
                                  cf* spec_b, float* est_a, float* est_b, const int64_t N[3], const int64_t K[3], int iterations,
-                                 float eps, float** result) {
+                                 float eps, float* out) {
     const int CONV = otf_real ? COL_FILTER : COL_CONV, CORR = otf_real ? COL_FILTER : COL_CORR;
     const int64_t P[3] = {pl.d.Z, pl.d.Y, pl.d.X};
     xw::Params::Wrap we[3], wr[3];  // extension of the estimate (lo below, hi above) and of the ratio (hi below, lo above)
@@ -1635,14 +1637,13 @@ int fftconv_richardson_lucy_wrap(bh_ctx* ctx, const ConvPlan& pl, const float* d
         BH_TRY(launch_col(ctx, pl, COL_FWD, false, spec_b, nullptr, 1.f));
         BH_TRY(launch_col(ctx, pl, CORR, true, spec_b, otf, 1.f));
         BH_TRY(launch_col(ctx, pl, COL_INV, false, spec_b, nullptr, 1.f));
-        if (it + 1 == iterations) {  // the last update is needed on the volume's own voxels only: plain, in place
-            BH_TRY(launch_x(ctx, pl, true, XE_UPDATE, nullptr, spec_b, cur, cur, eps, false));
+        if (it + 1 == iterations) {  // the last update is needed on the volume's own voxels only: stored cropped
+            BH_TRY(launch_x3_wrap(ctx, pl, xw::INV_UPDATE_CROP, spec_b, nullptr, out, cur, eps, we[0], we[2]));
         } else {
             BH_TRY(launch_x3_wrap(ctx, pl, xw::FUSED_UPDATE_WRAP, spec_b, spec_a, nxt, cur, eps, we[0], we[2]));
             std::swap(cur, nxt);
         }
     }
-    *result = cur;
     return BH_OK;
 }
 

@@ -1703,6 +1703,8 @@ def test_config2_full_size_oracle_parity(gpu):
     ((21, 64, 1000), (7, 5, 9)),     # box (32, 64, 1024): power-of-two rows, the wrap modes of csrc/fftconv_xw.inc (two pairs per wave)
     ((10, 32, 2000), (3, 3, 8)),     # box (16, 32, 2048): one pair per wavefront, even extent along x
     ((12, 32, 500), (5, 3, 7)),      # box (16, 32, 512): four pairs per wavefront
+    ((40, 256, 1500), (5, 5, 9)),    # box (48, 256, 1536): 6144 row pairs — every wavefront walks several pairs (prefetch chain)
+    ((40, 256, 1000), (5, 5, 9)),    # box (48, 256, 1024): the same for the power-of-two kernels
 ])
 def test_richardson_lucy_wrap_padded_box(gpu, shape, pshape, monkeypatch):
     """Rows of 1536 / 3072 voxels at a wrap-padded box run Richardson-Lucy in the 8 passes of the unpadded path: estimate and
