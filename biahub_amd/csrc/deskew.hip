@@ -344,6 +344,9 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
 #ifndef BH_DK_PROBE
 #define BH_DK_PROBE 0  // timing probes with WRONG results: bit 0 = no output stores, bit 1 = no LDS reads in the sampler, bit 2 = no LDS-DMA
 #endif
+#ifndef BH_DK_PIPE
+#define BH_DK_PIPE 1
+#endif
 #ifndef BH_DK_NLOAD
 #define BH_DK_NLOAD 2  // loader wavefronts of the 8; 0: every wavefront loads and samples (and waits for its own stores once per tile)
 #endif
@@ -499,22 +502,35 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
             }
         }
         {
+            // the taps of the NEXT row are requested before this row is computed and stored (BH_DK_PIPE=0: A/B switch): the
+            // sampler's LDS latency is otherwise paid once per row — SQ counters put 38 % of its cycles in waits
+            float tp0[N][4], tp1[N][4];
+            auto load_taps = [&](int xl_) {
+                const float* tc = tb + min(xl_, TX - 1);
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        tp0[k][j] = (BH_DK_PROBE & 2) ? (float)(xl_ + k) : tc[i0[k][j]];
+                        tp1[k][j] = (BH_DK_PROBE & 2) ? (float)j : tc[i0[k][j] + PITCH];
+                    }
+            };
+            load_taps(wave);
             for (int xl = wave; xl < TX; xl += NWV) {
                 const int yo = g.X - 1 - (q.xt0 + xl);
                 const size_t orow_i = (size_t)q.a * g.X + yo;
                 float* orow = out + orow_i * g.Xp;
-                const float* tcol = tb + xl;
                 float acc[4];
+                if (!BH_DK_PIPE && xl != wave) load_taps(xl);
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float t0 = (BH_DK_PROBE & 2) ? (float)(xl + k) : tcol[i0[k][j]];
-                        const float t1 = (BH_DK_PROBE & 2) ? (float)j : tcol[i0[k][j] + PITCH];
-                        const float val = __builtin_fmaf(t1, w1[k][j], t0 * w0[k][j]);
+                        const float val = __builtin_fmaf(tp1[k][j], w1[k][j], tp0[k][j] * w0[k][j]);
                         acc[j] = (k == 0) ? val : acc[j] + val;
                     }
                 }
+                if (BH_DK_PIPE) load_taps(xl + NWV);  // clamped: the last round re-reads a row of the tile
                 float val[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) val[j] = (N > 1) ? div_small(acc[j], fN, rN) : acc[j];
