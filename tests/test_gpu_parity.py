@@ -962,7 +962,8 @@ def test_flat_field_golden_and_oracle(gpu, monkeypatch, bitsearch):
     rng = np.random.default_rng(12)
     # every staging width: 64 columns (uint16, Z = 1068 like a mantis position), 32 (float32, Z = 700), 8 (float32, Z = 4000)
     for shape, dt in (((1068, 3, 200), np.uint16), ((700, 2, 150), np.float32), ((4000, 1, 40), np.float32),
-                      ((512, 5, 64), np.int16), ((300, 7, 33), np.uint8), ((2, 9, 129), np.uint16)):
+                      ((512, 5, 64), np.int16), ((300, 7, 33), np.uint8), ((2, 9, 129), np.uint16),
+                      ((200, 4, 130), np.uint16), ((129, 3, 66), np.int16), ((511, 2, 256), np.uint16), ((384, 2, 300), np.uint8)):
         lo, hi = (-3000, 3000) if dt == np.int16 else ((0, 255) if dt == np.uint8 else (1, 4096))
         data = (rng.random(shape) * (hi - lo) + lo).astype(dt)
         if dt == np.float32:
