@@ -458,7 +458,7 @@ int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, con
                             float eps, float* est);
 int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, const float* est_p, const float* d_p, const cf* otf,
                                 bool otf_real, cf* spec, float eps, float* corr_p);
-bool fftconv_rl_wrap_supported(const ConvPlan& pl, const int64_t N[3], const int64_t P[3]);
+bool fftconv_rl_wrap_supported(const ConvPlan& pl, const int64_t N[3], const int64_t K[3], const int64_t P[3]);
 int fftconv_richardson_lucy_wrap(bh_ctx* ctx, const ConvPlan& pl, const float* d_p, const cf* otf, bool otf_real, cf* spec_a,
                                  cf* spec_b, float* est_a, float* est_b, const int64_t N[3], const int64_t K[3], int iterations,
                                  float eps, float* out);
@@ -689,7 +689,7 @@ static int rl_padded_run(bh_ctx* ctx, ConvPlan* pl, const float* d, const void* 
     const int64_t VP = P[0] * P[1] * P[2];
     hipStream_t s = ctx->stream;
     const size_t NS = fftconv_spectrum_elems(*pl);
-    const bool wrap = fftconv_rl_wrap_supported(*pl, N, P);  // no fold pass: fftconv_richardson_lucy_wrap
+    const bool wrap = fftconv_rl_wrap_supported(*pl, N, K, P);  // no fold pass: fftconv_richardson_lucy_wrap
     float *a, *b, *c = nullptr, *dp;
     cf *spec, *spec_b = nullptr;
     BH_TRY(get_scratch(ctx, "fft_real", VP * sizeof(float), (void**)&a));

@@ -1587,8 +1587,9 @@ int fftconv_rl_iteration_padded(bh_ctx* ctx, const ConvPlan& pl, const float* es
 // spectrum and the epilogue operand of the plane it mirrors and redo that plane's row — no pass over memory of its own.  Because
 // a margin plane reads what another wavefront overwrites, the X passes run out of place here (two spectrum buffers, two
 // estimate buffers).  One iteration = the 8 passes of the unpadded path instead of 9 transform passes + a fold / rewrap pass.
-bool fftconv_rl_wrap_supported(const ConvPlan& pl, const int64_t N[3], const int64_t P[3]) {
-    return pl.xw && N[1] == P[1] && getenv("BH_RL_NOWRAP") == nullptr;  // any wave-private row length, Y unpadded
+bool fftconv_rl_wrap_supported(const ConvPlan& pl, const int64_t N[3], const int64_t K[3], const int64_t P[3]) {
+    // any wave-private row length, Y unpadded; the two x strips (K - 1 floats) travel through the head of a row's LDS buffer
+    return pl.xw && N[1] == P[1] && K[2] <= 256 && getenv("BH_RL_NOWRAP") == nullptr;
 }
 
 static int launch_x3_wrap(bh_ctx* ctx, const ConvPlan& pl, int mode, const cf* S_in, cf* S_out, float* out, const float* aux,

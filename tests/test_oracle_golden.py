@@ -345,3 +345,31 @@ def test_oracle_inverse_filter_z_padding_mirrors_edge_planes():
         assert np.allclose(got[:-1], x[1:], atol=1e-5)
         want_last = x[-1] if pad < 4 else np.zeros_like(x[-1])   # mirrored edge plane, or the zero fallback
         assert np.allclose(got[-1], want_last, atol=1e-5), pad
+
+
+def test_oracle_richardson_lucy_against_spatial_domain_restatement():
+    """Richardson-Lucy has no reference implementation (parity unpinned by construction); what the oracle must be is the
+    DEFINITION in DESIGN.md 2.3.  This restates that definition in the spatial domain — circular convolution and correlation as
+    explicit sums of rolled copies, no FFT anywhere — and holds the FFT oracle to it, for odd and even PSF extents (the centre
+    convention: tap k of an axis of extent K sits at offset k - K // 2)."""
+    rng = np.random.default_rng(4)
+    for shape, pshape in (((6, 7, 9), (3, 3, 5)), ((5, 8, 6), (2, 4, 3)), ((4, 4, 4), (3, 1, 2))):
+        d = (rng.random(shape) * 50 + 5).astype(np.float64)
+        d[0, 0, 0] = -3.0                                   # clipped by e0 = max(d, 0)
+        psf = rng.random(pshape) + 0.1
+        h = psf / psf.sum()
+
+        def conv(x, flip):
+            out = np.zeros_like(x)
+            for k in np.ndindex(*pshape):
+                off = tuple(ki - K // 2 for ki, K in zip(k, pshape))
+                # (h * x)[n] = sum_k h[k] x[n - off_k];  correlation: x[n + off_k]
+                out += h[k] * np.roll(x, tuple(-o if flip else o for o in off), axis=(0, 1, 2))
+            return out
+
+        est = np.maximum(d, 0.0)
+        for _ in range(4):
+            ratio = d / np.maximum(conv(est, False), 1e-6)
+            est = np.maximum(est * conv(ratio, True), 0.0)
+        got = O.richardson_lucy_zyx(d.astype(np.float32), psf.astype(np.float32), iterations=4, eps=1e-6)
+        assert np.abs(got - est).max() <= 2e-5 * np.abs(est).max(), (shape, pshape)
