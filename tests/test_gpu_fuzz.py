@@ -84,6 +84,40 @@ def test_fuzz_richardson_lucy_backends_vs_oracle(gpu, monkeypatch):
     print("hipFFT plans rebuilt after a failed self-check:", get_context(gpu).fft_plans_replaced())
 
 
+def test_fuzz_richardson_lucy_wrap_paths_vs_oracle(gpu, monkeypatch):
+    """Random volumes whose rows pad to a length the wave-private X passes take (512 ... 3072 voxels) with Y a power of two:
+    the wrap-padded box without a fold pass (csrc/fftconv_xw.inc / fftconv_x3.inc WRAP modes, cropped last update) for random
+    odd and even PSF extents, a prepared handle reused across two volumes, against the oracle and the fold path."""
+    from biahub_amd.deconvolve import PreparedRichardsonLucy, richardson_lucy
+
+    rng = np.random.default_rng(77)
+    boxes = set()
+    for trial in range(10):
+        X = int(rng.choice([rng.integers(400, 505), rng.integers(900, 1010), rng.integers(1300, 1525), rng.integers(1800, 2040),
+                            rng.integers(2700, 3060)]))
+        Y = int(rng.choice([32, 64]))
+        Z = int(rng.integers(5, 30))
+        shape = (Z, Y, X)
+        pshape = (int(rng.integers(1, min(6, Z // 2 + 1))), int(rng.integers(1, 6)), int(rng.integers(2, 12)))
+        psfh = (rng.random(pshape) + 0.05).astype(np.float32)
+        with PreparedRichardsonLucy(psfh, shape, gpu) as h:
+            if h.backend != "engine-padded":
+                continue
+            boxes.add(h.box[2])
+            for seed in (0, 1):
+                volh = (np.random.default_rng(trial * 2 + seed).random(shape) * 300).astype(np.float32)
+                volh[0, :, -1] += 500.0
+                volh[-1, 0, :] += 250.0
+                want = O.richardson_lucy_zyx(volh, psfh, iterations=3, eps=1e-6)
+                got = h(torch.from_numpy(volh).to(gpu), 3, 1e-6).cpu().numpy()
+                assert rel_err(got, want) <= 1e-4, (shape, pshape, h.box, rel_err(got, want))
+        monkeypatch.setenv("BH_RL_NOWRAP", "1")
+        fold = richardson_lucy(torch.from_numpy(volh).to(gpu), torch.from_numpy(psfh).to(gpu), 3, 1e-6).cpu().numpy()
+        monkeypatch.delenv("BH_RL_NOWRAP")
+        assert rel_err(got, fold) <= 3e-5, (shape, pshape)
+    assert len(boxes) >= 3, boxes
+
+
 def test_fuzz_deskew_flatfield_affine_vs_oracle(gpu):
     from biahub_amd.deskew import fast_deskew_zyx
     from biahub_amd.flat_field import flat_field_zyx, median_z_device
