@@ -982,8 +982,11 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
         colz::make_tables(h);
         BH_TRY(upload(h, &pl.colz));
     }
-    if (Z == colz3::N && pl.d.XP >= colz3::W) {
-        colz3::make_tables(h);
+    if (Z == 384 && pl.d.XP >= 32) {
+        colz3::make_tables<7>(h);
+        BH_TRY(upload(h, &pl.colz3));
+    } else if (Z == 768 && pl.d.XP >= 16) {
+        colz3::make_tables<8>(h);
         BH_TRY(upload(h, &pl.colz3));
     }
     if (xw_on) {
@@ -1092,26 +1095,29 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
             default: return run(colz::colz_kernel<COL_PCC>);
         }
     }
-    // 384-point Z passes with a spectral product (the deskewed config-4 volume's box): register stages (BH_FC_COLZ3=0: A/B switch)
-    if (zaxis && pl.colz3 && p.N == colz3::N && (mode == COL_CONV || mode == COL_CORR || mode == COL_FILTER) &&
+    // 384- / 768-point Z passes with a spectral product (the boxes of the deskewed config-4 / config-2 volumes): register stages
+    // (BH_FC_COLZ3=0: A/B switch)
+    if (zaxis && pl.colz3 && (p.N == 384 || p.N == 768) && (mode == COL_CONV || mode == COL_CORR || mode == COL_FILTER) &&
         !(getenv("BH_FC_COLZ3") && atoi(getenv("BH_FC_COLZ3")) == 0)) {
-        p.W = colz3::W;
         p.tw = pl.colz3;
-        p.ncoltiles = (int)ceil_div(p.XP, p.W);
-        const long ntiles = (long)p.nouter * p.ncoltiles;
-        const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
-        auto run = [&](auto kern) -> int {
-            BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)colz3::LDS_BYTES));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(colz3::NT), colz3::LDS_BYTES, ctx->stream, p);
+        auto run = [&](auto kern, int w, int nt, int lds) -> int {
+            p.W = w;
+            p.ncoltiles = (int)ceil_div(p.XP, p.W);
+            const long ntiles = (long)p.nouter * p.ncoltiles;
+            const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
+            BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, ctx->stream, p);
             BH_CHECK_HIP(hipGetLastError());
             return BH_OK;
         };
-        switch (mode) {
-            case COL_CONV: return run(colz3::colz3_kernel<COL_CONV>);
-            case COL_CORR: return run(colz3::colz3_kernel<COL_CORR>);
-            default: return run(colz3::colz3_kernel<COL_FILTER>);
-        }
+#define BH_COLZ3(LOGL_)                                                                                                       \
+    switch (mode) {                                                                                                           \
+        case COL_CONV: return run(colz3::colz3_kernel<LOGL_, COL_CONV>, colz3::Geo<LOGL_>::W, colz3::Geo<LOGL_>::NT, colz3::Geo<LOGL_>::LDS_BYTES); \
+        case COL_CORR: return run(colz3::colz3_kernel<LOGL_, COL_CORR>, colz3::Geo<LOGL_>::W, colz3::Geo<LOGL_>::NT, colz3::Geo<LOGL_>::LDS_BYTES); \
+        default: return run(colz3::colz3_kernel<LOGL_, COL_FILTER>, colz3::Geo<LOGL_>::W, colz3::Geo<LOGL_>::NT, colz3::Geo<LOGL_>::LDS_BYTES);     \
+    }
+        if (p.N == 384) { BH_COLZ3(7) } else { BH_COLZ3(8) }
+#undef BH_COLZ3
     }
     // columns of 256 / 512 / 1024 points: the register-stage kernels (BH_FC_COLW=0 keeps the LDS-stepped ones: A/B switch)
     const cf* colw_tab = zaxis ? pl.colw_z : pl.colw_y;

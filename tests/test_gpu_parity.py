@@ -1739,9 +1739,10 @@ def test_richardson_lucy_wrap_padded_box(gpu, shape, pshape, monkeypatch):
         assert rel_err(got, O.richardson_lucy_zyx(vol, sym, iterations=3, eps=1e-6)) <= FFT_TOL
 
 
-@pytest.mark.parametrize("shape,pshape", [((384, 32, 64), (7, 3, 5)), ((384, 64, 160), (9, 5, 5)), ((350, 32, 1500), (9, 3, 9))])
+@pytest.mark.parametrize("shape,pshape", [((384, 32, 64), (7, 3, 5)), ((384, 64, 160), (9, 5, 5)), ((350, 32, 1500), (9, 3, 9)),
+                                          ((768, 32, 64), (7, 3, 5)), ((768, 32, 72), (5, 5, 3)), ((700, 32, 1500), (9, 3, 9))])
 def test_radix3_register_z_pass(gpu, shape, pshape, monkeypatch):
-    """384-point Z passes (3 x 128: the box of the deskewed BASELINE config-4 volume) with a spectral product run register
+    """384- and 768-point Z passes (3 x 128, 3 x 256: the boxes of the deskewed BASELINE config-4 / config-2 volumes) with a spectral product run register
     stages (csrc/fftconv_colz3.inc: radix-3 + radix-2 in registers, two radix-8 steps, four LDS round trips).  Real transfer
     function (symmetric PSF) and complex convolution / correlation (asymmetric PSF) agree with the oracle and with the LDS-step
     kernel (BH_FC_COLZ3=0) on the same inputs, including a ragged last column tile and the wrap-padded path."""
