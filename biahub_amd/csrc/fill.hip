@@ -253,12 +253,19 @@ __global__ __launch_bounds__(256) void apply_fill_kernel(float* __restrict__ dat
         m = (c * 64 + lane < W32) ? w[lane] : 0u;
         mnext = (c * 64 + 64 < W32) ? w[64] : 0u;
     };
-    long u = (long)blockIdx.x * 4 + wave;
+#ifndef BH_FILL_CONTIG
+#define BH_FILL_CONTIG 1  // a wavefront walks a CONTIGUOUS range of units (2.1 MB of voxels) instead of every (4 x grid)-th one: 2.69 -> 2.25 ms
+                          // at config 2 (same box, tools/time_deskew.py: fill passes 4.85 -> 4.4 ms); 0 is the A/B switch
+#endif
+    const long per = (nunits + step - 1) / step;
+    long u = BH_FILL_CONTIG ? ((long)blockIdx.x * 4 + wave) * per : (long)blockIdx.x * 4 + wave;
+    const long ustep = BH_FILL_CONTIG ? 1 : step;
+    const long uend = BH_FILL_CONTIG ? min(nunits, u + per) : nunits;
     uint32_t m = 0u, mnext = 0u;
-    if (u < nunits) load_words(u, m, mnext);
-    for (; u < nunits; u += step) {
+    if (u < uend) load_words(u, m, mnext);
+    for (; u < uend; u += ustep) {
         const uint32_t cur = m, curn = mnext;
-        if (u + step < nunits) load_words(u + step, m, mnext);
+        if (u + ustep < uend) load_words(u + ustep, m, mnext);
         if (__ballot(cur != 0u) == 0ull && curn == 0u) continue;
         const long row = u / nchunk;
         const int c = (int)(u - row * nchunk);
