@@ -30,7 +30,12 @@ def run_overlapped(items: Iterable, upload: Callable, compute: Callable, downloa
     timing events per unit — ``timeline_ms`` turns them into milliseconds once everything has finished.
     """
     dev = resolve_device(device)
-    s_in, s_c, s_out = (torch.cuda.Stream(dev) for _ in range(3))
+    # The download leg is NOT a DMA transfer on this platform: ROCclr copies device -> pinned host memory with a blit kernel
+    # (`__amd_rocclr_copyBuffer`, profiles/r03_d2h_probe.txt — HSA_ENABLE_SDMA / GPU_BLIT_ENGINE_TYPE do not change that), which
+    # shares the CUs with the compute leg for as long as the copy takes.  The compute stream therefore gets the higher priority:
+    # its workgroups are dispatched ahead of the copy kernel's.
+    s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    s_c = torch.cuda.Stream(dev, priority=-1)
     staged: deque = deque()   # (uploaded, event): waiting for compute
     landing: deque = deque()  # (handed, event): waiting for the copy back to finish
 
