@@ -103,6 +103,7 @@ namespace bh {
 
 // returns a device buffer of at least `bytes`, cached under `name`
 int get_scratch(bh_ctx* ctx, const char* name, size_t bytes, void** out);
+int free_scratch(bh_ctx* ctx, const char* name);
 int get_plans(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, FftPlans** out);
 // real (Z,Y,X) -> half spectrum (Z,Y,X/2+1), unnormalised
 int fft_forward(const FftPlans* pl, const float* real, float2* spec);

@@ -35,6 +35,16 @@ int get_scratch(bh_ctx* ctx, const char* name, size_t bytes, void** out) {
     return BH_OK;
 }
 
+// gives a named scratch buffer back to the driver (transients of a one-off set-up: hundreds of milliseconds for gigabytes)
+int free_scratch(bh_ctx* ctx, const char* name) {
+    auto it = ctx->scratch.find(name);
+    if (it == ctx->scratch.end() || !it->second.ptr) return BH_OK;
+    BH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    BH_CHECK_HIP(hipFree(it->second.ptr));
+    ctx->scratch.erase(it);
+    return BH_OK;
+}
+
 // ---- plan self-check ---------------------------------------------------------------------------------------------
 // rocFFT 1.0.36 (ROCm 7.2) can hand back a 3-D real plan that computes garbage, depending on which other plans the process
 // created before (tools/hipfft_two_plans.cpp, tools/hipfft_plan3d_sweep.cpp).  Such a plan is wrong from its

@@ -1102,6 +1102,10 @@ int bh_richardson_lucy_create(bh_ctx* ctx, const float* psf, int64_t pz, int64_t
                            (int64_t)NS);
         if (hipGetLastError() != hipSuccess) return (set_error("real_part_kernel launch failed"), fail(BH_ERR_HIP));
     }
+    // the transients of the set-up go back to the driver: the complex transfer function when only its real part is kept (and
+    // with it the one-shot path's cache), the padded PSF when the apply path has no use for a real-volume scratch of its own
+    if (h->otf_real && (rc = free_scratch(ctx, "fc_otf")) != BH_OK) return fail(rc);
+    if (h->backend == BH_RL_ENGINE && (rc = free_scratch(ctx, "fft_real")) != BH_OK) return fail(rc);
     *out = h;
     return BH_OK;
 }
