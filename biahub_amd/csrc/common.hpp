@@ -134,4 +134,10 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 void* filter_pool_take(int device, size_t bytes);
 void filter_pool_give(int device, size_t bytes, void* p);
 
+// |value| and flat index of a running argmax (np.argmax semantics: the FIRST occurrence of the maximum wins)
+struct ArgMax {
+    float v;
+    long long i;
+};
+
 }  // namespace bh

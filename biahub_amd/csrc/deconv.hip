@@ -392,10 +392,6 @@ __global__ void pcc_product_kernel(cf* __restrict__ f1, const cf* __restrict__ f
     }
 }
 
-struct ArgMax {
-    float v;
-    long long i;
-};
 __device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {  // np.argmax: first occurrence of the maximum
     if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
     return a;
@@ -465,7 +461,9 @@ int fftconv_richardson_lucy_wrap(bh_ctx* ctx, const ConvPlan& pl, const float* d
 int fftconv_forward(bh_ctx* ctx, const ConvPlan& pl, const float* in, cf* spec);
 int fftconv_inverse(bh_ctx* ctx, const ConvPlan& pl, cf* spec, float* out);
 int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t bytes, cf** spec);
-int fftconv_pcc(bh_ctx* ctx, const ConvPlan& pl, const float* ref, const float* mov, cf* s1, cf* s2, int norm, float scale, float* corr);
+bool fftconv_pcc_peak_only(const ConvPlan& pl);
+int fftconv_pcc(bh_ctx* ctx, const ConvPlan& pl, const float* ref, const float* mov, cf* s1, cf* s2, int norm, float scale, float* corr,
+                ArgMax* partial, int* npartial);
 int fftconv_tikhonov(bh_ctx* ctx, const ConvPlan& pl, const float* in, const float* tf_full, float reg, cf* spec,
                      float* filt, float* out);
 
@@ -668,7 +666,11 @@ static bool engine_pad_box(const int64_t N[3], const int64_t K[3], int64_t P[3])
         // 5 * 2^k or 3 * 2^k (odd first step of that axis' transform) when that is enough
         if (radix3 && P[a] >= 16) {
             const int64_t p5 = 5 * (P[a] / 8), p3 = 3 * (P[a] / 4);
-            if (p5 >= need && alone(p5)) P[a] = p5;
+            // Rows of 1536 / 3072 voxels run the wave-private radix-3 X passes (fftconv_x3.inc) and, with them, the wrap-padded
+            // iteration without a fold pass; rows of 5 * 2^k voxels still take the tile X passes, which cost ~1.6x as much per
+            // voxel (158 against 98 ms on the config-4 box) — more than the 1.2x larger box.  BH_RL_X5=1: old choice.
+            const bool x3_rows = a == 2 && (p3 == 1536 || p3 == 3072) && getenv("BH_RL_X5") == nullptr;
+            if (p5 >= need && alone(p5) && !(x3_rows && alone(p3))) P[a] = p5;
             else if (p3 >= need && alone(p3)) P[a] = p3;
         }
         if (K[a] - 1 >= N[a]) return false;  // the wrap below assumes margins shorter than the axis
@@ -796,7 +798,10 @@ static int rl_plan(int64_t pz, int64_t py, int64_t px, int64_t Z, int64_t Y, int
     const char* be = getenv("BH_FFT_BACKEND");
     const bool hipfft_forced = be != nullptr && strcmp(be, "hipfft") == 0;
     if (!hipfft_forced && !nopad && !(force && force[0] == '0') && engine_pad_box(N, K, PE)) {
-        const double cost_engine = (double)PE[0] * PE[1] * PE[2] / 3.9, cost_lib = (double)P[0] * P[1] * P[2] / 1.9;
+        // (round 3: rows the wave-private X passes take, Y unpadded, run the 8-pass wrap-padded iteration at ~6 Gvox/s)
+        const bool wrap_rows = (PE[2] == 512 || PE[2] == 1024 || PE[2] == 2048 || PE[2] == 1536 || PE[2] == 3072) && PE[1] == N[1] &&
+                               K[2] <= 256 && getenv("BH_RL_NOWRAP") == nullptr;
+        const double cost_engine = (double)PE[0] * PE[1] * PE[2] / (wrap_rows ? 6.0 : 3.9), cost_lib = (double)P[0] * P[1] * P[2] / 1.9;
         if ((force && force[0] == '1') || cost_engine < cost_lib) {
             for (int a = 0; a < 3; ++a) box[a] = PE[a];
             return BH_RL_ENGINE_PADDED;
@@ -861,18 +866,23 @@ int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t
     BH_REQUIRE(Xc >= 2, "X must be at least 2");
     const int64_t V = Z * Y * Xc;
     cf *s1, *s2;
-    float* corr;
+    float* corr = nullptr;
     ArgMax *partial, *result;
     const int nblk = ctx->num_cus * 8;
-    BH_TRY(get_scratch(ctx, "fft_real", Z * Y * X * sizeof(float), (void**)&corr));
+    int npartial = nblk;
     BH_TRY(get_scratch(ctx, "pcc_partial", (nblk + 1) * sizeof(ArgMax), (void**)&partial));
     result = partial + nblk;
     hipStream_t s = ctx->stream;
-    if (use_fused_engine_any_order(Z, Y, X)) {
+    ConvPlan* cp = nullptr;
+    const bool engine = use_fused_engine_any_order(Z, Y, X);
+    if (engine) BH_TRY(fftconv_plan(ctx, Z, Y, X, &cp));
+    // Only the peak is wanted and the rows are ones the wave-private X kernels take: the last inverse pass keeps the argmax
+    // candidates itself and the correlation volume never exists (no store, no search pass, no scratch volume).
+    const bool peak_only = engine && !corr_shifted && !getenv("BH_PCC_UNFUSED") && fftconv_pcc_peak_only(*cp);
+    if (!peak_only) BH_TRY(get_scratch(ctx, "fft_real", Z * Y * X * sizeof(float), (void**)&corr));
+    if (engine) {
         // power-of-two (z, y also 3 * 2^k) volume: six in-place passes each way on the fused engine instead of hipFFT's
         // transposing pipeline; the normalised product treats every coefficient alike, so their order does not matter
-        ConvPlan* cp;
-        BH_TRY(fftconv_plan(ctx, Z, Y, X, &cp));
         const size_t NSf = fftconv_spectrum_elems(*cp);
         BH_TRY(get_scratch(ctx, "fc_spec", NSf * sizeof(cf), (void**)&s1));
         BH_TRY(get_scratch(ctx, "pcc_spec2", NSf * sizeof(cf), (void**)&s2));
@@ -884,7 +894,8 @@ int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t
                                (float)(2.0 / (double)V));
             BH_TRY(fftconv_inverse(ctx, *cp, s1, corr));
         } else {
-            BH_TRY(fftconv_pcc(ctx, *cp, ref, mov, s1, s2, normalization, (float)(2.0 / (double)V), corr));
+            BH_TRY(fftconv_pcc(ctx, *cp, ref, mov, s1, s2, normalization, (float)(2.0 / (double)V), corr, partial, &npartial));
+            BH_REQUIRE(npartial <= nblk, "internal: %d argmax candidates for %d slots", npartial, nblk);
         }
     } else {
         FftPlans *pl, *plc;
@@ -899,8 +910,8 @@ int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t
                            (float)(1.0 / (double)V));
         BH_TRY(fft_inverse(plc, s1, corr));
     }
-    hipLaunchKernelGGL(pcc_argmax_kernel, dim3(nblk), dim3(256), 0, s, corr, corr_shifted, Z, Y, Xc, partial);
-    hipLaunchKernelGGL(pcc_argmax_final_kernel, dim3(1), dim3(256), 0, s, partial, nblk, result);
+    if (!peak_only) hipLaunchKernelGGL(pcc_argmax_kernel, dim3(nblk), dim3(256), 0, s, corr, corr_shifted, Z, Y, Xc, partial);
+    hipLaunchKernelGGL(pcc_argmax_final_kernel, dim3(1), dim3(256), 0, s, partial, peak_only ? npartial : nblk, result);
     BH_CHECK_HIP(hipGetLastError());
     ArgMax h;
     BH_CHECK_HIP(hipMemcpyAsync(&h, result, sizeof(h), hipMemcpyDeviceToHost, s));

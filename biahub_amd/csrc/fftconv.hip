@@ -514,12 +514,24 @@ enum ColMode { COL_FWD = 0, COL_INV = 1, COL_FWD_SCALE = 2, COL_CONV = 3, COL_CO
 __device__ __forceinline__ float2 pcc_bin(float2 a, float2 b, int mode, float scale) {
     const float eps = 1.1920929e-07f;  // np.finfo(complex64).eps
     float2 p = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
-    float nrm = 1.0f;
-    if (mode == BH_PCC_NORM_MAGNITUDE) nrm = fmaxf(hypotf(p.x, p.y), eps);
-    if (mode == BH_PCC_NORM_CLASSIC) nrm = hypotf(a.x, a.y) * hypotf(b.x, b.y);
-    p.x = (p.x / nrm) * scale;
-    p.y = (p.y / nrm) * scale;
-    return p;
+    if (mode == BH_PCC_NORM_NONE) return make_float2(p.x * scale, p.y * scale);
+    if (mode == BH_PCC_NORM_CLASSIC) {
+        const float nrm = hypotf(a.x, a.y) * hypotf(b.x, b.y);
+        return make_float2((p.x / nrm) * scale, (p.y / nrm) * scale);
+    }
+    // magnitude: p / max(|p|, eps).  |p|^2 leaves the float range for the low frequencies of a large volume, so p is brought to
+    // q = p 2^-e with max(|q.x|, |q.y|) in [1/2, 1) first: p / |p| = q / |q| is one reciprocal square root (1 ulp) and two
+    // products instead of hypotf and two correctly rounded divisions — a fifth of the instructions, in the Z pass whose
+    // arithmetic showed (6.5 ms against 5.1 ms for the complex product on the same bytes)
+    const float big = fmaxf(fabsf(p.x), fabsf(p.y));
+    const int e = big > 0.0f ? __builtin_amdgcn_frexp_expf(big) : 0;
+    const float qx = __builtin_amdgcn_ldexpf(p.x, -e), qy = __builtin_amdgcn_ldexpf(p.y, -e);
+    const float qq = qx * qx + qy * qy;  // in [1/4, 2) unless p == 0
+    const float rs = __builtin_amdgcn_rsqf(qq);
+    const float mag = __builtin_amdgcn_ldexpf(qq * rs, e);  // |p| (inf beyond the float range: still >= eps)
+    if (mag >= eps) return make_float2(qx * (rs * scale), qy * (rs * scale));
+    const float s = scale / eps;
+    return make_float2(p.x * s, p.y * s);
 }
 
 struct ColParams {
@@ -1174,10 +1186,11 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
 }
 
 template <int LOGM>
-static int launch_xw_m(bh_ctx* ctx, const xw::Params& p, int mode) {
+static int launch_xw_m(bh_ctx* ctx, const xw::Params& p, int mode, int* grid_out = nullptr) {
     using G = xw::Geo<LOGM>;
     const long npairs = (long)p.Z * (p.Y / 2);
     const int grid = (int)std::min<long>(ceil_div(npairs, (long)xw::NW * G::PAIRS), ctx->num_cus);
+    if (grid_out) *grid_out = grid;
     auto run = [&](auto kern) -> int {
         BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)G::LDS_BYTES));
@@ -1194,6 +1207,7 @@ static int launch_xw_m(bh_ctx* ctx, const xw::Params& p, int mode) {
         case xw::FUSED_RATIO_WRAP: return run(xw::xw_kernel<LOGM, xw::FUSED_RATIO_WRAP>);
         case xw::FUSED_UPDATE_WRAP: return run(xw::xw_kernel<LOGM, xw::FUSED_UPDATE_WRAP>);
         case xw::INV_UPDATE_CROP: return run(xw::xw_kernel<LOGM, xw::INV_UPDATE_CROP>);
+        case xw::INV_ARGMAX: return run(xw::xw_kernel<LOGM, xw::INV_ARGMAX>);
         default: return run(xw::xw_kernel<LOGM, xw::FUSED_UPDATE>);
     }
 }
@@ -1245,6 +1259,29 @@ static int launch_xw(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, con
                                        : (fuse_fwd ? xw::FUSED_UPDATE : xw::INV_UPDATE);
     if (pl.x3) return pl.d.M == 1536 ? launch_x3_m<9>(ctx, p, mode) : launch_x3_m<8>(ctx, p, mode);
     return pl.d.M == 1024 ? launch_xw_m<10>(ctx, p, mode) : (pl.d.M == 512 ? launch_xw_m<9>(ctx, p, mode) : launch_xw_m<8>(ctx, p, mode));
+}
+
+// inverse X pass that keeps only the first occurrence of max |.| (xw::INV_ARGMAX): `partial` receives *npartial entries
+static int launch_xw_argmax(bh_ctx* ctx, const ConvPlan& pl, cf* S, ArgMax* partial, int* npartial) {
+    xw::Params p;
+    p.norm_mean = nullptr;
+    p.S_out = nullptr;
+    p.wz = p.wx = xw::Params::Wrap{0, 0, 0, 0};
+    p.in = nullptr;
+    p.S = S;
+    p.out = reinterpret_cast<float*>(partial);
+    p.aux = nullptr;
+    p.tab = pl.xw_tab;
+    p.twy = pl.twy;
+    p.Z = pl.d.Z;
+    p.Y = pl.d.Y;
+    p.XP = pl.d.XP;
+    p.eps = 0.f;
+    int grid = 0;
+    BH_TRY(pl.d.M == 1024 ? launch_xw_m<10>(ctx, p, xw::INV_ARGMAX, &grid)
+                          : (pl.d.M == 512 ? launch_xw_m<9>(ctx, p, xw::INV_ARGMAX, &grid) : launch_xw_m<8>(ctx, p, xw::INV_ARGMAX, &grid)));
+    *npartial = grid * xw::NW;
+    return BH_OK;
 }
 
 static int launch_x(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, const float* in, cf* S, float* out,
@@ -1673,13 +1710,19 @@ int fftconv_inverse(bh_ctx* ctx, const ConvPlan& pl, cf* spec, float* out) {
 
 // corr = irfft( rfft(ref) * conj(rfft(mov)) / norm ) with the product inside the Z pass of `mov`'s transform: 7 passes for the two
 // forward transforms, the product and the inverse transform instead of 10 (spectrum layout and scaling as fftconv_forward /
-// fftconv_inverse: scale = 2 / V)
-int fftconv_pcc(bh_ctx* ctx, const ConvPlan& pl, const float* ref, const float* mov, cf* s1, cf* s2, int norm, float scale, float* corr) {
+// fftconv_inverse: scale = 2 / V).  corr == nullptr (rows the wave-private xw kernels take: fftconv_pcc_peak_only): the
+// correlation volume is not stored — the last pass leaves *npartial argmax candidates of |corr| in `partial` (at most
+// 8 per compute unit) for the caller's final reduction.
+bool fftconv_pcc_peak_only(const ConvPlan& pl) { return pl.xw && !pl.x3 && getenv("BH_PCC_NO_FUSED_PEAK") == nullptr; }
+int fftconv_pcc(bh_ctx* ctx, const ConvPlan& pl, const float* ref, const float* mov, cf* s1, cf* s2, int norm, float scale, float* corr,
+                ArgMax* partial, int* npartial) {
+    BH_REQUIRE(corr || (partial && npartial && fftconv_pcc_peak_only(pl)), "internal: correlation volume or peak buffer required");
     BH_TRY(fftconv_forward(ctx, pl, ref, s1));
     BH_TRY(launch_x(ctx, pl, false, 0, mov, s2, nullptr, nullptr, 0.f));
     BH_TRY(launch_col(ctx, pl, COL_FWD, false, s2, nullptr, 1.f));
     BH_TRY(launch_col(ctx, pl, COL_PCC, true, s2, s1, scale, norm));
     BH_TRY(launch_col(ctx, pl, COL_INV, false, s2, nullptr, 1.f));
+    if (!corr) return launch_xw_argmax(ctx, pl, s2, partial, npartial);
     BH_TRY(launch_x(ctx, pl, true, XE_STORE, nullptr, s2, corr, nullptr, 0.f));
     return BH_OK;
 }

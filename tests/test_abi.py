@@ -160,6 +160,12 @@ def test_richardson_lucy_plan_boxes(monkeypatch):
     assert plan((33, 17, 17), (683, 2048, 3034)) == ((768, 2048, 3072), "engine-padded")       # deskewed config 2: 8-row X passes
     assert plan((33, 17, 17), (683, 2048, 3100)) == ((720, 2048, 3125), "library")             # x beyond the engine's 3072
     assert plan((5, 5, 5), (15, 42, 50)) == ((15, 42, 50), "library")                          # 7-smooth and small
+    # rows that would fit 5 * 2^k take the next 3 * 2^k instead: wave-private X passes and no fold pass beat the smaller box
+    assert plan((33, 17, 17), (342, 1024, 2100)) == ((384, 1024, 3072), "engine-padded")
+    assert plan((33, 17, 17), (342, 1024, 1100)) == ((384, 1024, 1536), "engine-padded")
+    monkeypatch.setenv("BH_RL_X5", "1")
+    assert plan((33, 17, 17), (342, 1024, 2100)) == ((384, 1024, 2560), "engine-padded")
+    monkeypatch.delenv("BH_RL_X5")
     monkeypatch.setenv("BH_RL_ENGINE_PAD", "0")
     assert plan((33, 17, 17), (342, 1024, 1517)) == ((375, 1024, 1536), "library")
     monkeypatch.setenv("BH_RL_ENGINE_PAD", "1")

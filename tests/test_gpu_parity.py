@@ -857,6 +857,37 @@ def test_phase_cross_corr_golden_and_oracle(gpu):
         phase_cross_corr(ref, ref, normalization="l2")
 
 
+@pytest.mark.gpu
+def test_phase_cross_corr_peak_only(gpu):
+    """``want_corr=False`` on rows the wave-private X kernels take: the last inverse pass keeps the argmax candidates itself
+    (xw::INV_ARGMAX) and the correlation volume is never stored — same shift as the search over the stored volume and as the
+    oracle, including a tie between two equal peaks (np.argmax: the first one) and more row pairs than one launch round."""
+    from biahub_amd.estimate_stabilization import phase_cross_corr_device
+
+    rng = np.random.default_rng(21)
+    for shape, rolls in (((16, 32, 512), ((0, 0, 0), (5, -11, 200), (-8, 16, -256))), ((8, 16, 1024), ((3, 7, -500),)),
+                         ((4, 16, 2048), ((-2, 8, 1023),)), ((256, 128, 512), ((100, -50, 17),))):
+        ref = rng.random(shape, dtype=np.float32)
+        for roll in rolls:
+            mov = np.roll(ref, roll, axis=(0, 1, 2)) + 0.05 * rng.random(shape, dtype=np.float32)
+            for norm in (None, "magnitude", "classic"):
+                stored, _ = phase_cross_corr_device(ref, mov, norm, want_corr=True)
+                peak, corr = phase_cross_corr_device(ref, mov, norm, want_corr=False)
+                assert corr is None and np.array_equal(peak, stored), (shape, roll, norm, peak, stored)
+                if shape[0] <= 16:
+                    want, _ = O.phase_cross_corr(ref, mov, norm)
+                    assert np.array_equal(peak, want), (shape, roll, norm, peak, want)
+    # two peaks of one height: the correlation of an impulse with two impulses
+    ref = np.zeros((8, 16, 512), np.float32)
+    mov = np.zeros_like(ref)
+    ref[0, 0, 0] = 1.0
+    mov[2, 5, 300] = mov[6, 3, 40] = 1.0
+    for norm in (None, "magnitude"):
+        stored, _ = phase_cross_corr_device(ref, mov, norm, want_corr=True)
+        peak, _ = phase_cross_corr_device(ref, mov, norm, want_corr=False)
+        assert np.array_equal(peak, stored), (norm, peak, stored)
+
+
 # ----------------------------------------------------------------------------- registration estimate (N1)
 def test_registration_kernels_vs_oracle(gpu):
     """bh_image_stats / bh_smooth_shrink / bh_sobel / bh_mattes_mi against their NumPy restatements."""
@@ -1706,6 +1737,8 @@ def test_config2_full_size_oracle_parity(gpu):
     ((12, 32, 500), (5, 3, 7)),      # box (16, 32, 512): four pairs per wavefront
     ((40, 256, 1500), (5, 5, 9)),    # box (48, 256, 1536): 6144 row pairs — every wavefront walks several pairs (prefetch chain)
     ((40, 256, 1000), (5, 5, 9)),    # box (48, 256, 1024): the same for the power-of-two kernels
+    ((12, 32, 1100), (5, 3, 9)),     # 1108 columns needed: box (16, 32, 1536), not the 1280-voxel rows of the tile kernels
+    ((10, 32, 2300), (3, 3, 7)),     # 2306 needed: box (16, 32, 3072) rather than 2560
 ])
 def test_richardson_lucy_wrap_padded_box(gpu, shape, pshape, monkeypatch):
     """Rows of 1536 / 3072 voxels at a wrap-padded box run Richardson-Lucy in the 8 passes of the unpadded path: estimate and
