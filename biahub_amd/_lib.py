@@ -75,6 +75,9 @@ SIGNATURES = {
     "bh_richardson_lucy_destroy": (_int, [_vp]),
     "bh_richardson_lucy_info": (_int, [_vp, C.POINTER(_i64), C.POINTER(_int), C.POINTER(_int), C.POINTER(C.c_uint64)]),
     "bh_phase_cross_corr": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, C.POINTER(_f32), _vp]),
+    "bh_phase_cross_corr_create": (_int, [_vp, _vp, _i64, _i64, _i64, _int, C.POINTER(_vp)]),
+    "bh_phase_cross_corr_apply": (_int, [_vp, _vp, _vp, _int, _int, C.POINTER(_f32), _vp]),
+    "bh_phase_cross_corr_destroy": (_int, [_vp]),
     "bh_image_stats": (_int, [_vp, _vp, _i64, _i64, _i64, C.POINTER(_f64)]),
     "bh_smooth_shrink": (_int, [_vp, _vp, _i64, _i64, _i64, C.POINTER(_f64), C.POINTER(_int), _vp, C.POINTER(_i64),
                                 C.POINTER(_i64)]),

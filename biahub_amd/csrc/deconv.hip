@@ -378,7 +378,8 @@ __global__ void clip_copy_kernel(const float* __restrict__ in, float* __restrict
 
 // ---- phase cross-correlation (estimate_stabilization.py:199-256) -------------------------------------------
 // prod = F1 * conj(F2) / norm / V   (the 1/V makes the C2R a normalised irfftn)
-__global__ void pcc_product_kernel(cf* __restrict__ f1, const cf* __restrict__ f2, int64_t n, int mode, float inv_v) {
+// dst may be either factor's buffer (every thread reads its bin of both before it writes)
+__global__ void pcc_product_kernel(const cf* f1, const cf* f2, cf* dst, int64_t n, int mode, float inv_v) {
     const float eps = 1.1920929e-07f;  // np.finfo(complex64).eps
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const cf a = f1[i], b = f2[i];
@@ -388,7 +389,7 @@ __global__ void pcc_product_kernel(cf* __restrict__ f1, const cf* __restrict__ f
         if (mode == BH_PCC_NORM_CLASSIC) nrm = hypotf(a.x, a.y) * hypotf(b.x, b.y);
         p.x = (p.x / nrm) * inv_v;
         p.y = (p.y / nrm) * inv_v;
-        f1[i] = p;
+        dst[i] = p;
     }
 }
 
@@ -462,8 +463,8 @@ int fftconv_forward(bh_ctx* ctx, const ConvPlan& pl, const float* in, cf* spec);
 int fftconv_inverse(bh_ctx* ctx, const ConvPlan& pl, cf* spec, float* out);
 int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t bytes, cf** spec);
 bool fftconv_pcc_peak_only(const ConvPlan& pl);
-int fftconv_pcc(bh_ctx* ctx, const ConvPlan& pl, const float* ref, const float* mov, cf* s1, cf* s2, int norm, float scale, float* corr,
-                ArgMax* partial, int* npartial);
+int fftconv_pcc_apply(bh_ctx* ctx, const ConvPlan& pl, const float* img, cf* fixed, bool fixed_is_mov, bool roll, cf* s2, int norm,
+                      float scale, float* corr, ArgMax* partial, int* npartial);
 int fftconv_tikhonov(bh_ctx* ctx, const ConvPlan& pl, const float* in, const float* tf_full, float reg, cf* spec,
                      float* filt, float* out);
 
@@ -853,19 +854,47 @@ int bh_transfer_function(bh_ctx* ctx, const float* psf, int64_t pz, int64_t py, 
     return BH_OK;
 }
 
-int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t Z, int64_t Y, int64_t X,
-                        int normalization, float shift[3], float* corr_shifted) {
-    BH_REQUIRE(ctx && ref && mov && shift, "NULL argument");
+// ---- phase cross-correlation: one image's finished spectrum is kept (scratch for the one-shot call, a pooled block for a
+// prepared handle), the other image meets it inside its own transform
+struct PccShape {
+    int64_t Z, Y, X, Xc;  // Xc: the reference calls irfftn without a shape (estimate_stabilization.py:240), so for an odd X the
+                          // correlation volume comes back with X - 1 columns; the same half spectrum is inverted by a (Z, Y, Xc) plan
+    bool engine;
+    ConvPlan* cp;
+    size_t spec_elems;    // complex elements of one spectrum buffer
+};
+static int pcc_shape(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, PccShape* sh) {
     BH_REQUIRE(Z > 0 && Y > 0 && X > 0, "invalid shape");
-    BH_REQUIRE(normalization >= BH_PCC_NORM_NONE && normalization <= BH_PCC_NORM_CLASSIC, "unknown normalization %d",
-               normalization);
-    BH_CHECK_HIP(hipSetDevice(ctx->device));
-    // The reference calls irfftn without a shape (estimate_stabilization.py:240), so for an odd X the correlation
-    // volume comes back with X - 1 columns; the same half spectrum is inverted by a (Z, Y, Xc) plan here.
-    const int64_t Xc = (X & 1) ? X - 1 : X;
-    BH_REQUIRE(Xc >= 2, "X must be at least 2");
-    const int64_t V = Z * Y * Xc;
-    cf *s1, *s2;
+    sh->Z = Z, sh->Y = Y, sh->X = X, sh->Xc = (X & 1) ? X - 1 : X;
+    BH_REQUIRE(sh->Xc >= 2, "X must be at least 2");
+    sh->cp = nullptr;
+    // power-of-two (z, y also 3 * 2^k) volume: in-place passes on the fused engine instead of hipFFT's transposing pipeline;
+    // the normalised product treats every coefficient alike, so their order does not matter
+    sh->engine = use_fused_engine_any_order(Z, Y, X);
+    if (sh->engine) {
+        BH_TRY(fftconv_plan(ctx, Z, Y, X, &sh->cp));
+        sh->spec_elems = fftconv_spectrum_elems(*sh->cp);
+    } else {
+        sh->spec_elems = (size_t)(Z * Y * (X / 2 + 1));
+        // both library plans now: a new plan's round-trip self-check runs through the shared FFT scratch, which must not
+        // happen between the stored spectrum's transform and its use
+        FftPlans* pl;
+        BH_TRY(get_plans(ctx, Z, Y, X, &pl));
+        BH_TRY(get_plans(ctx, Z, Y, sh->Xc, &pl));
+    }
+    return BH_OK;
+}
+// the stored image's spectrum
+static int pcc_prepare(bh_ctx* ctx, const PccShape& sh, const float* fixed_img, cf* fixed) {
+    if (sh.engine) return fftconv_forward(ctx, *sh.cp, fixed_img, fixed);
+    FftPlans* pl;
+    BH_TRY(get_plans(ctx, sh.Z, sh.Y, sh.X, &pl));
+    return fft_forward(pl, fixed_img, fixed);
+}
+static int pcc_run(bh_ctx* ctx, const PccShape& sh, cf* fixed, bool fixed_is_second, bool roll, const float* img, int normalization,
+                   float shift[3], float* corr_shifted) {
+    const int64_t Z = sh.Z, Y = sh.Y, X = sh.X, Xc = sh.Xc, V = Z * Y * Xc;
+    cf* s2;
     float* corr = nullptr;
     ArgMax *partial, *result;
     const int nblk = ctx->num_cus * 8;
@@ -873,42 +902,42 @@ int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t
     BH_TRY(get_scratch(ctx, "pcc_partial", (nblk + 1) * sizeof(ArgMax), (void**)&partial));
     result = partial + nblk;
     hipStream_t s = ctx->stream;
-    ConvPlan* cp = nullptr;
-    const bool engine = use_fused_engine_any_order(Z, Y, X);
-    if (engine) BH_TRY(fftconv_plan(ctx, Z, Y, X, &cp));
     // Only the peak is wanted and the rows are ones the wave-private X kernels take: the last inverse pass keeps the argmax
     // candidates itself and the correlation volume never exists (no store, no search pass, no scratch volume).
-    const bool peak_only = engine && !corr_shifted && !getenv("BH_PCC_UNFUSED") && fftconv_pcc_peak_only(*cp);
+    const bool unfused = getenv("BH_PCC_UNFUSED") != nullptr;
+    const bool peak_only = sh.engine && !corr_shifted && !unfused && fftconv_pcc_peak_only(*sh.cp);
     if (!peak_only) BH_TRY(get_scratch(ctx, "fft_real", Z * Y * X * sizeof(float), (void**)&corr));
-    if (engine) {
-        // power-of-two (z, y also 3 * 2^k) volume: six in-place passes each way on the fused engine instead of hipFFT's
-        // transposing pipeline; the normalised product treats every coefficient alike, so their order does not matter
-        const size_t NSf = fftconv_spectrum_elems(*cp);
-        BH_TRY(get_scratch(ctx, "fc_spec", NSf * sizeof(cf), (void**)&s1));
-        BH_TRY(get_scratch(ctx, "pcc_spec2", NSf * sizeof(cf), (void**)&s2));
-        if (getenv("BH_PCC_UNFUSED")) {  // A/B switch: the product as its own pass between whole transforms
-            BH_TRY(fftconv_forward(ctx, *cp, ref, s1));
-            BH_TRY(fftconv_forward(ctx, *cp, mov, s2));
-            const int64_t nprod = (int64_t)NSf - 64;  // Z * Y * XP stored coefficients (pad columns are zero), not the tail slack
-            hipLaunchKernelGGL(pcc_product_kernel, grid_for(ctx, nprod), dim3(256), 0, s, s1, s2, nprod, normalization,
-                               (float)(2.0 / (double)V));
-            BH_TRY(fftconv_inverse(ctx, *cp, s1, corr));
-        } else {
-            BH_TRY(fftconv_pcc(ctx, *cp, ref, mov, s1, s2, normalization, (float)(2.0 / (double)V), corr, partial, &npartial));
-            BH_REQUIRE(npartial <= nblk, "internal: %d argmax candidates for %d slots", npartial, nblk);
-        }
+    BH_TRY(get_scratch(ctx, "pcc_spec2", sh.spec_elems * sizeof(cf), (void**)&s2));
+    const cf* first = fixed_is_second ? s2 : fixed;
+    const cf* second = fixed_is_second ? fixed : s2;
+    if (sh.engine && !unfused) {
+        BH_TRY(fftconv_pcc_apply(ctx, *sh.cp, img, fixed, fixed_is_second, roll, s2, normalization, (float)(2.0 / (double)V), corr,
+                                 partial, &npartial));
+        BH_REQUIRE(npartial <= nblk, "internal: %d argmax candidates for %d slots", npartial, nblk);
     } else {
-        FftPlans *pl, *plc;
-        BH_TRY(get_plans(ctx, Z, Y, X, &pl));
-        BH_TRY(get_plans(ctx, Z, Y, Xc, &plc));
-        const int64_t Xh = X / 2 + 1, NS = Z * Y * Xh;
-        BH_TRY(get_scratch(ctx, "fft_spec", NS * sizeof(cf), (void**)&s1));
-        BH_TRY(get_scratch(ctx, "pcc_spec2", NS * sizeof(cf), (void**)&s2));
-        BH_TRY(fft_forward(pl, ref, s1));
-        BH_TRY(fft_forward(pl, mov, s2));
-        hipLaunchKernelGGL(pcc_product_kernel, grid_for(ctx, NS), dim3(256), 0, s, s1, s2, NS, normalization,
-                           (float)(1.0 / (double)V));
-        BH_TRY(fft_inverse(plc, s1, corr));
+        // library path (and the engine's A/B switch BH_PCC_UNFUSED): whole transforms, the product as a pass of its own.  It
+        // is written over the stored spectrum when that one is being replaced anyway (roll), over the new one otherwise.
+        FftPlans *pl = nullptr, *plc = nullptr;
+        if (sh.engine) {
+            BH_TRY(fftconv_forward(ctx, *sh.cp, img, s2));
+        } else {
+            BH_TRY(get_plans(ctx, Z, Y, X, &pl));
+            BH_TRY(get_plans(ctx, Z, Y, Xc, &plc));
+            BH_TRY(fft_forward(pl, img, s2));
+        }
+        // engine: Z * Y * XP stored coefficients (pad columns are zero), not the tail slack
+        const int64_t nprod = sh.engine ? (int64_t)sh.spec_elems - 64 : (int64_t)sh.spec_elems;
+        cf* prod = roll ? fixed : s2;
+        cf* keep = nullptr;
+        if (roll) {  // the new image's spectrum survives the inverse transform in a buffer of its own
+            BH_TRY(get_scratch(ctx, "pcc_spec3", sh.spec_elems * sizeof(cf), (void**)&keep));
+            BH_CHECK_HIP(hipMemcpyAsync(keep, s2, sh.spec_elems * sizeof(cf), hipMemcpyDeviceToDevice, s));
+        }
+        hipLaunchKernelGGL(pcc_product_kernel, grid_for(ctx, nprod), dim3(256), 0, s, first, second, prod, nprod, normalization,
+                           (float)((sh.engine ? 2.0 : 1.0) / (double)V));
+        if (sh.engine) BH_TRY(fftconv_inverse(ctx, *sh.cp, prod, corr));
+        else BH_TRY(fft_inverse(plc, prod, corr));
+        if (roll) BH_CHECK_HIP(hipMemcpyAsync(fixed, keep, sh.spec_elems * sizeof(cf), hipMemcpyDeviceToDevice, s));
     }
     if (!peak_only) hipLaunchKernelGGL(pcc_argmax_kernel, dim3(nblk), dim3(256), 0, s, corr, corr_shifted, Z, Y, Xc, partial);
     hipLaunchKernelGGL(pcc_argmax_final_kernel, dim3(1), dim3(256), 0, s, partial, peak_only ? npartial : nblk, result);
@@ -924,6 +953,76 @@ int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t
         if (sft > (float)(dims[a] / 2)) sft -= (float)dims[a];
         shift[a] = sft;
     }
+    return BH_OK;
+}
+
+int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t Z, int64_t Y, int64_t X,
+                        int normalization, float shift[3], float* corr_shifted) {
+    BH_REQUIRE(ctx && ref && mov && shift, "NULL argument");
+    BH_REQUIRE(normalization >= BH_PCC_NORM_NONE && normalization <= BH_PCC_NORM_CLASSIC, "unknown normalization %d",
+               normalization);
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    PccShape sh;
+    BH_TRY(pcc_shape(ctx, Z, Y, X, &sh));
+    cf* s1;
+    BH_TRY(get_scratch(ctx, sh.engine ? "fc_spec" : "fft_spec", sh.spec_elems * sizeof(cf), (void**)&s1));
+    BH_TRY(pcc_prepare(ctx, sh, ref, s1));
+    return pcc_run(ctx, sh, s1, false, false, mov, normalization, shift, corr_shifted);
+}
+
+// Prepared form: the stabilisation estimate correlates every timepoint with ONE image (t_reference "first") or with its
+// predecessor ("previous") — estimate_stabilization.py:505-520 — so that image's three forward passes are done once (or, with
+// `roll`, fall out of the previous call's Z pass) and a call costs the other image's transform only.
+struct bh_pcc {
+    int device = 0;
+    PccShape sh;
+    bool fixed_is_second = false;
+    cf* spec = nullptr;
+    size_t bytes = 0;
+};
+
+int bh_phase_cross_corr_create(bh_ctx* ctx, const float* fixed, int64_t Z, int64_t Y, int64_t X, int fixed_is_second,
+                               bh_pcc** out) {
+    BH_REQUIRE(ctx && fixed && out, "NULL argument");
+    *out = nullptr;
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    PccShape sh;
+    BH_TRY(pcc_shape(ctx, Z, Y, X, &sh));
+    bh_pcc* h = new bh_pcc();
+    h->device = ctx->device;
+    h->sh = sh;
+    h->fixed_is_second = fixed_is_second != 0;
+    h->bytes = sh.spec_elems * sizeof(cf);
+    h->spec = static_cast<cf*>(filter_pool_take(ctx->device, h->bytes));
+    if (!h->spec && hipMalloc((void**)&h->spec, h->bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("out of device memory (%zu bytes for the stored spectrum)", h->bytes);
+        delete h;
+        return BH_ERR_HIP;
+    }
+    const int rc = pcc_prepare(ctx, sh, fixed, h->spec);
+    if (rc != BH_OK) {
+        (void)bh_phase_cross_corr_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return BH_OK;
+}
+
+int bh_phase_cross_corr_apply(bh_ctx* ctx, bh_pcc* h, const float* img, int normalization, int roll, float shift[3],
+                              float* corr_shifted) {
+    BH_REQUIRE(ctx && h && img && shift, "NULL argument");
+    BH_REQUIRE(ctx->device == h->device, "handle was created on device %d, context is on device %d", h->device, ctx->device);
+    BH_REQUIRE(normalization >= BH_PCC_NORM_NONE && normalization <= BH_PCC_NORM_CLASSIC, "unknown normalization %d",
+               normalization);
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    return pcc_run(ctx, h->sh, h->spec, h->fixed_is_second, roll != 0, img, normalization, shift, corr_shifted);
+}
+
+int bh_phase_cross_corr_destroy(bh_pcc* h) {
+    if (!h) return BH_OK;
+    if (h->spec) filter_pool_give(h->device, h->bytes, h->spec);
+    delete h;
     return BH_OK;
 }
 

@@ -552,6 +552,9 @@ struct ColParams {
     float scale;
     int midfuse;        // fuse the unit-twiddle steps around the spectral product (BH_FC_NOZMID=1 turns it off)
     int pcc_norm;       // COL_PCC: BH_PCC_NORM_* of the product (`scale` multiplies it)
+    int pcc_swap;       // COL_PCC: 0 = otf * conj(column) (otf holds the FIRST image's spectrum), 1 = column * conj(otf)
+    cf* otf_out;        // COL_PCC, may be null: the column's forward spectrum replaces the multiplier rows it has just read
+                        // (the image becomes the stored one for the next call: bh_phase_cross_corr_apply's `roll`)
 };
 
 // The prefetch registers are sixteen named float4, of which ROUNDS are used (not an array: hipcc keeps a loop-carried
@@ -601,7 +604,8 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
     cf* const S = p.S;
     const cf* const otf = p.otf;
     const float scale = p.scale;
-    const int pcc_norm = p.pcc_norm;
+    const int pcc_norm = p.pcc_norm, pcc_swap = p.pcc_swap;
+    cf* const otf_out = p.otf_out;
     auto tile_base = [=](long tt) -> long {
         const long ou = tt / ncoltiles;
         const int ct = (int)(tt - ou * ncoltiles);
@@ -656,10 +660,13 @@ __global__ __launch_bounds__(FC_NT) void col_pass_kernel(ColParams p) {
             c.y = a.y * b.y;                                                                    \
             c.z = a.z * b.z;                                                                    \
             c.w = a.w * b.w;                                                                    \
-        } else if (MODE == COL_PCC) { /* b (reference) * conj(a) / norm * scale, as pcc_product_kernel */ \
-            const float2 p0 = pcc_bin(make_float2(b.x, b.y), make_float2(a.x, a.y), pcc_norm, scale);  \
-            const float2 p1 = pcc_bin(make_float2(b.z, b.w), make_float2(a.z, a.w), pcc_norm, scale);  \
+        } else if (MODE == COL_PCC) { /* first * conj(second) / norm * scale, as pcc_product_kernel; b = the stored spectrum */ \
+            const float2 f0 = make_float2(pcc_swap ? a.x : b.x, pcc_swap ? a.y : b.y), s0 = make_float2(pcc_swap ? b.x : a.x, pcc_swap ? b.y : a.y); \
+            const float2 f1 = make_float2(pcc_swap ? a.z : b.z, pcc_swap ? a.w : b.w), s1 = make_float2(pcc_swap ? b.z : a.z, pcc_swap ? b.w : a.w); \
+            const float2 p0 = pcc_bin(f0, s0, pcc_norm, scale);                                 \
+            const float2 p1 = pcc_bin(f1, s1, pcc_norm, scale);                                 \
             c = make_float4(p0.x, p0.y, p1.x, p1.y);                                            \
+            if (otf_out && col_ok) *reinterpret_cast<float4*>(otf_out + base + (long)(r0 + u * RPR) * row_stride) = a; \
         } else if (MODE == COL_CONV || MODE == COL_CONV16) {                                    \
             c.x = a.x * b.x - a.y * b.y;                                                        \
             c.y = a.x * b.y + a.y * b.x;                                                        \
@@ -1050,9 +1057,12 @@ static int launch_colw(bh_ctx* ctx, ColParams p, int mode) {
     }
 }
 
-static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf* S, const cf* otf, float scale, int pcc_norm = 0) {
+static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf* S, const cf* otf, float scale, int pcc_norm = 0,
+                      int pcc_swap = 0, cf* otf_out = nullptr) {
     ColParams p;
     p.pcc_norm = pcc_norm;
+    p.pcc_swap = pcc_swap;
+    p.otf_out = otf_out;
     p.S = S;
     p.otf = otf;
     p.XP = pl.d.XP;
@@ -1708,23 +1718,32 @@ int fftconv_inverse(bh_ctx* ctx, const ConvPlan& pl, cf* spec, float* out) {
     return BH_OK;
 }
 
-// corr = irfft( rfft(ref) * conj(rfft(mov)) / norm ) with the product inside the Z pass of `mov`'s transform: 7 passes for the two
-// forward transforms, the product and the inverse transform instead of 10 (spectrum layout and scaling as fftconv_forward /
-// fftconv_inverse: scale = 2 / V).  corr == nullptr (rows the wave-private xw kernels take: fftconv_pcc_peak_only): the
-// correlation volume is not stored — the last pass leaves *npartial argmax candidates of |corr| in `partial` (at most
-// 8 per compute unit) for the caller's final reduction.
+// corr = irfft( rfft(ref) * conj(rfft(mov)) / norm ) with the product inside the Z pass of ONE image's transform, the other
+// image's finished spectrum (fftconv_forward) being the multiplier: 5 passes per call once that spectrum is in hand, 8 with
+// it (instead of 10 for two forward transforms, a product pass and an inverse transform).  Spectrum layout and scaling as
+// fftconv_forward / fftconv_inverse: scale = 2 / V.
+// fixed: the finished spectrum of the stored image; fixed_is_mov says whether that image is the product's second (conjugated)
+// factor.  roll: the Z pass also writes img's forward spectrum over `fixed` (each thread replaces the rows it has just read), so
+// that img is the stored image of the next call — the "previous timepoint" reference of the stabilisation estimate for one
+// extra store stream.  corr == nullptr (rows the wave-private xw kernels take: fftconv_pcc_peak_only): the correlation volume
+// is not stored — the last pass leaves *npartial argmax candidates of |corr| in `partial` (at most 8 per compute unit) for the
+// caller's final reduction.
 bool fftconv_pcc_peak_only(const ConvPlan& pl) { return pl.xw && !pl.x3 && getenv("BH_PCC_NO_FUSED_PEAK") == nullptr; }
-int fftconv_pcc(bh_ctx* ctx, const ConvPlan& pl, const float* ref, const float* mov, cf* s1, cf* s2, int norm, float scale, float* corr,
-                ArgMax* partial, int* npartial) {
+int fftconv_pcc_apply(bh_ctx* ctx, const ConvPlan& pl, const float* img, cf* fixed, bool fixed_is_mov, bool roll, cf* s2, int norm,
+                      float scale, float* corr, ArgMax* partial, int* npartial) {
     BH_REQUIRE(corr || (partial && npartial && fftconv_pcc_peak_only(pl)), "internal: correlation volume or peak buffer required");
-    BH_TRY(fftconv_forward(ctx, pl, ref, s1));
-    BH_TRY(launch_x(ctx, pl, false, 0, mov, s2, nullptr, nullptr, 0.f));
+    BH_TRY(launch_x(ctx, pl, false, 0, img, s2, nullptr, nullptr, 0.f));
     BH_TRY(launch_col(ctx, pl, COL_FWD, false, s2, nullptr, 1.f));
-    BH_TRY(launch_col(ctx, pl, COL_PCC, true, s2, s1, scale, norm));
+    BH_TRY(launch_col(ctx, pl, COL_PCC, true, s2, fixed, scale, norm, fixed_is_mov ? 1 : 0, roll ? fixed : nullptr));
     BH_TRY(launch_col(ctx, pl, COL_INV, false, s2, nullptr, 1.f));
     if (!corr) return launch_xw_argmax(ctx, pl, s2, partial, npartial);
     BH_TRY(launch_x(ctx, pl, true, XE_STORE, nullptr, s2, corr, nullptr, 0.f));
     return BH_OK;
+}
+int fftconv_pcc(bh_ctx* ctx, const ConvPlan& pl, const float* ref, const float* mov, cf* s1, cf* s2, int norm, float scale, float* corr,
+                ArgMax* partial, int* npartial) {
+    BH_TRY(fftconv_forward(ctx, pl, ref, s1));
+    return fftconv_pcc_apply(ctx, pl, mov, s1, false, false, s2, norm, scale, corr, partial, npartial);
 }
 
 // out = irfft( rfft(in) * H/(H^2+reg) ), H = tf_full (natural order, real, even)

@@ -41,6 +41,64 @@ def phase_cross_corr_device(ref_img, mov_img, normalization=None, device="cuda",
     return np.array(list(shift), dtype=np.float32), corr
 
 
+class PreparedPhaseCrossCorr:
+    """``phase_cross_corr`` with ONE of the two images fixed (``bh_phase_cross_corr_create``): its spectrum is computed once, a
+    call transforms the other image only.  The stabilisation estimate correlates every timepoint with the first one — or, with
+    ``roll=True``, with its predecessor: the image of a call then becomes the stored one, its spectrum a by-product of the
+    call's own Z pass (estimate_stabilization.py:505-520).  ``fixed_is_second``: the stored image is ``phase_cross_corr``'s
+    second argument (``mov_img``), as in ``get_tform_from_pcc``, which passes the varying timepoint first."""
+
+    def __init__(self, fixed_img, fixed_is_second: bool = False, device="cuda"):
+        self.device = resolve_device(device if not isinstance(fixed_img, torch.Tensor) else fixed_img.device)
+        a, _, _ = as_device_volume(fixed_img, self.device)
+        a = a.to(torch.float32)
+        if a.ndim != 3:
+            raise ValueError(f"expected a 3-D image, got shape {tuple(a.shape)}")
+        self.shape = tuple(int(n) for n in a.shape)
+        self.fixed_is_second = bool(fixed_is_second)
+        self._ctx = get_context(self.device)
+        self._handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._ctx.lib.bh_phase_cross_corr_create(self._ctx.handle, ptr(a), *self.shape, int(self.fixed_is_second),
+                                                                C.byref(self._handle)))
+            torch.cuda.current_stream(self.device).synchronize()  # the image may be dropped by the caller from here on
+
+    def __call__(self, img, normalization=None, want_corr: bool = False, roll: bool = False):
+        """``(shift float32[3], fftshift(|corr|) tensor or None)`` of ``phase_cross_corr(fixed, img)`` — of
+        ``phase_cross_corr(img, fixed)`` when ``fixed_is_second``."""
+        if normalization not in _lib.PCC_NORM:
+            raise ValueError(f"unknown normalization {normalization!r}")
+        b, _, _ = as_device_volume(img, self.device)
+        b = b.to(torch.float32)
+        if tuple(b.shape) != self.shape:
+            raise ValueError(f"image shape {tuple(b.shape)} != the shape this handle was prepared for {self.shape}")
+        Z, Y, X = self.shape
+        shift = (C.c_float * 3)()
+        with torch.cuda.device(self.device):
+            corr = torch.empty((Z, Y, X - (X & 1)), dtype=torch.float32, device=self.device) if want_corr else None
+            _lib.check(self._ctx.lib.bh_phase_cross_corr_apply(self._ctx.handle, self._handle, ptr(b), _lib.PCC_NORM[normalization],
+                                                               int(bool(roll)), shift, ptr(corr) if want_corr else None))
+        return np.array(list(shift), dtype=np.float32), corr
+
+    def close(self) -> None:
+        if self._handle:
+            torch.cuda.synchronize(self.device)
+            _lib.check(self._ctx.lib.bh_phase_cross_corr_destroy(self._handle))
+            self._handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 def phase_cross_corr(ref_img, mov_img, normalization=None, output_path=None, verbose: bool = False, device="cuda"):
     """Translation between two equally shaped 3-D images: ``(shift, corr_shifted)`` like the reference.
 
@@ -158,16 +216,31 @@ def estimate_xyz_stabilization_pcc_per_position(input_position_dirpath, output_f
     target = [vols[0]] * T if s.t_reference == "first" else [vols[0]] + vols[:-1]
     name = "_".join(input_position_dirpath.parts[-3:])
     transforms, shifts = [], []
+    # function_type "custom": get_tform_from_pcc calls phase_cross_corr(source[t], target[t]) — the varying timepoint first, the
+    # reference timepoint as the conjugated factor.  The reference image's spectrum is computed once ("first") or falls out of
+    # the previous call ("previous": roll) instead of being rebuilt for every timepoint; same shifts (tests/test_io_cli.py).
+    prepared = None
+    if s.function_type == "custom" and T > 1:
+        prepared = PreparedPhaseCrossCorr(vols[0].astype(np.float32), fixed_is_second=True, device=device)
     for t in range(T):
         if t == 0:
             transforms.append(np.eye(4).tolist())
             shifts.append((t, 0, 0, 0))
             continue
-        transform, shift, _corr = get_tform_from_pcc(t, source, target, function_type=s.function_type,
-                                                     normalization=s.normalization, verbose=verbose, device=device,
-                                                     want_corr=False)
+        if prepared is not None:
+            shift, _ = prepared(vols[t].astype(np.float32), s.normalization, want_corr=False, roll=s.t_reference == "previous")
+            if verbose:
+                print(f"Time {t}: shift (dz,dy,dx) = {shift[0]}, {shift[1]}, {shift[2]}")
+            transform = np.eye(4)
+            transform[0, 3], transform[1, 3], transform[2, 3] = shift[2], shift[1], shift[0]
+        else:
+            transform, shift, _corr = get_tform_from_pcc(t, source, target, function_type=s.function_type,
+                                                         normalization=s.normalization, verbose=verbose, device=device,
+                                                         want_corr=False)
         transforms.append(transform)
         shifts.append((t, *[float(v) for v in shift]))
+    if prepared is not None:
+        prepared.close()
     output_folder_path = Path(output_folder_path)
     output_folder_path.mkdir(parents=True, exist_ok=True)
     np.save(output_folder_path / f"{name}.npy", np.array(transforms, dtype=np.float32))

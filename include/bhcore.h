@@ -294,6 +294,20 @@ int bh_richardson_lucy_info(const bh_rl* handle, int64_t box[3], int* backend, i
 int bh_phase_cross_corr(bh_ctx* ctx, const float* ref, const float* mov, int64_t Z, int64_t Y, int64_t X,
                         int normalization, float shift[3], float* corr_shifted);
 
+/* Prepared form for the stabilisation estimate's loop (biahub/estimate_stabilization.py:505-520: every timepoint against the
+ * first one, or against its predecessor): `fixed`'s spectrum is computed once and kept in the handle; a call transforms the
+ * other image only (5 passes over the volume instead of 8).  fixed_is_second: the stored image is phase_cross_corr's second
+ * argument (the conjugated factor) rather than its first.  roll != 0: after the call `img` is the stored image (its spectrum
+ * falls out of the call's own Z pass) — the "previous" reference.  Results equal bh_phase_cross_corr's on the same pair.
+ * apply synchronises (the shift is returned to the host); corr_shifted may be NULL, and then no correlation volume is written
+ * at all when the rows are ones the wave-private X passes take (X = 512, 1024, 2048). */
+typedef struct bh_pcc bh_pcc;
+int bh_phase_cross_corr_create(bh_ctx* ctx, const float* fixed, int64_t Z, int64_t Y, int64_t X, int fixed_is_second,
+                               bh_pcc** handle);
+int bh_phase_cross_corr_apply(bh_ctx* ctx, bh_pcc* handle, const float* img, int normalization, int roll, float shift[3],
+                              float* corr_shifted);
+int bh_phase_cross_corr_destroy(bh_pcc* handle);
+
 /* ---- intensity-registration building blocks (biahub/registration/ants.py:55-122 estimate) ---------- */
 /* The reference delegates to ants.registration(type_of_transform="Similarity", aff_shrink_factors (6,3,1),
  * aff_smoothing_sigmas (2,1,0), aff_iterations (2100,1200,50)) (:93-98,104-109): ITK's multi-resolution gradient descent

@@ -888,6 +888,46 @@ def test_phase_cross_corr_peak_only(gpu):
         assert np.array_equal(peak, stored), (norm, peak, stored)
 
 
+@pytest.mark.gpu
+def test_prepared_phase_cross_corr(gpu):
+    """``PreparedPhaseCrossCorr`` (bh_phase_cross_corr_create / _apply): one image's spectrum kept, either as the product's first
+    or as its second (conjugated) factor; ``roll`` makes the image of a call the stored one of the next.  Same shifts and the
+    same correlation volumes as the one-shot call on every pair, on the fused engine (wave-private and tile X passes, register
+    and LDS-stepped Z passes, a 3 * 2^k axis) and on the library path (odd X included)."""
+    from biahub_amd.estimate_stabilization import PreparedPhaseCrossCorr, phase_cross_corr_device
+
+    rng = np.random.default_rng(33)
+    for shape in ((16, 32, 512), (32, 64, 128), (512, 16, 64), (48, 32, 64), (20, 30, 50), (9, 14, 31)):
+        vols = [rng.random(shape, dtype=np.float32) for _ in range(2)]
+        vols.append(np.roll(vols[0], (3, -5, 7), axis=(0, 1, 2)) + 0.05 * rng.random(shape, dtype=np.float32))
+        vols.append(np.roll(vols[2], (-2, 4, 9), axis=(0, 1, 2)))
+        for norm in (None, "magnitude", "classic"):
+            for second in (False, True):
+                with PreparedPhaseCrossCorr(vols[0], fixed_is_second=second, device=gpu) as h:
+                    for v in vols[1:]:
+                        pair = (v, vols[0]) if second else (vols[0], v)
+                        want_s, want_c = phase_cross_corr_device(*pair, norm, gpu, want_corr=True)
+                        for want_corr in (True, False):
+                            got_s, got_c = h(v, norm, want_corr=want_corr)
+                            assert np.array_equal(got_s, want_s), (shape, norm, second, want_corr, got_s, want_s)
+                            if want_corr:
+                                assert rel_err(got_c.cpu().numpy(), want_c.cpu().numpy()) <= 1e-6, (shape, norm, second)
+                # the "previous timepoint" chain: each image against the one before it
+                with PreparedPhaseCrossCorr(vols[0], fixed_is_second=second, device=gpu) as h:
+                    for k in range(1, len(vols)):
+                        pair = (vols[k], vols[k - 1]) if second else (vols[k - 1], vols[k])
+                        want_s, want_c = phase_cross_corr_device(*pair, norm, gpu, want_corr=True)
+                        got_s, got_c = h(vols[k], norm, want_corr=(k % 2 == 0), roll=True)
+                        assert np.array_equal(got_s, want_s), (shape, norm, second, k, got_s, want_s)
+                        if got_c is not None:
+                            assert rel_err(got_c.cpu().numpy(), want_c.cpu().numpy()) <= 1e-6, (shape, norm, second, k)
+    with PreparedPhaseCrossCorr(vols[0], device=gpu) as h:
+        with pytest.raises(ValueError):
+            h(vols[0][:-1])
+        with pytest.raises(ValueError):
+            h(vols[0], "l2")
+
+
 # ----------------------------------------------------------------------------- registration estimate (N1)
 def test_registration_kernels_vs_oracle(gpu):
     """bh_image_stats / bh_smooth_shrink / bh_sobel / bh_mattes_mi against their NumPy restatements."""

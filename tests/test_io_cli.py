@@ -470,6 +470,18 @@ def test_cli_estimate_stabilization_then_stabilize(gpu, tmp_path):
         assert np.array_equal(mats[t], want) and np.array_equal(mats[t][:3, 3], np.array(rolls[t], float)[::-1])
     assert (out / "shifts_per_position" / "A_1_0.csv").exists() and not (out / "transforms_per_position").exists()
     assert est["stabilization_method"] == "phase-cross-corr" and est["output_voxel_size"] == [1, 1, 0.2, 0.1, 0.1]
+    # t_reference "previous": every timepoint against its predecessor (the prepared handle rolls its stored spectrum forward)
+    cfg.write_text("stabilization_estimation_channel: ch0\nstabilization_channels: [ch0]\nstabilization_type: xyz\n"
+                   "stabilization_method: phase-cross-corr\nphase_cross_corr_settings:\n  t_reference: previous\n")
+    out_prev = tmp_path / "stab_prev"
+    res = r.invoke(cli, ["estimate-stabilization", "-i", str(src / "A/1/0"), "-o", str(out_prev), "-c", str(cfg), "--local"])
+    assert res.exit_code == 0, res.output
+    prev = np.array(yaml.safe_load((out_prev / "xyz_stabilization_settings" / "A_1_0.yml").read_text())["affine_transform_zyx_list"])
+    before = np.stack([stack[0], stack[0], stack[1]])
+    for t in (1, 2):
+        want, _, _ = O.get_tform_from_pcc(t, stack, before, "custom", None)
+        assert np.array_equal(prev[t], want), (t, prev[t], want)
+    assert np.array_equal(prev[2][:3, 3], (np.array(rolls[2], float) - np.array(rolls[1], float))[::-1])
     res = r.invoke(cli, ["stabilize", "-i", str(src / "A/1/0"), "-c", str(yml), "-o", str(tmp_path / "stab.zarr"), "--local"])
     assert res.exit_code == 0, res.output
     cfg.write_text("stabilization_estimation_channel: ch0\nstabilization_channels: [ch0]\nstabilization_type: z\n")

@@ -22,3 +22,15 @@ for norm in ("magnitude", None, "classic"):
             del c
         torch.cuda.synchronize()
         print(f"norm={norm} want_corr={want}: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms  shift {sh}", flush=True)
+
+from biahub_amd.estimate_stabilization import PreparedPhaseCrossCorr  # noqa: E402
+
+for roll in (False, True):
+    with PreparedPhaseCrossCorr(mov, fixed_is_second=True, device=dev) as h:
+        sh, _ = h(vol, "magnitude", roll=roll)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            sh, _ = h(vol, "magnitude", roll=roll)
+        torch.cuda.synchronize()
+        print(f"prepared (stored image = second factor) roll={roll}: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms  shift {sh}", flush=True)
