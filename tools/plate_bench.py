@@ -16,7 +16,7 @@ import numpy as np, torch
 from biahub_amd import parallel
 from biahub_amd.deconvolve import PreparedRichardsonLucy, tikhonov_zyx, transfer_function_device
 from biahub_amd.deskew import fast_deskew_zyx, _fast_deskew_czyx
-from biahub_amd.estimate_stabilization import phase_cross_corr_device
+from biahub_amd.estimate_stabilization import PreparedPhaseCrossCorr
 from biahub_amd.flat_field import flat_field_device
 from biahub_amd.register import affine_device
 
@@ -88,17 +88,19 @@ def one_position(pos):
             else:
                 dec = timed("deskew", lambda: fast_deskew_zyx(flat, **DK))
                 dsk = timed("deconvolve", lambda: richardson_lucy(dec, psf, 10, 1e-6))
-            if t == 0:
-                ref[c] = flat
+            if t == 0:  # the reference timepoint's spectrum is kept for the position's other timepoints
+                ref[c] = timed("estimate_shift", lambda: PreparedPhaseCrossCorr(flat, device=dev))
                 m = np.eye(4)
             else:  # drift of the raw volume against t = 0 (estimate_stabilization.py:259-310), applied in deskewed space
-                sh, _ = timed("estimate_shift", lambda: phase_cross_corr_device(ref[c], flat, "magnitude", want_corr=False))
+                sh, _ = timed("estimate_shift", lambda: ref[c](flat, "magnitude"))
                 m = shifts[t]
                 assert tuple(sh) == (0.0, 2.0 * t, -3.0 * t), sh
             stab = timed("stabilize", lambda: affine_device(dsk, m, tuple(dsk.shape), "linear"))
             n += V
             del raw, dec, dsk, stab
     torch.cuda.synchronize(dev)
+    for h in ref.values():
+        h.close()
     return n
 
 one_position(10_000 + rank)  # warm-up: plans, OTF, allocator
