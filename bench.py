@@ -46,6 +46,19 @@ def gaussian_psf(shape, sigma, device):
     return (psf / psf.sum()).to(torch.float32)
 
 
+def _pooled(fn):
+    """Run an allocating function inside biahub_amd.device.volume_pool (the library's page layout for volumes in HBM)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        from biahub_amd.device import volume_pool
+        with volume_pool():
+            return fn(*a, **k)
+    return wrapper
+
+
+@_pooled
 def synthetic_position(shape, seed, device):
     """Camera-count-like volume generated on device: offset 110 + Gaussian noise + sparse bright blobs."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -248,7 +261,9 @@ def overlapped_units(vol_host_u16, rl, iterations, dev, ctx, n_units=8):
     into one of two pinned landing blocks) on three streams.  Returns ms per unit and the per-leg timeline of the measured run."""
     from biahub_amd.pipeline import run_overlapped, timeline_ms
 
-    probe = fast_deskew_zyx(rl(vol_host_u16.to(dev), 0, 1e-6), **DESKEW)
+    from biahub_amd.device import volume_pool
+    with volume_pool(dev):
+        probe = fast_deskew_zyx(rl(vol_host_u16.to(dev), 0, 1e-6), **DESKEW)
     landing = [torch.empty(probe.shape, dtype=torch.float32, pin_memory=True) for _ in range(2)]
     del probe
     count = [0]
@@ -287,12 +302,13 @@ def end_to_end(vol_host_u16, psf, rl, iterations, dev, ctx):
     """What the reference's operator boundary costs beside the resident figure (biahub/deskew.py:578-579: the worker uploads
     the volume and takes the result back): uint16 camera stack in pinned host memory -> H2D -> R-L + deskew -> float32
     result D2H into a pinned block, through the adapters' own transfer helpers.  PCIe-bound, never `value`."""
-    from biahub_amd.device import to_host
+    from biahub_amd.device import to_host, volume_pool
 
     def once():
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        d = vol_host_u16.to(dev, non_blocking=False)           # 2 B/voxel across PCIe
+        with volume_pool(dev):
+            d = vol_host_u16.to(dev, non_blocking=False)       # 2 B/voxel across PCIe
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         out = fast_deskew_zyx(rl(d, iterations, 1e-6), **DESKEW)

@@ -18,6 +18,7 @@ import torch
 from . import _lib
 from .compute_transfer_function import _refuse_unsupported, pixel_sizes
 from .device import as_device_volume, get_context, ptr, resolve_device, to_host
+from .device import empty as device_empty, empty_like as device_empty_like
 from .settings import ReconstructionSettings
 from .utils.config import yaml_to_model
 
@@ -65,7 +66,7 @@ class PreparedInverseFilter:
             raise ValueError(f"volume shape {tuple(x.shape)} != the shape this filter was prepared for {self.shape}")
         ctx = get_context(self.device)
         with torch.cuda.device(self.device):
-            out = torch.empty_like(x)
+            out = device_empty_like(x)
             _lib.check(ctx.lib.bh_inverse_filter_apply(ctx.handle, self._handle, ptr(x), int(bool(normalize)), ptr(out)))
         return out
 
@@ -103,7 +104,7 @@ def apply_inverse_transfer_function_zyx(zyx, transfer_function, z_padding: int =
         raise ValueError(f"filter_storage {filter_storage!r}: 'f32' or 'bf16'")
     ctx = get_context(dev)
     with torch.cuda.device(dev):
-        out = torch.empty_like(x)
+        out = device_empty_like(x)
         _lib.check(ctx.lib.bh_inverse_filter(ctx.handle, ptr(x), ptr(H), int(H.is_complex()), Z, Y, X, int(z_padding),
                                              float(regularization_strength), int(bool(normalize)), _STORAGE[filter_storage],
                                              ptr(out)))

@@ -4,7 +4,11 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <atomic>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
 
 namespace bh {
 
@@ -17,16 +21,128 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// Device memory of the workspace.  Normally hipMalloc.  BH_ALLOC_VMM_MB=<chunk size in MiB> (an experiment on where the driver
+// puts gigabyte buffers): allocations of 256 MiB and more are assembled with the virtual-memory API instead —
+// one reserved address range, physical chunks of that size created one by one and mapped in order, or in a random order with
+// BH_ALLOC_VMM_SHUFFLE=1 — so that the largest physically contiguous piece (what a page-table entry's fragment field can
+// cover) is under the caller's control.
+struct VmmBlock {
+    size_t size = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+static std::mutex g_vmm_mu;
+static std::map<void*, VmmBlock> g_vmm;
+
+static hipError_t vmm_alloc(int device, size_t bytes, size_t chunk, bool shuffle, void** out) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0, gran_rec = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return e;
+    (void)hipMemGetAllocationGranularity(&gran_rec, &prop, hipMemAllocationGranularityRecommended);
+    static bool said = false;
+    if (!said && getenv("BH_DEBUG_SCRATCH")) {
+        said = true;
+        fprintf(stderr, "[bh vmm] allocation granularity: minimum %zu, recommended %zu bytes; chunk %zu\n", gran, gran_rec, chunk);
+    }
+    chunk = std::max(chunk, gran) / gran * gran;
+    const size_t n = (bytes + chunk - 1) / chunk, size = n * chunk;
+    void* va = nullptr;
+    if ((e = hipMemAddressReserve(&va, size, chunk, nullptr, 0)) != hipSuccess) return e;
+    VmmBlock blk;
+    blk.size = size;
+    std::vector<size_t> slot(n);
+    for (size_t i = 0; i < n; ++i) slot[i] = i;
+    if (shuffle) {
+        // a different permutation for every allocation: buffers of one size that are walked in lockstep (estimate, data,
+        // result) must not share their physical pattern either (BH_ALLOC_VMM_SEED=fixed: one permutation for all, the A/B)
+        static std::atomic<unsigned long long> counter{0};
+        static const char* seed_env = getenv("BH_ALLOC_VMM_SEED");  // an integer: that permutation for every allocation
+        unsigned long long st = 0x9E3779B97F4A7C15ull +
+                                0xD1B54A32D192ED03ull * (seed_env ? strtoull(seed_env, nullptr, 10) : counter.fetch_add(1) + 1);
+        for (size_t i = n - 1; i > 0; --i) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(slot[i], slot[(size_t)((st >> 33) % (i + 1))]);
+        }
+    }
+    for (size_t i = 0; i < n && e == hipSuccess; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        if ((e = hipMemCreate(&h, chunk, &prop, 0)) != hipSuccess) break;
+        blk.handles.push_back(h);
+        e = hipMemMap(static_cast<char*>(va) + slot[i] * chunk, chunk, 0, h, 0);
+    }
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, size, &acc, 1);
+    }
+    if (e != hipSuccess) {
+        (void)hipMemUnmap(va, size);
+        for (auto h : blk.handles) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(va, size);
+        return e;
+    }
+    std::lock_guard<std::mutex> lk(g_vmm_mu);
+    g_vmm[va] = std::move(blk);
+    *out = va;
+    return hipSuccess;
+}
+
+static long vmm_chunk_kb() {
+    // default: 2-MiB chunks (BH_ALLOC_VMM_MB=0: plain hipMalloc; BH_ALLOC_VMM_KB takes precedence: chunks below 1 MiB)
+    static const long kb = getenv("BH_ALLOC_VMM_KB") ? atol(getenv("BH_ALLOC_VMM_KB"))
+                           : (getenv("BH_ALLOC_VMM_MB") ? atol(getenv("BH_ALLOC_VMM_MB")) * 1024 : 2048);
+    return kb;
+}
+static bool vmm_shuffle() {
+    static const bool on = !(getenv("BH_ALLOC_VMM_SHUFFLE") && atoi(getenv("BH_ALLOC_VMM_SHUFFLE")) == 0);
+    return on;
+}
+static std::atomic<bool> g_vmm_failed{false};  // the driver refused the virtual-memory API once: hipMalloc from then on
+bool dev_alloc_is_shuffled() { return vmm_chunk_kb() > 0 && vmm_shuffle() && !g_vmm_failed.load(); }
+
+hipError_t dev_alloc(int device, size_t bytes, void** out) {
+    const long chunk_kb = g_vmm_failed.load() ? 0 : vmm_chunk_kb();
+    const bool shuffle = vmm_shuffle();
+    static const size_t min_bytes = (size_t)(getenv("BH_ALLOC_VMM_MIN_MB") ? atol(getenv("BH_ALLOC_VMM_MIN_MB")) : 64) << 20;
+    if (chunk_kb > 0 && bytes >= min_bytes) {
+        const hipError_t e = vmm_alloc(device, bytes, (size_t)chunk_kb << 10, shuffle, out);
+        if (e == hipSuccess || e == hipErrorOutOfMemory) return e;
+        (void)hipGetLastError();  // a driver without the virtual-memory API: hipMalloc from here on
+        g_vmm_failed.store(true);
+    }
+    return hipMalloc(out, bytes);
+}
+hipError_t dev_free(void* p) {
+    if (!p) return hipSuccess;
+    VmmBlock blk;
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        auto it = g_vmm.find(p);
+        if (it == g_vmm.end()) return hipFree(p);
+        blk = std::move(it->second);
+        g_vmm.erase(it);
+    }
+    (void)hipDeviceSynchronize();
+    hipError_t e = hipMemUnmap(p, blk.size);
+    for (auto h : blk.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(p, blk.size);
+    return e;
+}
+
 int get_scratch(bh_ctx* ctx, const char* name, size_t bytes, void** out) {
     Scratch& s = ctx->scratch[name];
     if (s.bytes < bytes) {
         if (s.ptr) {
             BH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-            BH_CHECK_HIP(hipFree(s.ptr));
+            BH_CHECK_HIP(dev_free(s.ptr));
             s.ptr = nullptr;
             s.bytes = 0;
         }
-        BH_CHECK_HIP(hipMalloc(&s.ptr, bytes));
+        BH_CHECK_HIP(dev_alloc(ctx->device, bytes, &s.ptr));
         s.bytes = bytes;
         if (std::strcmp(name, "fc_spec") == 0) ctx->spec_tuned = nullptr;  // new pages: fftconv_tune_spectrum auditions them
         if (getenv("BH_DEBUG_SCRATCH")) fprintf(stderr, "[bh scratch] %-14s %p  %zu bytes\n", name, s.ptr, bytes);
@@ -40,7 +156,7 @@ int free_scratch(bh_ctx* ctx, const char* name) {
     auto it = ctx->scratch.find(name);
     if (it == ctx->scratch.end() || !it->second.ptr) return BH_OK;
     BH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    BH_CHECK_HIP(hipFree(it->second.ptr));
+    BH_CHECK_HIP(dev_free(it->second.ptr));
     ctx->scratch.erase(it);
     return BH_OK;
 }
@@ -202,6 +318,29 @@ extern "C" {
 
 int bh_abi_version(void) { return BH_ABI_VERSION; }
 
+// torch.cuda.memory.CUDAPluggableAllocator entry points: the allocator of a torch MemPool whose large blocks are laid out like
+// the library's own workspace (biahub_amd/device.py: volume_pool)
+void* bh_torch_alloc(size_t size, int device, void* stream) {
+    (void)stream;
+    void* p = nullptr;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != device) (void)hipSetDevice(device);
+    const hipError_t e = bh::dev_alloc(device, size ? size : 1, &p);
+    if (cur != device) (void)hipSetDevice(cur);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void bh_torch_free(void* ptr, size_t size, int device, void* stream) {
+    (void)size;
+    (void)device;
+    (void)stream;
+    (void)bh::dev_free(ptr);
+}
+
 const char* bh_last_error(void) { return bh::g_err; }
 
 int bh_device_count(int* count) {
@@ -237,7 +376,7 @@ int bh_ctx_release_workspace(bh_ctx* ctx) {
     }
     ctx->plans.clear();
     for (auto& kv : ctx->scratch)
-        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+        if (kv.second.ptr) (void)bh::dev_free(kv.second.ptr);
     ctx->scratch.clear();
     ctx->otf_valid = false;
     ctx->spec_tuned = nullptr;

@@ -994,7 +994,7 @@ int bh_phase_cross_corr_create(bh_ctx* ctx, const float* fixed, int64_t Z, int64
     h->fixed_is_second = fixed_is_second != 0;
     h->bytes = sh.spec_elems * sizeof(cf);
     h->spec = static_cast<cf*>(filter_pool_take(ctx->device, h->bytes));
-    if (!h->spec && hipMalloc((void**)&h->spec, h->bytes) != hipSuccess) {
+    if (!h->spec && dev_alloc(ctx->device, h->bytes, (void**)&h->spec) != hipSuccess) {
         (void)hipGetLastError();
         set_error("out of device memory (%zu bytes for the stored spectrum)", h->bytes);
         delete h;
@@ -1192,7 +1192,7 @@ int bh_richardson_lucy_create(bh_ctx* ctx, const float* psf, int64_t pz, int64_t
     h->otf_real = (pz & 1) && (py & 1) && (px & 1) && hv[2] == 1ull && getenv("BH_RL_COMPLEX_OTF") == nullptr;
     h->otf_bytes = NS * (h->otf_real ? sizeof(float) : sizeof(cf));
     if ((h->otf = filter_pool_take(ctx->device, h->otf_bytes)) == nullptr &&
-        hipMalloc(&h->otf, h->otf_bytes) != hipSuccess) {
+        dev_alloc(ctx->device, h->otf_bytes, &h->otf) != hipSuccess) {
         h->otf = nullptr;
         (void)hipGetLastError();
         return (set_error("out of device memory (%zu bytes for the transfer function)", h->otf_bytes), fail(BH_ERR_HIP));

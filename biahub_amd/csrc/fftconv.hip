@@ -1564,7 +1564,11 @@ int fftconv_richardson_lucy(bh_ctx* ctx, const ConvPlan& pl, const float* d, con
 // `est` is any V-float buffer the caller is about to overwrite (the pass reads and writes it), `bytes` the allocation size.
 int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t bytes, cf** spec) {
     const double V = (double)pl.d.Z * pl.d.Y * pl.d.X;
-    if (!pl.xw || V < (double)(1u << 28) || (getenv("BH_FC_TUNE_ALLOC") && atoi(getenv("BH_FC_TUNE_ALLOC")) == 0)) return BH_OK;
+    // Round 3: with the workspace's default layout (2-MiB physical chunks in a shuffled order, context.hip dev_alloc) the pass
+    // reads 5.87-6.5 ms on every allocation tried and the audition is off; it stays for the hipMalloc layout
+    // (BH_ALLOC_VMM_MB=0), where the two states are 5.95 and 7.07 ms.  BH_FC_TUNE_ALLOC=0 / 1 forces it off / on.
+    const bool tune = getenv("BH_FC_TUNE_ALLOC") ? atoi(getenv("BH_FC_TUNE_ALLOC")) != 0 : !dev_alloc_is_shuffled();
+    if (!pl.xw || V < (double)(1u << 28) || !tune) return BH_OK;
     hipEvent_t e0, e1;
     BH_CHECK_HIP(hipEventCreate(&e0));
     BH_CHECK_HIP(hipEventCreate(&e1));
@@ -1585,7 +1589,7 @@ int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t by
     float slowest = ms[0];
     for (; rc == BH_OK && n < NC; ++n) {
         if (ms[best] < 0.93f * slowest) break;  // both levels seen: the fast one is in hand
-        if (hipMalloc((void**)&cand[n], bytes) != hipSuccess) {
+        if (dev_alloc(ctx->device, bytes, (void**)&cand[n]) != hipSuccess) {
             (void)hipGetLastError();
             cand[n] = nullptr;
             break;
@@ -1602,7 +1606,7 @@ int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t by
         fprintf(stderr, "[bh tune] fused update pass on %d spectrum allocation(s): %.3f %.3f %.3f %.3f %.3f ms -> #%d\n", n, ms[0], ms[1],
                 ms[2], ms[3], ms[4], best);
     for (int i = 0; i < n; ++i)
-        if (i != best && cand[i]) (void)hipFree(cand[i]);
+        if (i != best && cand[i]) (void)dev_free(cand[i]);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *spec = cand[best];

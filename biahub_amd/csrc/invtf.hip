@@ -192,7 +192,7 @@ static int inverse_filter_create_impl(bh_ctx* ctx, const void* tf, int tf_is_com
         f->filt_bytes = bytes;
         if (use_scratch) return get_scratch(ctx, "itf_filter", bytes, &f->filt);
         if ((f->filt = filter_pool_take(ctx->device, bytes)) != nullptr) return BH_OK;
-        if (hipMalloc(&f->filt, bytes) != hipSuccess) {
+        if (dev_alloc(ctx->device, bytes, &f->filt) != hipSuccess) {
             f->filt = nullptr;
             set_error("out of device memory for the staged inverse filter (%zu bytes)", bytes);
             return BH_ERR_NOMEM;
@@ -251,7 +251,7 @@ extern "C" int bh_inverse_filter_trim(void) {
     std::lock_guard<std::mutex> lock(g_filter_pool_mu);
     for (auto& kv : g_filter_pool) {
         (void)hipSetDevice(kv.first.first);
-        for (void* p : kv.second) (void)hipFree(p);
+        for (void* p : kv.second) (void)dev_free(p);
     }
     g_filter_pool.clear();
     return BH_OK;

@@ -13,6 +13,7 @@ import torch
 
 from . import _lib
 from .device import as_device_volume, get_context, ptr, resolve_device, to_host
+from .device import empty as device_empty, empty_like as device_empty_like
 
 
 def _f32_device(x, device=None):
@@ -34,7 +35,7 @@ def transfer_function_device(psf_zyx, output_zyx_shape, device="cuda") -> torch.
         raise ValueError("index can't contain negative values")
     ctx = get_context(dev)
     with torch.cuda.device(dev):
-        tf = torch.empty((Z, Y, X), dtype=torch.float32, device=dev)
+        tf = device_empty((Z, Y, X), torch.float32, dev)
         _lib.check(ctx.lib.bh_transfer_function(ctx.handle, ptr(psf), pz, py, px, Z, Y, X, ptr(tf)))
     return tf
 
@@ -58,7 +59,7 @@ def tikhonov_zyx(zyx, transfer_function, regularization_strength: float = 1e-3) 
     Z, Y, X = (int(s) for s in x.shape)
     ctx = get_context(dev)
     with torch.cuda.device(dev):
-        out = torch.empty_like(x)
+        out = device_empty_like(x)
         _lib.check(ctx.lib.bh_tikhonov(ctx.handle, ptr(x), ptr(H), Z, Y, X, float(regularization_strength),
                                        ptr(out)))
     return out
@@ -136,7 +137,7 @@ def richardson_lucy(zyx, psf_zyx, iterations: int = 10, eps: float = 1e-6) -> to
     pz, py, px = (int(s) for s in psf.shape)
     ctx = get_context(dev)
     with torch.cuda.device(dev):
-        out = torch.empty_like(d)
+        out = device_empty_like(d)
         _lib.check(ctx.lib.bh_richardson_lucy(ctx.handle, ptr(d), ptr(psf), pz, py, px, Z, Y, X, int(iterations),
                                               float(eps), ptr(out)))
     return out
@@ -180,7 +181,7 @@ class PreparedRichardsonLucy:
         ctx = get_context(self.device)
         with torch.cuda.device(self.device):
             if out is None:
-                out = torch.empty_like(d)
+                out = device_empty_like(d)
             _lib.check(ctx.lib.bh_richardson_lucy_apply(ctx.handle, self._handle, ptr(d), int(iterations), float(eps), ptr(out)))
         return out
 

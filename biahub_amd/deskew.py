@@ -15,6 +15,7 @@ import torch
 
 from . import _lib
 from .device import as_device_volume, get_context, ptr, resolve_device, to_host
+from .device import empty as device_empty, empty_like as device_empty_like
 
 
 def _get_averaged_shape(deskewed_data_shape: tuple, average_window_width: int) -> tuple:
@@ -102,7 +103,7 @@ def fast_deskew_zyx(
     mode, value = _fill_args(overhang_fill)
     ctx = get_context(dev)
     with torch.cuda.device(dev):
-        out = torch.empty(out_shape, dtype=torch.float32, device=dev)
+        out = device_empty(out_shape, torch.float32, dev)
         _lib.check(ctx.lib.bh_deskew(ctx.handle, ptr(t), code, Z, Y, X, float(ls_angle_deg),
                                      float(px_to_scan_ratio), int(bool(keep_overhang)), int(average_n_slices),
                                      mode, value, ptr(out), None))

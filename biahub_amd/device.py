@@ -6,7 +6,10 @@ the kernels order correctly with torch copies issued around them.
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import os
+import threading
 
 import numpy as np
 import torch
@@ -47,6 +50,64 @@ def resolve_device(device) -> torch.device:
     return dev
 
 
+# ---- volumes in HBM: where their pages go matters ------------------------------------------------------
+# hipMalloc hands out physically contiguous gigabytes, and the strided streams of the transform passes (rows 8 KiB apart,
+# planes 16 MiB apart, four of them per kernel) then collide in the HBM channel / bank hash: the same kernels run ~10 % faster on
+# buffers whose 2-MiB physical chunks are mapped in a shuffled order (library default for its own workspace: csrc/context.hip
+# dev_alloc).  ``volume_pool`` gives torch tensors the same layout: a torch MemPool whose blocks come from the library's
+# allocator; tensors allocated inside the context manager live in it (and return to it, cached, when they are dropped).
+_POOL = None
+_POOL_ALLOCATOR = None
+_POOL_TLS = threading.local()
+
+
+@contextlib.contextmanager
+def volume_pool(device=None):
+    """Context manager: torch allocations inside it come from the library's allocator (``bh_torch_alloc``).  Re-entrant (torch
+    refuses to nest ``use_mem_pool`` on one pool: the inner uses are no-ops); a no-op when ``BH_VOLUME_POOL=0`` or when this
+    torch build has no pluggable allocator."""
+    global _POOL, _POOL_ALLOCATOR
+    if os.environ.get("BH_VOLUME_POOL", "1") == "0" or getattr(_POOL_TLS, "depth", 0) > 0:
+        yield
+        return
+    if _POOL is None:
+        try:
+            _lib.load()
+            path = str(os.environ.get("BHCORE_LIB", _lib.LIB_PATH))
+            _POOL_ALLOCATOR = torch.cuda.memory.CUDAPluggableAllocator(path, "bh_torch_alloc", "bh_torch_free")
+            _POOL = torch.cuda.MemPool(_POOL_ALLOCATOR.allocator())
+        except (AttributeError, RuntimeError):  # torch without MemPool / pluggable allocators
+            _POOL = False
+    if _POOL is False:
+        yield
+        return
+    _POOL_TLS.depth = 1
+    try:
+        with torch.cuda.use_mem_pool(_POOL, device=device):
+            yield
+    finally:
+        _POOL_TLS.depth = 0
+
+
+def release_volume_pool() -> None:
+    """Give the pool's cached blocks back to the driver (blocks that live tensors still use go when those tensors do): the
+    pool object is dropped — torch releases a pool's blocks with its last reference — and a new one is made on the next use."""
+    global _POOL
+    if _POOL:
+        _POOL = None
+        torch.cuda.empty_cache()
+
+
+def empty(shape, dtype, device) -> torch.Tensor:
+    """``torch.empty`` on the GPU inside ``volume_pool``: where the operators allocate their results."""
+    with volume_pool(device):
+        return torch.empty(tuple(int(n) for n in shape), dtype=dtype, device=device)
+
+
+def empty_like(t: torch.Tensor) -> torch.Tensor:
+    return empty(t.shape, t.dtype, t.device)
+
+
 class Context:
     def __init__(self, index: int):
         self.index = index
@@ -85,6 +146,7 @@ class Context:
     def release_workspace(self):
         _lib.check(self.lib.bh_ctx_release_workspace(self.handle))
         _lib.check(self.lib.bh_inverse_filter_trim())  # the pool of released staged-filter blocks (gigabytes each) goes too
+        release_volume_pool()
 
     def fft_plans_replaced(self) -> int:
         """hipFFT 3-D plans that failed their creation-time round trip and were rebuilt decomposed."""
@@ -123,7 +185,8 @@ def upload(array: np.ndarray, device: torch.device) -> tuple[torch.Tensor, int]:
         a = a.astype(np.float32)
     a = np.ascontiguousarray(a)
     code = _NP_TO_DT[a.dtype]
-    return torch.from_numpy(a).to(device), code
+    with volume_pool(device):
+        return torch.from_numpy(a).to(device), code
 
 
 _PIN_MIN_BYTES = 8 << 20  # small results are not worth a pinned allocation
@@ -151,10 +214,12 @@ def as_device_volume(x, device=None) -> tuple[torch.Tensor, int, torch.device]:
     """Accept a numpy array or a torch tensor; return (contiguous device tensor, dtype code, device)."""
     if isinstance(x, torch.Tensor):
         dev = resolve_device(x.device if device is None else device)
-        t = x.to(dev)
-        if t.dtype not in _TORCH_TO_DT:
-            t = t.to(torch.float32)
-        return t.contiguous(), _TORCH_TO_DT[t.dtype], dev
+        with volume_pool(dev):
+            t = x.to(dev)
+            if t.dtype not in _TORCH_TO_DT:
+                t = t.to(torch.float32)
+            t = t.contiguous()
+        return t, _TORCH_TO_DT[t.dtype], dev
     dev = resolve_device("cuda" if device is None else device)
     t, code = upload(x, dev)
     return t, code, dev

@@ -14,6 +14,7 @@ import torch
 
 from . import _lib
 from .device import as_device_volume, get_context, ptr, to_host
+from .device import empty as device_empty, empty_like as device_empty_like
 
 
 def median_z_device(vol, device=None) -> torch.Tensor:
@@ -54,7 +55,7 @@ def flat_field_device(vol, device=None, return_pattern: bool = False):
     ctx = get_context(dev)
     Z, Y, X = (int(s) for s in t.shape)
     with torch.cuda.device(dev):
-        out = torch.empty((Z, Y, X), dtype=torch.float32, device=dev)
+        out = device_empty((Z, Y, X), torch.float32, dev)
         pattern = torch.empty((Y, X), dtype=torch.float64, device=dev) if return_pattern else None
     _lib.check(ctx.lib.bh_flat_field(ctx.handle, ptr(t), code, Z, Y, X, ptr(out),
                                      ptr(pattern) if return_pattern else None, None))

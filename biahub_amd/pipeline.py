@@ -14,7 +14,17 @@ from typing import Callable, Iterable, Iterator
 
 import torch
 
-from .device import resolve_device
+from .device import resolve_device, volume_pool
+
+
+_STREAMS: dict = {}
+
+
+def _streams(dev):
+    key = dev.index
+    if key not in _STREAMS:
+        _STREAMS[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=-1))
+    return _STREAMS[key]
 
 
 def run_overlapped(items: Iterable, upload: Callable, compute: Callable, download: Callable, device="cuda",
@@ -34,8 +44,10 @@ def run_overlapped(items: Iterable, upload: Callable, compute: Callable, downloa
     # (`__amd_rocclr_copyBuffer`, profiles/r03_d2h_probe.txt — HSA_ENABLE_SDMA / GPU_BLIT_ENGINE_TYPE do not change that), which
     # shares the CUs with the compute leg for as long as the copy takes.  The compute stream therefore gets the higher priority:
     # its workgroups are dispatched ahead of the copy kernel's.
-    s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    s_c = torch.cuda.Stream(dev, priority=-1)
+    # The three streams are made once per device: torch's caching allocator hands a freed block back only to the stream it
+    # was allocated on, so new streams per call would find none of the previous call's gigabyte buffers reusable (and the
+    # blocks of device.volume_pool cost ~30 ms per GB to build).
+    s_in, s_out, s_c = _streams(dev)
     staged: deque = deque()   # (uploaded, event): waiting for compute
     landing: deque = deque()  # (handed, event): waiting for the copy back to finish
 
@@ -85,7 +97,8 @@ def run_overlapped(items: Iterable, upload: Callable, compute: Callable, downloa
         for item in items:
             with torch.cuda.stream(s_in):
                 row = [_mark(s_in)] if timed else None
-                up = upload(item)
+                with volume_pool(dev):  # the uploaded volume gets the library's page layout (device.volume_pool)
+                    up = upload(item)
                 ev = _mark(s_in)
             if timed:
                 row.append(ev)

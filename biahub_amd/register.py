@@ -15,6 +15,7 @@ import torch
 
 from . import _lib
 from .device import as_device_volume, get_context, ptr, resolve_device, to_host
+from .device import empty as device_empty, empty_like as device_empty_like
 
 _INTERP = {"linear": _lib.INTERP_LINEAR, "nearestneighbor": _lib.INTERP_NEAREST}
 
@@ -85,7 +86,7 @@ def affine_device(vol, matrix, output_shape_zyx, interpolation="linear", boundar
     Zi, Yi, Xi = (int(s) for s in t.shape)
     ctx = get_context(dev)
     with torch.cuda.device(dev):
-        out = torch.empty(shape, dtype=torch.float32, device=dev)
+        out = device_empty(shape, torch.float32, dev)
         if out.numel():
             _lib.check(ctx.lib.bh_affine(ctx.handle, ptr(t), code, Zi, Yi, Xi, m12, _INTERP[interpolation],
                                          int(boundary), float(cval), ptr(out), shape[0], shape[1], shape[2], lo))

@@ -101,6 +101,12 @@ typedef struct bh_ctx bh_ctx;
 int bh_abi_version(void);
 const char* bh_last_error(void);
 int bh_device_count(int* count);
+/* Device memory laid out like the library's own workspace (blocks of 64 MiB and more: 2-MiB physical chunks mapped in a
+ * shuffled order through the HIP virtual-memory API; smaller ones: hipMalloc).  The signatures are the ones
+ * torch.cuda.memory.CUDAPluggableAllocator binds (biahub_amd/device.py: volume_pool); any host may call them directly. */
+void* bh_torch_alloc(size_t size, int device, void* hip_stream);
+void bh_torch_free(void* ptr, size_t size, int device, void* hip_stream);
+
 int bh_ctx_create(int device, void* hip_stream, bh_ctx** out);
 int bh_ctx_destroy(bh_ctx* ctx);
 int bh_ctx_set_stream(bh_ctx* ctx, void* hip_stream);

@@ -928,6 +928,41 @@ def test_prepared_phase_cross_corr(gpu):
             h(vols[0], "l2")
 
 
+@pytest.mark.gpu
+def test_volume_pool_layout(gpu, monkeypatch):
+    """``device.volume_pool``: torch tensors allocated inside it come from the library's allocator (``bh_torch_alloc``: 2-MiB
+    physical chunks mapped in a shuffled order for blocks of 64 MiB and more).  Re-entrant, tensors outlive the context, freed
+    blocks are reused, and the operators compute the same bits on pooled and on plain tensors."""
+    from biahub_amd.deconvolve import richardson_lucy
+    from biahub_amd.device import empty, get_context, volume_pool
+
+    ctx = get_context(gpu)
+    lib = ctx.lib
+    p = lib.bh_torch_alloc(96 << 20, gpu.index or 0, None)          # a shuffled block straight through the C entry points
+    assert p
+    lib.bh_torch_free(p, 96 << 20, gpu.index or 0, None)
+    with volume_pool(gpu):
+        a = empty((48, 1024, 1024), torch.float32, gpu)               # 192 MiB: virtual-memory path
+        with volume_pool(gpu):                                        # nested: a no-op, not an error
+            b = torch.full((16, 64, 64), 3.0, device=gpu)
+    a.copy_((torch.arange(a.numel(), device=gpu) % 1021).reshape(a.shape))
+    assert float(b.sum()) == 3.0 * b.numel()
+    idx = (47, 1023, 1023)
+    assert float(a[idx]) == float((a.numel() - 1) % 1021) and float(a[0, 0, 5]) == 5.0
+    ptr_a = a.data_ptr()
+    del a
+    with volume_pool(gpu):
+        c = empty((48, 1024, 1024), torch.float32, gpu)               # the cached block comes back
+    assert c.data_ptr() == ptr_a
+    del c
+    vol = O.synthetic_volume((32, 64, 128), seed=9, n_blobs=6)
+    psf = O.gaussian_psf((5, 5, 5), (1.0, 1.2, 1.2))
+    got = richardson_lucy(torch.from_numpy(vol).to(gpu), torch.from_numpy(psf).to(gpu), 3, 1e-6).cpu().numpy()
+    monkeypatch.setenv("BH_VOLUME_POOL", "0")
+    plain = richardson_lucy(torch.from_numpy(vol).to(gpu), torch.from_numpy(psf).to(gpu), 3, 1e-6).cpu().numpy()
+    assert np.array_equal(got, plain)
+
+
 # ----------------------------------------------------------------------------- registration estimate (N1)
 def test_registration_kernels_vs_oracle(gpu):
     """bh_image_stats / bh_smooth_shrink / bh_sobel / bh_mattes_mi against their NumPy restatements."""
