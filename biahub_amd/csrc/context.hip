@@ -192,7 +192,7 @@ static void destroy_handles(FftPlans& p) {
             hipfftDestroy(*h);
             *h = 0;
         }
-    if (p.work) (void)hipFree(p.work);
+    if (p.work) (void)dev_free(p.work);
     p.work = nullptr;
     p.work_bytes = 0;
 }
@@ -223,7 +223,7 @@ static int make_handles(bh_ctx* ctx, FftPlans& p, int64_t Z, int64_t Y, int64_t 
     for (int i = 0; i < nh; ++i)
         if (ws[i] > p.work_bytes) p.work_bytes = ws[i];
     // one work area shared by all plans of the shape (they never run concurrently on one stream)
-    if (p.work_bytes) BH_CHECK_HIP(hipMalloc(&p.work, p.work_bytes));
+    if (p.work_bytes) BH_CHECK_HIP(dev_alloc(ctx->device, p.work_bytes, &p.work));
     for (int i = 0; i < nh; ++i) {
         if (p.work_bytes) BH_CHECK_FFT(hipfftSetWorkArea(*hs[i], p.work));
         BH_CHECK_FFT(hipfftSetStream(*hs[i], ctx->stream));
@@ -372,7 +372,7 @@ int bh_ctx_release_workspace(bh_ctx* ctx) {
     for (auto& kv : ctx->plans) {
         for (hipfftHandle h : {kv.second.r2c, kv.second.c2r, kv.second.xr, kv.second.xi, kv.second.zy})
             if (h) hipfftDestroy(h);
-        if (kv.second.work) (void)hipFree(kv.second.work);
+        if (kv.second.work) (void)bh::dev_free(kv.second.work);
     }
     ctx->plans.clear();
     for (auto& kv : ctx->scratch)
@@ -444,12 +444,14 @@ int bh_last_elapsed_ms(bh_ctx* ctx, int what, float* ms) {
 
 int bh_malloc(void** dptr, uint64_t bytes) {
     BH_REQUIRE(dptr != nullptr, "dptr is NULL");
-    BH_CHECK_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    int device = 0;
+    BH_CHECK_HIP(hipGetDevice(&device));  // torch-less hosts: their volumes get the library's page layout too
+    BH_CHECK_HIP(bh::dev_alloc(device, bytes ? bytes : 1, dptr));
     return BH_OK;
 }
 
 int bh_free(void* dptr) {
-    if (dptr) BH_CHECK_HIP(hipFree(dptr));
+    if (dptr) BH_CHECK_HIP(bh::dev_free(dptr));
     return BH_OK;
 }
 
