@@ -529,6 +529,7 @@ def main():
                 "fill_passes_ms": fill_s * 1e3,
             },
             "workspace_gb": ctx.workspace_bytes() / 1e9,
+            "alloc_layout": __import__("biahub_amd.device", fromlist=["alloc_layout"]).alloc_layout(),
             "rl_handle": {"backend": rl_prepared.backend, "box": list(rl_prepared.box), "otf_is_real": rl_prepared.otf_is_real,
                           "otf_gb": rl_prepared.otf_bytes / 1e9},
             "rccl": rccl,

@@ -111,6 +111,8 @@ hipError_t dev_alloc(int device, size_t bytes, void** out) {
     if (chunk_kb > 0 && bytes >= min_bytes) {
         const hipError_t e = vmm_alloc(device, bytes, (size_t)chunk_kb << 10, shuffle, out);
         if (e == hipSuccess || e == hipErrorOutOfMemory) return e;
+        fprintf(stderr, "[bhcore] virtual-memory allocation of %zu bytes failed (%s): gigabyte buffers come from hipMalloc from here on\n",
+                bytes, hipGetErrorString(e));
         (void)hipGetLastError();  // a driver without the virtual-memory API: hipMalloc from here on
         g_vmm_failed.store(true);
     }
@@ -317,6 +319,21 @@ int fft_inverse(const FftPlans* pl, float2* spec, float* real) {
 extern "C" {
 
 int bh_abi_version(void) { return BH_ABI_VERSION; }
+
+// How gigabyte buffers are laid out right now: chunk size in KiB (0 = hipMalloc), chunks shuffled or not, and how many
+// blocks / bytes are currently built that way (diagnostics: bench.py prints it).
+int bh_alloc_layout(int* chunk_kib, int* shuffled, uint64_t* live_blocks, uint64_t* live_bytes) {
+    if (chunk_kib) *chunk_kib = bh::g_vmm_failed.load() ? 0 : (int)bh::vmm_chunk_kb();
+    if (shuffled) *shuffled = bh::dev_alloc_is_shuffled() ? 1 : 0;
+    std::lock_guard<std::mutex> lk(bh::g_vmm_mu);
+    if (live_blocks) *live_blocks = bh::g_vmm.size();
+    if (live_bytes) {
+        uint64_t n = 0;
+        for (auto& kv : bh::g_vmm) n += kv.second.size;
+        *live_bytes = n;
+    }
+    return BH_OK;
+}
 
 // torch.cuda.memory.CUDAPluggableAllocator entry points: the allocator of a torch MemPool whose large blocks are laid out like
 // the library's own workspace (biahub_amd/device.py: volume_pool)

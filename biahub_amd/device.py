@@ -89,6 +89,15 @@ def volume_pool(device=None):
         _POOL_TLS.depth = 0
 
 
+def alloc_layout() -> dict:
+    """How the library lays out gigabyte buffers right now (``bh_alloc_layout``): chunk size, shuffled or not, live blocks."""
+    lib = _lib.load()
+    kib, shuf, nblk, nbytes = C.c_int(), C.c_int(), C.c_uint64(), C.c_uint64()
+    _lib.check(lib.bh_alloc_layout(C.byref(kib), C.byref(shuf), C.byref(nblk), C.byref(nbytes)))
+    return {"chunk_kib": kib.value, "shuffled": bool(shuf.value), "live_blocks": int(nblk.value), "live_gb": nbytes.value / 1e9,
+            "volume_pool": os.environ.get("BH_VOLUME_POOL", "1") != "0" and _POOL is not False}
+
+
 def release_volume_pool() -> None:
     """Give the pool's cached blocks back to the driver (blocks that live tensors still use go when those tensors do): the
     pool object is dropped — torch releases a pool's blocks with its last reference — and a new one is made on the next use."""

@@ -104,6 +104,7 @@ int bh_device_count(int* count);
 /* Device memory laid out like the library's own workspace (blocks of 64 MiB and more: 2-MiB physical chunks mapped in a
  * shuffled order through the HIP virtual-memory API; smaller ones: hipMalloc).  The signatures are the ones
  * torch.cuda.memory.CUDAPluggableAllocator binds (biahub_amd/device.py: volume_pool); any host may call them directly. */
+int bh_alloc_layout(int* chunk_kib, int* shuffled, uint64_t* live_blocks, uint64_t* live_bytes); /* diagnostics; any pointer may be NULL */
 void* bh_torch_alloc(size_t size, int device, void* hip_stream);
 void bh_torch_free(void* ptr, size_t size, int device, void* hip_stream);
 
