@@ -1101,7 +1101,7 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
         p.tw = pl.colz;
         p.ncoltiles = (int)ceil_div(p.XP, p.W);
         const long ntiles = (long)p.nouter * p.ncoltiles;
-        const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
+        const int grid = (int)std::min<long>(ntiles, (long)ctx->num_cus * (1024 / colz::NT));
         auto run = [&](auto kern) -> int {
             BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)colz::LDS_BYTES));
