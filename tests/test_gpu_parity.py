@@ -8,6 +8,7 @@ Tolerances (relative to the volume's max |value|):
 """
 
 import json
+import os
 
 import numpy as np
 import pytest
@@ -961,6 +962,48 @@ def test_volume_pool_layout(gpu, monkeypatch):
     monkeypatch.setenv("BH_VOLUME_POOL", "0")
     plain = richardson_lucy(torch.from_numpy(vol).to(gpu), torch.from_numpy(psf).to(gpu), 3, 1e-6).cpu().numpy()
     assert np.array_equal(got, plain)
+
+
+@pytest.mark.gpu
+def test_allocation_layout_switches(gpu, tmp_path):
+    """The physical layout of the workspace (csrc/context.hip ``dev_alloc``: 2-MiB chunks mapped in a shuffled order through the
+    HIP virtual-memory API, or ``hipMalloc`` with ``BH_ALLOC_VMM_MB=0``) is read once per process, so each layout runs in a
+    process of its own: same Richardson-Lucy bits, and ``bh_alloc_layout`` reports what was in force.  ``BH_ALLOC_VMM_MIN_MB=1``
+    makes the small test buffers take the virtual-memory path."""
+    import json
+    import subprocess
+    import sys
+
+    script = tmp_path / "layout_case.py"
+    script.write_text(
+        "import sys, json, numpy as np, torch\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "from biahub_amd.deconvolve import PreparedRichardsonLucy\n"
+        "from biahub_amd.device import alloc_layout\n"
+        "rng = np.random.default_rng(4)\n"
+        "vol = (rng.random((64, 128, 256), dtype=np.float32) * 300 + 50)\n"
+        "ax = [np.arange(n) - (n - 1) / 2 for n in (7, 5, 5)]\n"
+        "g = [np.exp(-0.5 * (a / 1.2) ** 2) for a in ax]\n"
+        "psf = (g[0][:, None, None] * g[1][None, :, None] * g[2][None, None, :]).astype(np.float32)\n"
+        "psf /= psf.sum()\n"
+        "dev = torch.device('cuda', 0)\n"
+        "with PreparedRichardsonLucy(psf, vol.shape, dev) as h:\n"
+        "    out = h(torch.from_numpy(vol).to(dev), 4, 1e-6).cpu().numpy()\n"
+        "    lay = alloc_layout()\n"
+        "np.save(sys.argv[1], out)\n"
+        "print(json.dumps(lay))\n")
+    outs, lays = [], []
+    for k, env in enumerate(({"BH_ALLOC_VMM_MIN_MB": "1"}, {"BH_ALLOC_VMM_MB": "0", "BH_VOLUME_POOL": "0"},
+                             {"BH_ALLOC_VMM_MIN_MB": "1", "BH_ALLOC_VMM_SHUFFLE": "0", "BH_ALLOC_VMM_MB": "4"})):
+        f = tmp_path / f"out{k}.npy"
+        r = subprocess.run([sys.executable, str(script), str(f)], capture_output=True, text=True, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr[-2000:]
+        lays.append(json.loads(r.stdout.strip().splitlines()[-1]))
+        outs.append(np.load(f))
+    assert lays[0]["chunk_kib"] == 2048 and lays[0]["shuffled"] and lays[0]["live_blocks"] >= 1
+    assert lays[1]["chunk_kib"] == 0 and not lays[1]["shuffled"] and lays[1]["live_blocks"] == 0 and not lays[1]["volume_pool"]
+    assert lays[2]["chunk_kib"] == 4096 and not lays[2]["shuffled"] and lays[2]["live_blocks"] >= 1
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 # ----------------------------------------------------------------------------- registration estimate (N1)
