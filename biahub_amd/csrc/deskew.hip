@@ -543,17 +543,26 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
                                          ((unsigned)(xb4 + 2 < g.Xp && val[2] == 0.0f) << 2) |
                                          ((unsigned)(xb4 + 3 < g.Xp && val[3] == 0.0f) << 3);
                     const int i16 = lane & 15;
-                    unsigned lo = i16 < 8 ? nib << (4 * i16) : 0u, hi = i16 < 8 ? 0u : nib << (4 * (i16 - 8));
+                    unsigned lo = 0u, hi = 0u;
+                    // most rows of the scanned range hold no exact zero at all: the words are then 0 without the row reduction
+                    // (a wave-uniform branch; BH_DK_MASK_SKIP=0: A/B switch)
+#ifndef BH_DK_MASK_SKIP
+#define BH_DK_MASK_SKIP 1
+#endif
+                    if (!BH_DK_MASK_SKIP || __ballot(nib != 0u) != 0ull) {
+                        lo = i16 < 8 ? nib << (4 * i16) : 0u;
+                        hi = i16 < 8 ? 0u : nib << (4 * (i16 - 8));
 #define BH_ROW_OR(v, sh) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + sh, 0xF, 0xF, true)  /* row_shr:sh, 0 shifted in */
-                    BH_ROW_OR(lo, 1);
-                    BH_ROW_OR(hi, 1);
-                    BH_ROW_OR(lo, 2);
-                    BH_ROW_OR(hi, 2);
-                    BH_ROW_OR(lo, 4);
-                    BH_ROW_OR(hi, 4);
-                    BH_ROW_OR(lo, 8);
-                    BH_ROW_OR(hi, 8);
+                        BH_ROW_OR(lo, 1);
+                        BH_ROW_OR(hi, 1);
+                        BH_ROW_OR(lo, 2);
+                        BH_ROW_OR(hi, 2);
+                        BH_ROW_OR(lo, 4);
+                        BH_ROW_OR(hi, 4);
+                        BH_ROW_OR(lo, 8);
+                        BH_ROW_OR(hi, 8);
 #undef BH_ROW_OR
+                    }
                     const int xw0 = q.xo0 + 64 * (lane >> 4);
                     if (i16 == 15 && xw0 < g.Xp)
                         *reinterpret_cast<uint2*>(g.mask0 + orow_i * g.W32 + xw0 / 32) = make_uint2(lo, hi);
