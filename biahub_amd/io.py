@@ -441,13 +441,14 @@ class ZarrArray:
         import torch
 
         from . import codecs
-        from .device import resolve_device
+        from .device import empty as device_empty, resolve_device, volume_pool
 
         dev = resolve_device("cuda" if device is None else device)
         plan = self._plane_chunks()
         tdt = _torch_dtype(self.dtype)
         if plan is None or tdt is None or not self.codecs:
-            return torch.from_numpy(self.read_volume(t, c)).to(dev)
+            with volume_pool(dev):  # the volume gets the library's page layout (device.volume_pool)
+                return torch.from_numpy(self.read_volume(t, c)).to(dev)
         T, C, Z, Y, X = self.shape
         ct, cc = self.chunks[:2]
         cbytes = self.inner[2] * Y * X * self.dtype.itemsize
@@ -476,7 +477,7 @@ class ZarrArray:
             heads[i] = h
 
         _io_map(one, range(len(plan)))
-        out = torch.empty((Z, Y, X), dtype=tdt, device=dev)
+        out = device_empty((Z, Y, X), tdt, dev)
         out8 = out.view(torch.uint8).reshape(-1)
         dstage = stage.to(dev, non_blocking=True)
         plane = Y * X * self.dtype.itemsize
