@@ -27,9 +27,19 @@ void set_error(const char* fmt, ...) {
 // BH_ALLOC_VMM_SHUFFLE=1 — so that the largest physically contiguous piece (what a page-table entry's fragment field can
 // cover) is under the caller's control.
 struct VmmBlock {
-    size_t size = 0;
+    size_t size = 0, chunk = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;
 };
+// every chunk is unmapped by a call of its own, with exactly the range its hipMemMap call had (an unmap spanning several
+// mappings is not something the API promises to take apart)
+static hipError_t vmm_unmap_all(void* va, const VmmBlock& blk, size_t mapped_chunks) {
+    hipError_t first = hipSuccess;
+    for (size_t i = 0; i < mapped_chunks; ++i) {
+        const hipError_t e = hipMemUnmap(static_cast<char*>(va) + i * blk.chunk, blk.chunk);
+        if (e != hipSuccess && first == hipSuccess) first = e;
+    }
+    return first;
+}
 static std::mutex g_vmm_mu;
 static std::map<void*, VmmBlock> g_vmm;
 
@@ -53,6 +63,7 @@ static hipError_t vmm_alloc(int device, size_t bytes, size_t chunk, bool shuffle
     if ((e = hipMemAddressReserve(&va, size, chunk, nullptr, 0)) != hipSuccess) return e;
     VmmBlock blk;
     blk.size = size;
+    blk.chunk = chunk;
     std::vector<size_t> slot(n);
     for (size_t i = 0; i < n; ++i) slot[i] = i;
     if (shuffle) {
@@ -80,7 +91,9 @@ static hipError_t vmm_alloc(int device, size_t bytes, size_t chunk, bool shuffle
         e = hipMemSetAccess(va, size, &acc, 1);
     }
     if (e != hipSuccess) {
-        (void)hipMemUnmap(va, size);
+        // slots are not mapped in address order: unmap whatever is there, chunk by chunk (errors for unmapped slots are expected)
+        (void)vmm_unmap_all(va, blk, n);
+        (void)hipGetLastError();
         for (auto h : blk.handles) (void)hipMemRelease(h);
         (void)hipMemAddressFree(va, size);
         return e;
@@ -104,7 +117,19 @@ static bool vmm_shuffle() {
 static std::atomic<bool> g_vmm_failed{false};  // the driver refused the virtual-memory API once: hipMalloc from then on
 bool dev_alloc_is_shuffled() { return vmm_chunk_kb() > 0 && vmm_shuffle() && !g_vmm_failed.load(); }
 
+static hipError_t dev_alloc_raw(int device, size_t bytes, void** out);
 hipError_t dev_alloc(int device, size_t bytes, void** out) {
+    // BH_ALLOC_POISON=1 (debugging): every new block is filled with 0xFF bytes (float NaNs, huge integers), so that a kernel
+    // that reads memory nobody wrote shows up deterministically instead of depending on what the pages held before
+    static const bool poison = getenv("BH_ALLOC_POISON") && atoi(getenv("BH_ALLOC_POISON")) != 0;
+    const hipError_t e = dev_alloc_raw(device, bytes, out);
+    if (e == hipSuccess && poison) {
+        (void)hipMemset(*out, 0xFF, bytes);
+        (void)hipDeviceSynchronize();
+    }
+    return e;
+}
+static hipError_t dev_alloc_raw(int device, size_t bytes, void** out) {
     const long chunk_kb = g_vmm_failed.load() ? 0 : vmm_chunk_kb();
     const bool shuffle = vmm_shuffle();
     static const size_t min_bytes = (size_t)(getenv("BH_ALLOC_VMM_MIN_MB") ? atol(getenv("BH_ALLOC_VMM_MIN_MB")) : 64) << 20;
@@ -129,9 +154,21 @@ hipError_t dev_free(void* p) {
         g_vmm.erase(it);
     }
     (void)hipDeviceSynchronize();
-    hipError_t e = hipMemUnmap(p, blk.size);
-    for (auto h : blk.handles) (void)hipMemRelease(h);
-    (void)hipMemAddressFree(p, blk.size);
+    hipError_t e = vmm_unmap_all(p, blk, blk.size / blk.chunk);
+    for (auto h : blk.handles) {
+        const hipError_t er = hipMemRelease(h);
+        if (er != hipSuccess && e == hipSuccess) e = er;
+    }
+    // The address range is NOT given back (BH_ALLOC_VMM_FREE_VA=1 does): a range that is reserved again right after its release
+    // and mapped onto other physical chunks was seen to deliver the old pages' contents now and then (tools/alloc_stress.py: a
+    // wrong Richardson-Lucy result once in ~100 rebuilds of the workspace, never with this) — address translations of the
+    // old mapping outliving it.  Address space is 2^47 bytes; a freed block costs none of it that matters.
+    static const bool free_va = getenv("BH_ALLOC_VMM_FREE_VA") && atoi(getenv("BH_ALLOC_VMM_FREE_VA")) != 0;
+    if (free_va) {
+        const hipError_t ef = hipMemAddressFree(p, blk.size);
+        if (ef != hipSuccess && e == hipSuccess) e = ef;
+    }
+    (void)hipDeviceSynchronize();
     return e;
 }
 

@@ -279,3 +279,18 @@ def test_fuzz_radix8_z_pass_equals_radix4(gpu, monkeypatch):
         for a, b in zip(res["1"], res["0"]):
             assert rel_err(a, b) <= 2e-5, (shape, pshape, rel_err(a, b))
         assert rel_err(res["1"][0], O.richardson_lucy_zyx(volh, sym, iterations=2, eps=1e-6)) <= 1e-4, shape
+
+
+def test_workspace_rebuild_stress(gpu):
+    """tools/alloc_stress.py: Richardson-Lucy on alternating shapes with the whole workspace given back to the driver every few
+    rounds, so that gigabyte-class blocks (virtual-memory mappings of shuffled 2-MiB chunks) are torn down and rebuilt again and
+    again; every result must equal the first of its shape bit for bit.  This is the regression test of the address-range reuse
+    hazard (csrc/context.hip dev_free: a released range that was reserved and mapped again delivered stale pages now and then)."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "alloc_stress.py"), "15"], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "0 mismatches" in r.stdout
