@@ -21,11 +21,13 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-// Device memory of the workspace.  Normally hipMalloc.  BH_ALLOC_VMM_MB=<chunk size in MiB> (an experiment on where the driver
-// puts gigabyte buffers): allocations of 256 MiB and more are assembled with the virtual-memory API instead —
-// one reserved address range, physical chunks of that size created one by one and mapped in order, or in a random order with
-// BH_ALLOC_VMM_SHUFFLE=1 — so that the largest physically contiguous piece (what a page-table entry's fragment field can
-// cover) is under the caller's control.
+// Device memory of the workspace ("Root cause").  Blocks of 64 MiB and more are assembled with the HIP
+// virtual-memory API: one reserved address range, physical chunks of 2 MiB created one by one and mapped in a shuffled order —
+// physically contiguous gigabytes make the strided streams of the transform passes collide in the HBM channel / bank hash
+// (R-L iteration 34.7 -> 31.5-32.7 ms), chunks below 2 MiB lose the page-table fragment (121-202 ms).  Smaller blocks, and
+// everything when BH_ALLOC_VMM_MB=0 or when the driver refuses the API, come from hipMalloc.  The knobs of the experiment
+// stay: BH_ALLOC_VMM_MB / _KB (chunk size), BH_ALLOC_VMM_SHUFFLE=0 (chunks in order), BH_ALLOC_VMM_SEED=n (one permutation
+// for all blocks), BH_ALLOC_VMM_MIN_MB (smallest block built this way), BH_ALLOC_POISON=1, BH_ALLOC_VMM_FREE_VA=1 (dev_free).
 struct VmmBlock {
     size_t size = 0, chunk = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;
