@@ -108,6 +108,7 @@ int free_scratch(bh_ctx* ctx, const char* name);
 hipError_t dev_alloc(int device, size_t bytes, void** out);
 hipError_t dev_free(void* p);
 bool dev_alloc_is_shuffled();  // the default layout is in force (not switched off by BH_ALLOC_VMM_MB=0)
+bool dev_block_is_vmm(const void* p);  // this block was built from mapped chunks (large enough for the layout)
 int get_plans(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, FftPlans** out);
 // real (Z,Y,X) -> half spectrum (Z,Y,X/2+1), unnormalised
 int fft_forward(const FftPlans* pl, const float* real, float2* spec);

@@ -1567,7 +1567,7 @@ int fftconv_tune_spectrum(bh_ctx* ctx, const ConvPlan& pl, float* est, size_t by
     // Round 3: with the workspace's default layout (2-MiB physical chunks in a shuffled order, context.hip dev_alloc) the pass
     // reads 5.87-6.5 ms on every allocation tried and the audition is off; it stays for the hipMalloc layout
     // (BH_ALLOC_VMM_MB=0), where the two states are 5.95 and 7.07 ms.  BH_FC_TUNE_ALLOC=0 / 1 forces it off / on.
-    const bool tune = getenv("BH_FC_TUNE_ALLOC") ? atoi(getenv("BH_FC_TUNE_ALLOC")) != 0 : !dev_alloc_is_shuffled();
+    const bool tune = getenv("BH_FC_TUNE_ALLOC") ? atoi(getenv("BH_FC_TUNE_ALLOC")) != 0 : !(dev_alloc_is_shuffled() && dev_block_is_vmm(*spec));
     if (!pl.xw || V < (double)(1u << 28) || !tune) return BH_OK;
     hipEvent_t e0, e1;
     BH_CHECK_HIP(hipEventCreate(&e0));

@@ -291,6 +291,10 @@ def test_workspace_rebuild_stress(gpu):
 
     from conftest import ROOT
 
-    r = subprocess.run([sys.executable, str(ROOT / "tools" / "alloc_stress.py"), "15"], capture_output=True, text=True)
+    import os
+
+    # the stress shapes are small: the threshold is lowered so that their buffers take the virtual-memory path
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "alloc_stress.py"), "15"], capture_output=True, text=True,
+                       env={**os.environ, "BH_ALLOC_VMM_MIN_MB": "64"})
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "0 mismatches" in r.stdout
