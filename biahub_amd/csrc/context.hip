@@ -21,7 +21,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-// Device memory of the workspace ("Root cause").  Blocks of 3 GiB and more are assembled with the HIP
+// Device memory of the workspace ("Root cause").  Blocks of 2 GiB and more are assembled with the HIP
 // virtual-memory API: one reserved address range, physical chunks of 2 MiB created one by one and mapped in a shuffled order —
 // physically contiguous gigabytes make the strided streams of the transform passes collide in the HBM channel / bank hash
 // (R-L iteration 34.7 -> 31.5-32.7 ms), chunks below 2 MiB lose the page-table fragment (121-202 ms).  Smaller blocks, and
@@ -138,11 +138,13 @@ hipError_t dev_alloc(int device, size_t bytes, void** out) {
 static hipError_t dev_alloc_raw(int device, size_t bytes, void** out) {
     const long chunk_kb = g_vmm_failed.load() ? 0 : vmm_chunk_kb();
     const bool shuffle = vmm_shuffle();
-    // 3 GiB: below that the shuffled layout costs instead of paying (R-L x10 on (256,1024,1024): 48.7 against 42.8 ms, on
+    // 2 GiB: below that the shuffled layout costs instead of paying (R-L x10 on (256,1024,1024): 48.7 against 42.8 ms, on
     // (128,512,512) 6.4 against 5.8; on (256,2048,2048), 4.4-GB buffers, 175-181 against 179; on (512,2048,2048), 8.7 GB, 31.5-32
     // against 34.7 per iteration: tools/time_rl_sizes.py) — 2-MiB fragments shorten the reach of the address translation, and
-    // only the giant blocks suffer enough from the contiguous layout to make up for it
-    static const size_t min_bytes = (size_t)(getenv("BH_ALLOC_VMM_MIN_MB") ? atol(getenv("BH_ALLOC_VMM_MIN_MB")) : 3072) << 20;
+    // only the giant blocks suffer enough from the contiguous layout to make up for it; a threshold sweep on one box (R-L x10,
+    // thresholds 3 GiB / 2000 MB / 1000 MB / hipMalloc): (256,1024,1024) 43.0 / 43.0 / 46.8 / 43.1 ms, the deskewed config-4
+    // volume (2.4-GB buffers) 102.6 / 101.2 / 99.2 / 102.7, (256,2048,2048) (4.4 GB) 172.4 / 167.9 / 166.3 / 172.9
+    static const size_t min_bytes = (size_t)(getenv("BH_ALLOC_VMM_MIN_MB") ? atol(getenv("BH_ALLOC_VMM_MIN_MB")) : 2048) << 20;
     if (chunk_kb > 0 && bytes >= min_bytes) {
         const hipError_t e = vmm_alloc(device, bytes, (size_t)chunk_kb << 10, shuffle, out);
         if (e == hipSuccess || e == hipErrorOutOfMemory) return e;

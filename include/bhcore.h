@@ -101,7 +101,7 @@ typedef struct bh_ctx bh_ctx;
 int bh_abi_version(void);
 const char* bh_last_error(void);
 int bh_device_count(int* count);
-/* Device memory laid out like the library's own workspace (blocks of 3 GiB and more: 2-MiB physical chunks mapped in a
+/* Device memory laid out like the library's own workspace (blocks of 2 GiB and more: 2-MiB physical chunks mapped in a
  * shuffled order through the HIP virtual-memory API; smaller ones: hipMalloc).  The signatures are the ones
  * torch.cuda.memory.CUDAPluggableAllocator binds (biahub_amd/device.py: volume_pool); any host may call them directly. */
 int bh_alloc_layout(int* chunk_kib, int* shuffled, uint64_t* live_blocks, uint64_t* live_bytes); /* diagnostics; any pointer may be NULL */

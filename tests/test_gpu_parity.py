@@ -932,7 +932,7 @@ def test_prepared_phase_cross_corr(gpu):
 @pytest.mark.gpu
 def test_volume_pool_layout(gpu, monkeypatch):
     """``device.volume_pool``: torch tensors allocated inside it come from the library's allocator (``bh_torch_alloc``: 2-MiB
-    physical chunks mapped in a shuffled order for blocks of 3 GiB and more — ``BH_ALLOC_VMM_MIN_MB`` — ``hipMalloc`` below).  Re-entrant, tensors outlive the context, freed
+    physical chunks mapped in a shuffled order for blocks of 2 GiB and more — ``BH_ALLOC_VMM_MIN_MB`` — ``hipMalloc`` below).  Re-entrant, tensors outlive the context, freed
     blocks are reused, and the operators compute the same bits on pooled and on plain tensors."""
     from biahub_amd.deconvolve import richardson_lucy
     from biahub_amd.device import empty, get_context, volume_pool

@@ -8,7 +8,7 @@ ax = [torch.arange(n, dtype=torch.float64, device=dev) - (n - 1) / 2 for n in (3
 g = [torch.exp(-0.5 * (a / s) ** 2) for a, s in zip(ax, (3.0, 1.5, 1.5))]
 psf = g[0][:, None, None] * g[1][None, :, None] * g[2][None, None, :]
 psf = (psf / psf.sum()).float()
-for shape in ((256, 1024, 1024), (128, 512, 512), (256, 2048, 2048)):
+for shape in ((256, 1024, 1024), (128, 512, 512), (342, 1024, 1517), (256, 2048, 2048)):
     vol = empty(shape, torch.float32, dev).uniform_(90, 400)
     out = empty(shape, torch.float32, dev)
     with PreparedRichardsonLucy(psf, shape, dev) as h:
