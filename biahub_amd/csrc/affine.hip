@@ -476,6 +476,158 @@ __global__ __launch_bounds__(A_NT) void affine_kernel(const TIN* __restrict__ in
     sample_tile<TIN, INTERP, BOUNDARY>(in, out, p, box, tile);
 }
 
+// Strongly coupled warps (a rotation of more than a few degrees that mixes z with x or y): the source box of a 64 x 8 x 8
+// output tile no longer fits LDS, and affine_kernel's fallback — every lane of a 64-voxel x row gathering its eight taps from
+// wherever the map sends it — touches up to 64 planes per wave instruction (20 degrees about y: 33 ms, 45 degrees about an
+// oblique axis: 94 ms for an 8.6-GB volume; tools/affine_angle_sweep.py).  Here a workgroup owns a COMPACT block of the output,
+// 16 (z) x 4 (y) x 16 (x) voxels, a wavefront 16 x-voxels of 4 rows of one plane and then the next three planes: the source
+// footprint of a workgroup is a small rotated box that lives in L1 / L2 whatever the matrix, stores are 64-byte segments.
+// The per-voxel arithmetic is sample_tile's, branch for branch (Q32.32 + lerp8 for linear with an edge clamp, the generic float64
+// path otherwise): results are bit-identical to the tile kernel's.
+constexpr int GX = 16, GY = 4, GZL = 4, GK = 4;  // lanes along x, y, z and planes per lane: block = GX x GY x (GZL * GK)
+template <typename TIN, int INTERP, int BOUNDARY>
+__global__ __launch_bounds__(256) void affine_gather_kernel(const TIN* __restrict__ in, float* __restrict__ out, AffineParams p,
+                                                            int nbx, int nby, int nblocks, int per_xcd) {
+    const int b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // every XCD walks its own contiguous run of blocks (x fastest)
+    if ((int)(blockIdx.x >> 3) >= per_xcd || b >= nblocks) return;
+    const int bz = b / (nbx * nby), rem = b - bz * (nbx * nby), byi = rem / nbx, bxi = rem - byi * nbx;
+    const int t = threadIdx.x;
+    const int ox = bxi * GX + (t & (GX - 1)), oy = byi * GY + ((t >> 4) & (GY - 1)), ozb = bz * (GZL * GK) + (t >> 6) * GK;
+    if (ox >= p.Xo || oy >= p.Yo) return;
+    const size_t sY = (size_t)p.Xi, sZ = (size_t)p.Yi * p.Xi;
+    auto fetch = [&](int iz, int iy, int ix) -> float { return load_clean(in + (size_t)iz * sZ + (size_t)iy * sY + ix); };
+    const int dims[3] = {p.Zi, p.Yi, p.Xi};
+    if (INTERP == BH_INTERP_LINEAR && BOUNDARY != BH_BOUNDARY_ZEROS) {
+        // the tile kernel's linear path for tiles that are not interior, voxel for voxel: Q32.32 coordinates (exact integer
+        // arithmetic: the value does not depend on how the walk through z is organised), the inside decision on the float64
+        // coordinate in numpy / ITK association, clamped taps through load_clean, lerp8 — bit-identical results
+        long long c0[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            c0[a] = p.mq[4 * a] * (long long)(ozb + p.cz) + p.mq[4 * a + 1] * (long long)(oy + p.cy) +
+                    p.mq[4 * a + 2] * (long long)(ox + p.cx) + p.mq[4 * a + 3];
+        for (int k = 0; k < GK; ++k) {
+            const int oz = ozb + k;
+            if (oz >= p.Zo) break;
+            const int iz = (int)(c0[0] >> 32), iy = (int)(c0[1] >> 32), ix = (int)(c0[2] >> 32);
+            bool inside = true;
+            {
+#pragma clang fp contract(off)
+                const double zd = (double)(oz + p.cz), yd = (double)(oy + p.cy), xd = (double)(ox + p.cx);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double ca = p.m[4 * a] * zd + p.m[4 * a + 1] * yd + p.m[4 * a + 2] * xd + p.m[4 * a + 3];
+                    if (BOUNDARY == BH_BOUNDARY_ITK)
+                        inside = inside && ca >= -0.5 && ca < (double)dims[a] - 0.5;
+                    else
+                        inside = inside && ca >= 0.0 && ca <= (double)(dims[a] - 1);
+                }
+            }
+            float r = p.cval;
+            if (inside) {
+                const int z0 = max(0, min(iz, p.Zi - 1)), z1 = max(0, min(iz + 1, p.Zi - 1));
+                const int y0 = max(0, min(iy, p.Yi - 1)), y1 = max(0, min(iy + 1, p.Yi - 1));
+                const int x0 = max(0, min(ix, p.Xi - 1)), x1 = max(0, min(ix + 1, p.Xi - 1));
+                // (one unaligned 8-byte load per x pair instead of two 4-byte ones was tried: 2-3x SLOWER)
+                const f2 P0 = {fetch(z0, y0, x0), fetch(z0, y0, x1)};
+                const f2 P1 = {fetch(z0, y1, x0), fetch(z0, y1, x1)};
+                const f2 P2 = {fetch(z1, y0, x0), fetch(z1, y0, x1)};
+                const f2 P3 = {fetch(z1, y1, x0), fetch(z1, y1, x1)};
+                r = lerp8(P0, P1, P2, P3, (unsigned)c0[0], (unsigned)c0[1], (unsigned)c0[2]);
+            }
+            out[((size_t)oz * p.Yo + oy) * p.Xo + ox] = r;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) c0[a] += p.mq[4 * a];
+        }
+        return;
+    }
+    double py[3], px[3];
+    {
+#pragma clang fp contract(off)
+        const double yd = (double)(oy + p.cy), xd = (double)(ox + p.cx);
+        for (int a = 0; a < 3; ++a) {
+            py[a] = p.m[4 * a + 1] * yd;
+            px[a] = p.m[4 * a + 2] * xd;
+        }
+    }
+    for (int k = 0; k < GK; ++k) {
+        const int oz = ozb + k;
+        if (oz >= p.Zo) break;
+        double c[3];
+        {
+#pragma clang fp contract(off)
+            const double zd = (double)(oz + p.cz);
+            for (int a = 0; a < 3; ++a) c[a] = ((p.m[4 * a] * zd + py[a]) + px[a]) + p.m[4 * a + 3];
+        }
+        bool inside = true;
+        if (BOUNDARY == BH_BOUNDARY_ITK) {
+            for (int a = 0; a < 3; ++a) inside = inside && (c[a] >= -0.5) && (c[a] < (double)dims[a] - 0.5);
+        } else if (BOUNDARY == BH_BOUNDARY_SCIPY_CONSTANT) {
+            for (int a = 0; a < 3; ++a) inside = inside && (c[a] >= 0.0) && (c[a] <= (double)(dims[a] - 1));
+        } else {
+            for (int a = 0; a < 3; ++a) inside = inside && (c[a] > -2.0) && (c[a] < (double)dims[a] + 1.0);
+        }
+        float r = p.cval;
+        if (inside) {
+            if (INTERP == BH_INTERP_NEAREST) {
+                int i[3];
+                bool ok = true;
+                for (int a = 0; a < 3; ++a) {
+                    i[a] = (int)floor(c[a] + 0.5);
+                    if (BOUNDARY == BH_BOUNDARY_ITK) i[a] = max(0, min(i[a], dims[a] - 1));
+                    ok = ok && i[a] >= 0 && i[a] < dims[a];
+                }
+                if (ok) r = fetch(i[0], i[1], i[2]);
+            } else {
+                int z0, z1, y0, y1, x0, x1;
+                float wz0, wz1, wy0, wy1, wx0, wx1;
+                axis_plan<BOUNDARY>(c[0], p.Zi, z0, z1, wz0, wz1);
+                axis_plan<BOUNDARY>(c[1], p.Yi, y0, y1, wy0, wy1);
+                axis_plan<BOUNDARY>(c[2], p.Xi, x0, x1, wx0, wx1);
+                float acc = 0.0f;
+                acc += (wz0 * wy0 * wx0) * fetch(z0, y0, x0);
+                acc += (wz0 * wy0 * wx1) * fetch(z0, y0, x1);
+                acc += (wz0 * wy1 * wx0) * fetch(z0, y1, x0);
+                acc += (wz0 * wy1 * wx1) * fetch(z0, y1, x1);
+                acc += (wz1 * wy0 * wx0) * fetch(z1, y0, x0);
+                acc += (wz1 * wy0 * wx1) * fetch(z1, y0, x1);
+                acc += (wz1 * wy1 * wx0) * fetch(z1, y1, x0);
+                acc += (wz1 * wy1 * wx1) * fetch(z1, y1, x1);
+                if (BOUNDARY == BH_BOUNDARY_ZEROS) {
+                    const float cover = (wz0 + wz1) * (wy0 + wy1) * (wx0 + wx1);
+                    acc += (1.0f - cover) * p.cval;
+                }
+                r = acc;
+            }
+        }
+        out[((size_t)oz * p.Yo + oy) * p.Xo + ox] = r;
+    }
+}
+
+template <typename TIN>
+static int launch_affine_gather(bh_ctx* ctx, const TIN* in, float* out, const AffineParams& p) {
+    const int64_t nbx = ceil_div(p.Xo, GX), nby = ceil_div(p.Yo, GY), nbz = ceil_div(p.Zo, GZL * GK);
+    const int64_t nblocks = nbx * nby * nbz;
+    BH_REQUIRE(nblocks < (1ll << 31) - 8, "affine output too large");
+    const int per_xcd = (int)ceil_div(nblocks, (int64_t)8);
+    const int grid = per_xcd * 8;
+    auto run = [&](auto kern) -> int {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, ctx->stream, in, out, p, (int)nbx, (int)nby, (int)nblocks, per_xcd);
+        BH_CHECK_HIP(hipGetLastError());
+        return BH_OK;
+    };
+#define BH_AFF(I, B) return run(affine_gather_kernel<TIN, I, B>)
+    if (p.interp == BH_INTERP_NEAREST) {
+        if (p.boundary == BH_BOUNDARY_ITK) BH_AFF(BH_INTERP_NEAREST, BH_BOUNDARY_ITK);
+        if (p.boundary == BH_BOUNDARY_SCIPY_CONSTANT) BH_AFF(BH_INTERP_NEAREST, BH_BOUNDARY_SCIPY_CONSTANT);
+        BH_AFF(BH_INTERP_NEAREST, BH_BOUNDARY_ZEROS);
+    }
+    if (p.boundary == BH_BOUNDARY_ITK) BH_AFF(BH_INTERP_LINEAR, BH_BOUNDARY_ITK);
+    if (p.boundary == BH_BOUNDARY_SCIPY_CONSTANT) BH_AFF(BH_INTERP_LINEAR, BH_BOUNDARY_SCIPY_CONSTANT);
+    BH_AFF(BH_INTERP_LINEAR, BH_BOUNDARY_ZEROS);
+#undef BH_AFF
+}
+
 template <typename TIN>
 static int launch_affine(bh_ctx* ctx, const TIN* in, float* out, const AffineParams& p) {
     const int64_t ntx = ceil_div(p.Xo, ATX), nty = ceil_div(p.Yo, ATY), ntz = ceil_div(p.Zo, ATZ);
@@ -539,6 +691,7 @@ extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, 
     p.cval = cval;
     p.x4 = (in_dtype == BH_DT_F32 && Xi % 4 == 0 && ((uintptr_t)in & 15) == 0) ? 1 : 0;
     p.x8 = ((in_dtype == BH_DT_U16 || in_dtype == BH_DT_I16) && Xi % 8 == 0 && ((uintptr_t)in & 15) == 0) ? 1 : 0;
+    bool box_fits = true;
     // Upper bound of any tile's source box (compute_box: hi - lo <= sum |m| * (T - 1), then floor / floor + 1 and the
     // slack add at most 3): the launch asks for exactly that much LDS, so a gentle warp (a stabilisation shift needs
     // 10 x 10 x 66 floats) runs six workgroups per CU instead of four.  Tiles that exceed it gather from global memory.
@@ -555,6 +708,12 @@ extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, 
         }
         const int cap = p.x8 ? A_LDS_FLOATS_X8 : A_LDS_FLOATS;
         p.lds_floats = nb < (double)cap ? (int)nb : cap;
+        // The tile kernel stages every tile whose own box fits and gathers for the others, which it does well as long as a
+        // row of 64 x-voxels stays within a few source planes.  The compact-block kernel takes over when a full tile's box
+        // does not fit AND the tile's x extent crosses 20 planes or more (|m_zx| * 63: 20 degrees about y; measured per angle
+        // and axis by tools/affine_angle_sweep.py — below that the tile kernel is the faster one, z-y coupling never needs it).
+        const double zx_min = getenv("BH_AFFINE_GATHER_ZX") ? atof(getenv("BH_AFFINE_GATHER_ZX")) : 20.0;
+        box_fits = nb < (double)cap || std::fabs(matrix[2]) * (double)(ATX - 1) < zx_min;
     }
     p.zslot = 0;
     if ((p.x4 || p.x8) && getenv("BH_ZW_NOLDS") == nullptr) {
@@ -582,6 +741,17 @@ extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, 
         if (slot && in_dtype == BH_DT_F32) return zo::launch(ctx, (const float*)in, out, p, slot, zchunk);
         if (slot && in_dtype == BH_DT_U16) return zo::launch(ctx, (const uint16_t*)in, out, p, slot, zchunk);
         if (slot) return zo::launch(ctx, (const int16_t*)in, out, p, slot, zchunk);
+    }
+    // a full tile's source box does not fit LDS: compact blocks gathering through the caches (BH_AFFINE_GATHER=0, and
+    // BH_AFFINE_NOZWALK=1 — "everything on the tile kernel", the reference of the bit-identity tests —: the tile kernel)
+    if (!box_fits && !(getenv("BH_AFFINE_GATHER") && atoi(getenv("BH_AFFINE_GATHER")) == 0) && getenv("BH_AFFINE_NOZWALK") == nullptr) {
+        switch (in_dtype) {
+            case BH_DT_F32: return launch_affine_gather(ctx, (const float*)in, out, p);
+            case BH_DT_U16: return launch_affine_gather(ctx, (const uint16_t*)in, out, p);
+            case BH_DT_U8: return launch_affine_gather(ctx, (const uint8_t*)in, out, p);
+            case BH_DT_I16: return launch_affine_gather(ctx, (const int16_t*)in, out, p);
+            default: BH_REQUIRE(false, "unsupported input dtype code %d", in_dtype);
+        }
     }
     switch (in_dtype) {
         case BH_DT_F32: return launch_affine(ctx, (const float*)in, out, p);

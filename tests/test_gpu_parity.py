@@ -478,6 +478,47 @@ def test_affine_itk_mode_vs_oracle(gpu, M, interp):
     assert got4.shape == (2,) + out_shape and np.array_equal(got4[0], got)
 
 
+def _rotation_about(axis, angle_deg, centre):
+    ax = np.asarray(axis, float) / np.linalg.norm(axis)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    th = np.deg2rad(angle_deg)
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    M = np.eye(4)
+    M[:3, :3] = R
+    M[:3, 3] = np.asarray(centre) - R @ np.asarray(centre)
+    return M
+
+
+@pytest.mark.parametrize("interp", ["linear", "nearestneighbor"])
+@pytest.mark.parametrize("axis,angle", [((0, 1.0, 0), 20.0), ((0, 1.0, 0), 45.0), ((1.0, 0.4, 0.3), 30.0), ((1.0, 0.4, 0.3), 90.0),
+                                        ((0, 0.2, 1.0), 60.0)])
+def test_affine_strongly_coupled_rotations(gpu, axis, angle, interp, monkeypatch):
+    """Rotations that mix z with x / y by more than a few degrees: a full output tile's source box does not fit LDS and the
+    warp runs on compact 16 x 4 x 16 blocks gathering through the caches (affine_gather_kernel).  Against the oracle, against
+    the tile kernel's own gather fallback (BH_AFFINE_GATHER=0), for float32 and uint16 input, with a cropped launch."""
+    from biahub_amd.register import apply_affine_transform
+
+    rng = np.random.default_rng(17)
+    shape = (40, 72, 136)
+    vol = (rng.random(shape, dtype=np.float32) * 1000).round()
+    M = _rotation_about(axis, angle, [(n - 1) / 2 for n in shape])
+    out_shape = (44, 70, 150)
+    want = O.apply_affine_transform(vol, M, out_shape, interp)
+    got = apply_affine_transform(vol, M, out_shape, interpolation=interp)
+    if interp == "linear":
+        assert rel_err(got, want) <= 1e-5
+    else:
+        assert np.array_equal(got, want)
+    monkeypatch.setenv("BH_AFFINE_GATHER", "0")
+    tile = apply_affine_transform(vol, M, out_shape, interpolation=interp)
+    monkeypatch.delenv("BH_AFFINE_GATHER")
+    assert np.array_equal(got, tile)  # same arithmetic voxel for voxel: which kernel ran does not show
+    got16 = apply_affine_transform(vol.astype(np.uint16), M, out_shape, interpolation=interp)
+    assert np.array_equal(got16, got)
+    crop = (slice(3, 40), slice(5, 66), slice(9, 140))
+    assert np.array_equal(apply_affine_transform(vol, M, out_shape, interpolation=interp, crop_output_slicing=crop), got[crop])
+
+
 @pytest.mark.parametrize("X", [200, 198])  # 16-B LDS-DMA staging / dword staging (rows not 16-B aligned)
 def test_affine_interior_tiles_nonfinite(gpu, X):
     """Volume large enough that most tiles take the interior (branch-free) loop; NaN / +-inf taps inside them must

@@ -9,7 +9,8 @@ from biahub_amd.register import affine_device
 dev = torch.device("cuda", 0)
 ctx = get_context(dev); ctx.set_timing(True)
 shape = (512, 2048, 2048)
-vol = torch.rand(shape, device=dev) * 1000
+from biahub_amd.device import empty
+vol = empty(shape, torch.float32, dev).uniform_(0, 1000)
 th = np.deg2rad(2.0)
 c, s = np.cos(th), np.sin(th)
 MATS = {
@@ -18,12 +19,18 @@ MATS = {
     "shift": np.array([[1, 0, 0, 2.25], [0, 1, 0, -7.5], [0, 0, 1, 11.125], [0, 0, 0, 1.0]]),
     # the same 2 deg / 1.02x similarity about an oblique axis (z couples with y and x: the staged-tile kernel)
     "oblique": None,
+    "strong": None,
 }
 ax = np.array([1.0, 0.4, 0.3]); ax /= np.linalg.norm(ax)
 K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
 Rm = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
 ob = np.eye(4); ob[:3, :3] = 1.02 * Rm; ob[:3, 3] = (3.5, -12.25, 20.75)
 MATS["oblique"] = ob
+# 20 degrees about the same axis: strong z coupling, the staged-tile kernel
+th2 = np.deg2rad(20.0)
+Rm2 = np.eye(3) + np.sin(th2) * K + (1 - np.cos(th2)) * K @ K
+st = np.eye(4); st[:3, :3] = Rm2; st[:3, 3] = (30.0, -120.0, 200.0)
+MATS["strong"] = st
 names = [a for a in sys.argv[1:] if a in MATS] or ["similarity"]
 for name in names:
     for interp in ("linear", "nearestneighbor"):
