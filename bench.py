@@ -171,6 +171,15 @@ def ops_suite(vol, psf, dev, ctx):
     rec("affine_linear_f32_oblique", lambda: affine_device(vol, Mo, shape, "linear"), _lib.T_AFFINE, 8 * V,
         "the same 2 deg / 1.02x similarity about an oblique axis: z couples weakly with y and x — the z walk with per-lane source "
         "planes (csrc/affine_zoblique.inc); stronger couplings run the staged-tile kernel")
+    c0 = np.array([(n - 1) / 2 for n in shape])
+    th = np.deg2rad(45.0)
+    R45 = np.array([[np.cos(th), 0.0, np.sin(th)], [0.0, 1.0, 0.0], [-np.sin(th), 0.0, np.cos(th)]])
+    M45 = np.eye(4)
+    M45[:3, :3] = R45
+    M45[:3, 3] = c0 - R45 @ c0
+    rec("affine_linear_f32_rot45_about_y", lambda: affine_device(vol, M45, shape, "linear"), _lib.T_AFFINE, 8 * V,
+        "45 deg about the y axis through the centre: z couples strongly with x — compact 16 x 4 x 16 output blocks gathering "
+        "through the caches (affine_gather_kernel; the tile kernel's fallback took 59 ms)")
     x = torch.empty_like(vol)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for _ in range(3):
