@@ -481,21 +481,58 @@ __global__ __launch_bounds__(A_NT) void affine_kernel(const TIN* __restrict__ in
 // wherever the map sends it — touches up to 64 planes per wave instruction (20 degrees about y: 33 ms, 45 degrees about an
 // oblique axis: 94 ms for an 8.6-GB volume; tools/affine_angle_sweep.py).  Here a workgroup owns a COMPACT block of the output,
 // 16 (z) x 4 (y) x 16 (x) voxels, a wavefront 16 x-voxels of 4 rows of one plane and then the next three planes: the source
-// footprint of a workgroup is a small rotated box that lives in L1 / L2 whatever the matrix, stores are 64-byte segments.
+// footprint of a workgroup is a small rotated box whatever the matrix — a few thousand voxels, staged in LDS once per block
+// (through load_clean), so every tap is an LDS read; stores are 64-byte segments.
 // The per-voxel arithmetic is sample_tile's, branch for branch (Q32.32 + lerp8 for linear with an edge clamp, the generic float64
 // path otherwise): results are bit-identical to the tile kernel's.
 constexpr int GX = 16, GY = 4, GZL = 4, GK = 4;  // lanes along x, y, z and planes per lane: block = GX x GY x (GZL * GK)
 template <typename TIN, int INTERP, int BOUNDARY>
 __global__ __launch_bounds__(256) void affine_gather_kernel(const TIN* __restrict__ in, float* __restrict__ out, AffineParams p,
                                                             int nbx, int nby, int nblocks, int per_xcd) {
+    extern __shared__ __attribute__((aligned(16))) float gtile[];
+    __shared__ int gorg[3], gext[3];
     const int b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // every XCD walks its own contiguous run of blocks (x fastest)
     if ((int)(blockIdx.x >> 3) >= per_xcd || b >= nblocks) return;
     const int bz = b / (nbx * nby), rem = b - bz * (nbx * nby), byi = rem / nbx, bxi = rem - byi * nbx;
     const int t = threadIdx.x;
     const int ox = bxi * GX + (t & (GX - 1)), oy = byi * GY + ((t >> 4) & (GY - 1)), ozb = bz * (GZL * GK) + (t >> 6) * GK;
-    if (ox >= p.Xo || oy >= p.Yo) return;
     const size_t sY = (size_t)p.Xi, sZ = (size_t)p.Yi * p.Xi;
-    auto fetch = [&](int iz, int iy, int ix) -> float { return load_clean(in + (size_t)iz * sZ + (size_t)iy * sY + ix); };
+    // The block's source box (compute_box's bound on the block's own extents), staged in LDS through load_clean when it fits
+    // the launch's capacity: a compact block's box is a few thousand voxels at any angle, so every tap comes from LDS and each
+    // source voxel is fetched once per block instead of once per tap.
+    if (t < 3) {
+        const int a = t, oz0 = bz * (GZL * GK), oy0 = byi * GY, ox0 = bxi * GX;
+        const int z1 = min(oz0 + GZL * GK, p.Zo) - 1, y1 = min(oy0 + GY, p.Yo) - 1, x1 = min(ox0 + GX, p.Xo) - 1;
+        const double base = p.m[4 * a] * (double)(oz0 + p.cz) + p.m[4 * a + 1] * (double)(oy0 + p.cy) +
+                            p.m[4 * a + 2] * (double)(ox0 + p.cx) + p.m[4 * a + 3];
+        const double ez = p.m[4 * a] * (double)(z1 - oz0), ey = p.m[4 * a + 1] * (double)(y1 - oy0), ex = p.m[4 * a + 2] * (double)(x1 - ox0);
+        double lo = base + fmin(ez, 0.0) + fmin(ey, 0.0) + fmin(ex, 0.0);
+        double hi = base + fmax(ez, 0.0) + fmax(ey, 0.0) + fmax(ex, 0.0);
+        const double slack = 1e-9 * (fabs(lo) + fabs(hi) + 1.0);
+        lo -= slack;
+        hi += slack;
+        const int n = a == 0 ? p.Zi : (a == 1 ? p.Yi : p.Xi);
+        const double l = fmax(floor(lo), 0.0), h = fmin(floor(hi) + 1.0, (double)(n - 1));
+        gorg[a] = (int)l;
+        gext[a] = (h >= l) ? (int)(h - l) + 1 : 0;
+    }
+    __syncthreads();
+    const int gz0 = gorg[0], gy0 = gorg[1], gx0 = gorg[2], gez = gext[0], gey = gext[1], gex = gext[2];
+    const long gbox = (long)gez * gey * gex;
+    const bool staged = gbox > 0 && gbox <= (long)p.lds_floats;
+    if (staged) {
+        const unsigned nb = (unsigned)gbox, uex = (unsigned)gex, uey = (unsigned)gey;
+        for (unsigned i = t; i < nb; i += 256) {
+            const unsigned r = i / uex, x = i - r * uex, z = r / uey, y = r - z * uey;
+            gtile[i] = load_clean(in + (size_t)(gz0 + (int)z) * sZ + (size_t)(gy0 + (int)y) * sY + (gx0 + (int)x));
+        }
+        __syncthreads();
+    }
+    if (ox >= p.Xo || oy >= p.Yo) return;
+    auto fetch = [&](int iz, int iy, int ix) -> float {
+        if (staged) return gtile[((iz - gz0) * gey + (iy - gy0)) * gex + (ix - gx0)];  // cleaned when it was staged
+        return load_clean(in + (size_t)iz * sZ + (size_t)iy * sY + ix);
+    };
     const int dims[3] = {p.Zi, p.Yi, p.Xi};
     if (INTERP == BH_INTERP_LINEAR && BOUNDARY != BH_BOUNDARY_ZEROS) {
         // the tile kernel's linear path for tiles that are not interior, voxel for voxel: Q32.32 coordinates (exact integer
@@ -611,8 +648,22 @@ static int launch_affine_gather(bh_ctx* ctx, const TIN* in, float* out, const Af
     BH_REQUIRE(nblocks < (1ll << 31) - 8, "affine output too large");
     const int per_xcd = (int)ceil_div(nblocks, (int64_t)8);
     const int grid = per_xcd * 8;
+    // LDS for the source box of a full block (the bound of bh_affine for the tile kernel, on the block's extents), 48 KiB at
+    // most (three workgroups per CU); blocks whose box is larger gather from global memory
+    AffineParams q = p;
+    {
+        const int T[3] = {GZL * GK, GY, GX};
+        double nb = 1.0;
+        for (int a = 0; a < 3; ++a) {
+            double span = 0.0;
+            for (int j = 0; j < 3; ++j) span += std::fabs(p.m[4 * a + j]) * (double)(T[j] - 1);
+            nb *= std::floor(span * (1.0 + 1e-6)) + 4.0;
+        }
+        q.lds_floats = nb < 12288.0 ? (int)nb : 12288;
+    }
     auto run = [&](auto kern) -> int {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, ctx->stream, in, out, p, (int)nbx, (int)nby, (int)nblocks, per_xcd);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), (size_t)q.lds_floats * sizeof(float), ctx->stream, in, out, q, (int)nbx, (int)nby,
+                           (int)nblocks, per_xcd);
         BH_CHECK_HIP(hipGetLastError());
         return BH_OK;
     };
@@ -710,9 +761,9 @@ extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, 
         p.lds_floats = nb < (double)cap ? (int)nb : cap;
         // The tile kernel stages every tile whose own box fits and gathers for the others, which it does well as long as a
         // row of 64 x-voxels stays within a few source planes.  The compact-block kernel takes over when a full tile's box
-        // does not fit AND the tile's x extent crosses 20 planes or more (|m_zx| * 63: 20 degrees about y; measured per angle
-        // and axis by tools/affine_angle_sweep.py — below that the tile kernel is the faster one, z-y coupling never needs it).
-        const double zx_min = getenv("BH_AFFINE_GATHER_ZX") ? atof(getenv("BH_AFFINE_GATHER_ZX")) : 20.0;
+        // does not fit AND the tile's x extent crosses 4 planes or more (|m_zx| * 63: ~4 degrees about y; measured per angle
+        // and axis by tools/affine_angle_sweep.py — below that, and for z-y coupling at any angle, the tile kernel is faster).
+        const double zx_min = getenv("BH_AFFINE_GATHER_ZX") ? atof(getenv("BH_AFFINE_GATHER_ZX")) : 4.0;
         box_fits = nb < (double)cap || std::fabs(matrix[2]) * (double)(ATX - 1) < zx_min;
     }
     p.zslot = 0;
