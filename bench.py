@@ -178,7 +178,7 @@ def ops_suite(vol, psf, dev, ctx):
     M45[:3, :3] = R45
     M45[:3, 3] = c0 - R45 @ c0
     rec("affine_linear_f32_rot45_about_y", lambda: affine_device(vol, M45, shape, "linear"), _lib.T_AFFINE, 8 * V,
-        "45 deg about the y axis through the centre: z couples strongly with x — compact 16 x 4 x 16 output blocks, their source "
+        "45 deg about the y axis through the centre: z couples strongly with x — compact 8 x 8 x 16 output blocks, their source "
         "box staged in LDS (affine_gather_kernel; the tile kernel's fallback took 59 ms)")
     x = torch.empty_like(vol)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

@@ -480,12 +480,18 @@ __global__ __launch_bounds__(A_NT) void affine_kernel(const TIN* __restrict__ in
 // output tile no longer fits LDS, and affine_kernel's fallback — every lane of a 64-voxel x row gathering its eight taps from
 // wherever the map sends it — touches up to 64 planes per wave instruction (20 degrees about y: 33 ms, 45 degrees about an
 // oblique axis: 94 ms for an 8.6-GB volume; tools/affine_angle_sweep.py).  Here a workgroup owns a COMPACT block of the output,
-// 16 (z) x 4 (y) x 16 (x) voxels, a wavefront 16 x-voxels of 4 rows of one plane and then the next three planes: the source
+// 8 (z) x 8 (y) x 16 (x) voxels, a wavefront 16 x-voxels of 4 rows of one plane and then the next three planes: the source
 // footprint of a workgroup is a small rotated box whatever the matrix — a few thousand voxels, staged in LDS once per block
 // (through load_clean), so every tap is an LDS read; stores are 64-byte segments.
 // The per-voxel arithmetic is sample_tile's, branch for branch (Q32.32 + lerp8 for linear with an edge clamp, the generic float64
 // path otherwise): results are bit-identical to the tile kernel's.
-constexpr int GX = 16, GY = 4, GZL = 4, GK = 4;  // lanes along x, y, z and planes per lane: block = GX x GY x (GZL * GK)
+#ifndef BH_AFFINE_GY
+#define BH_AFFINE_GY 8  // block rows: 8 (8 z x 8 y x 16 x) or 4 (16 z x 4 y x 16 x: measured 0-7 ms slower per 8.6-GB volume, e.g. 45 deg
+                        // about an oblique axis 22.4 against 15.7 ms: tools/affine_angle_sweep.py)
+#endif
+constexpr int GX = 16, GY = BH_AFFINE_GY, GZL = 256 / (GX * GY), GK = 4;  // lanes along x, y, z and planes per lane: block = GX x GY x (GZL * GK)
+constexpr int GYLOG = GY == 8 ? 3 : 2;
+static_assert(GY == 4 || GY == 8, "BH_AFFINE_GY must be 4 or 8");
 template <typename TIN, int INTERP, int BOUNDARY>
 __global__ __launch_bounds__(256) void affine_gather_kernel(const TIN* __restrict__ in, float* __restrict__ out, AffineParams p,
                                                             int nbx, int nby, int nblocks, int per_xcd) {
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(256) void affine_gather_kernel(const TIN* __restric
     if ((int)(blockIdx.x >> 3) >= per_xcd || b >= nblocks) return;
     const int bz = b / (nbx * nby), rem = b - bz * (nbx * nby), byi = rem / nbx, bxi = rem - byi * nbx;
     const int t = threadIdx.x;
-    const int ox = bxi * GX + (t & (GX - 1)), oy = byi * GY + ((t >> 4) & (GY - 1)), ozb = bz * (GZL * GK) + (t >> 6) * GK;
+    const int ox = bxi * GX + (t & (GX - 1)), oy = byi * GY + ((t >> 4) & (GY - 1)), ozb = bz * (GZL * GK) + (t >> (4 + GYLOG)) * GK;
     const size_t sY = (size_t)p.Xi, sZ = (size_t)p.Yi * p.Xi;
     // The block's source box (compute_box's bound on the block's own extents), staged in LDS through load_clean when it fits
     // the launch's capacity: a compact block's box is a few thousand voxels at any angle, so every tap comes from LDS and each

@@ -494,7 +494,7 @@ def _rotation_about(axis, angle_deg, centre):
                                         ((0, 0.2, 1.0), 60.0)])
 def test_affine_strongly_coupled_rotations(gpu, axis, angle, interp, monkeypatch):
     """Rotations that mix z with x / y by more than a few degrees: a full output tile's source box does not fit LDS and the
-    warp runs on compact 16 x 4 x 16 blocks gathering through the caches (affine_gather_kernel).  Against the oracle, against
+    warp runs on compact 8 x 8 x 16 blocks whose source box is staged in LDS (affine_gather_kernel).  Against the oracle, against
     the tile kernel's own gather fallback (BH_AFFINE_GATHER=0), for float32 and uint16 input, with a cropped launch."""
     from biahub_amd.register import apply_affine_transform
 
