@@ -264,7 +264,7 @@ def ops_suite(vol, psf, dev, ctx):
     return out
 
 
-def overlapped_units(vol_host_u16, rl, iterations, dev, ctx, n_units=8):
+def overlapped_units(vol_host_u16, rl, iterations, dev, ctx, n_units=8, n_landing=2):
     """`n_units` positions through biahub_amd.pipeline.run_overlapped: upload of unit i + 1 (pinned uint16), compute of unit i
     (prepared R-L handle: nothing in the compute leg waits on the host) and download of unit i - 1 (float32 deskewed volume
     into one of two pinned landing blocks) on three streams.  Returns ms per unit and the per-leg timeline of the measured run."""
@@ -273,12 +273,14 @@ def overlapped_units(vol_host_u16, rl, iterations, dev, ctx, n_units=8):
     from biahub_amd.device import volume_pool
     with volume_pool(dev):
         probe = fast_deskew_zyx(rl(vol_host_u16.to(dev), 0, 1e-6), **DESKEW)
-    landing = [torch.empty(probe.shape, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+    # n_landing = 1 (the N > 1 line): downloads are serial on their stream and nobody consumes the blocks here, so one pinned
+    # landing block bounds what eight ranks pin on one host (8 x (4.3 + 17) GB instead of 8 x 38)
+    landing = [torch.empty(probe.shape, dtype=torch.float32, pin_memory=True) for _ in range(n_landing)]
     del probe
     count = [0]
 
     def download(t):
-        buf = landing[count[0] % 2]
+        buf = landing[count[0] % n_landing]
         count[0] += 1
         buf.copy_(t, non_blocking=True)
         return buf
@@ -387,7 +389,7 @@ def main():
     ap.add_argument("--host-fed", choices=["auto", "on", "off"], default="auto",
                     help="after the resident measurement every rank also runs the overlapped host-fed pipeline (pinned uint16 in, "
                          "pinned float32 out) so that host-memory / PCIe contention between ranks shows in the N>1 line; auto = on for N>1")
-    ap.add_argument("--host-fed-units", type=int, default=4)
+    ap.add_argument("--host-fed-units", type=int, default=2)
     args = ap.parse_args()
 
     rank, local_rank, world = parallel.world_info()
@@ -455,22 +457,35 @@ def main():
     # pinned float32 blocks — the one thing that can break 8-GPU scaling (8 x 57 GB/s of D2H into one host) is in the line
     host_fed = None
     if args.host_fed == "on" or (args.host_fed == "auto" and world > 1):
+        # every rank runs the SAME sequence of collectives: a rank that fails locally (pinned memory, HBM) does not leave the
+        # others waiting in an all_reduce — the failure is agreed on first, then every rank skips the leg's reductions together
+        err, per_unit, steady, tl, legs = None, 0.0, 0.0, None, None
         try:
             host = torch.empty(shape, dtype=torch.uint16, pin_memory=True)
             host.copy_(vols[0].to(torch.uint16))
+        except RuntimeError as e:
+            err, host = str(e)[:200], None
+        any_failed = parallel.max_over_ranks(1.0 if err else 0.0, dev) > 0.0
+        if not any_failed:
             fence()
-            per_unit, tl, legs = overlapped_units(host, rl_prepared, args.iterations, dev, ctx, n_units=args.host_fed_units)
-            del host
+            try:
+                per_unit, tl, legs = overlapped_units(host, rl_prepared, args.iterations, dev, ctx, n_units=args.host_fed_units,
+                                                      n_landing=1 if world > 1 else 2)
+                steady = (tl[-1][5] - tl[0][5]) / (len(tl) - 1) / 1e3 if len(tl) > 1 else per_unit
+            except RuntimeError as e:
+                err = str(e)[:200]
+            any_failed = parallel.max_over_ranks(1.0 if err else 0.0, dev) > 0.0
+        del host
+        if any_failed:
+            host_fed = {"skipped": err or "another rank failed"}
+        else:
             slowest = parallel.max_over_ranks(per_unit, dev)
-            steady = (tl[-1][5] - tl[0][5]) / (len(tl) - 1) / 1e3 if len(tl) > 1 else per_unit
             steady = parallel.max_over_ranks(steady, dev)
             host_fed = {"ms_per_unit_slowest_rank": slowest * 1e3, "voxels_per_s": world * V / slowest,
                         "steady_state_ms_per_unit_slowest_rank": steady * 1e3, "steady_state_voxels_per_s": world * V / steady,
                         "units_per_rank": args.host_fed_units, "legs_while_overlapped_rank0": legs,
                         "note": "every rank: pinned uint16 H2D -> R-L + deskew -> float32 D2H into pinned blocks, three streams "
                                 "(biahub_amd.pipeline.run_overlapped); all ranks at once, max over ranks; never `value`"}
-        except RuntimeError as e:
-            host_fed = {"skipped": str(e)[:200]}
 
     if rank == 0:
         rl_iter_s = float(np.mean(rl_ms)) / 1e3

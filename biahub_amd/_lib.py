@@ -17,7 +17,7 @@ LIB_PATH = PKG / "libbhcore.so"
 BH_OK, BH_ERR_INVALID, BH_ERR_HIP, BH_ERR_NOMEM, BH_ERR_UNSUPPORTED = range(5)
 DT_U8, DT_U16, DT_F32, DT_I16 = 0, 1, 2, 3
 FILL_NONE, FILL_CONSTANT, FILL_MEAN = 0, 1, 2
-INTERP_NEAREST, INTERP_LINEAR = 0, 1
+INTERP_NEAREST, INTERP_LINEAR, INTERP_CUBIC = 0, 1, 3
 BOUNDARY_ITK, BOUNDARY_SCIPY_CONSTANT, BOUNDARY_ZEROS = 0, 1, 2
 PCC_NORM = {None: 0, "magnitude": 1, "classic": 2}
 FILTER_F32, FILTER_BF16 = 0, 1
@@ -54,6 +54,9 @@ SIGNATURES = {
     "bh_deskew_shape": (_int, [_i64, _i64, _i64, _f64, _f64, _int, _int, _f64, C.POINTER(_i64), C.POINTER(_f64)]),
     "bh_deskew": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _f64, _f64, _int, _int, _int, _f32, _vp,
                          C.POINTER(_f32)]),
+    "bh_deskew_rows": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _f64, _f64, _int, _int, _int, _f32, _vp,
+                              C.POINTER(_f32), _vp]),
+    "bh_deskew_fill_path": (_int, [_vp, C.POINTER(_int)]),
     "bh_overhang_fill": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _f32, _int, C.POINTER(_f32)]),
     "bh_overhang_fill_connectivity": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _f32, _int, _int, C.POINTER(_f32)]),
     "bh_transfer_function": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
@@ -75,6 +78,7 @@ SIGNATURES = {
     "bh_richardson_lucy_destroy": (_int, [_vp]),
     "bh_richardson_lucy_info": (_int, [_vp, C.POINTER(_i64), C.POINTER(_int), C.POINTER(_int), C.POINTER(C.c_uint64)]),
     "bh_alloc_layout": (_int, [C.POINTER(_int), C.POINTER(_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "bh_alloc_retained": (_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "bh_torch_alloc": (_vp, [C.c_size_t, _int, _vp]),
     "bh_torch_free": (None, [_vp, C.c_size_t, _int, _vp]),
     "bh_phase_cross_corr": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, C.POINTER(_f32), _vp]),
@@ -92,6 +96,7 @@ SIGNATURES = {
     "bh_average_patches": (_int, [_vp, _vp, _i64, _i64, _i64, C.POINTER(_int), _int, C.POINTER(_int), _int, _vp]),
     "bh_affine": (_int, [_vp, _vp, _int, _i64, _i64, _i64, C.POINTER(_f64), _int, _int, _f32, _vp, _i64, _i64,
                          _i64, C.POINTER(_i64)]),
+    "bh_spline_prefilter": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp]),
     "bh_crop_flip": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, C.POINTER(_i64), _i64, _i64, _i64, _int,
                             _int, _int, _vp]),
     "bh_last_elapsed_ms": (_int, [_vp, _int, C.POINTER(_f32)]),

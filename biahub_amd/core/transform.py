@@ -117,27 +117,34 @@ class Transform:
         ``backend="scipy"`` -> SciPy "constant" boundary; ``backend="ants"`` -> ITK boundary rule.
         Result dtype follows the reference: the input dtype for SciPy, float32 for ANTs.
         """
-        from ..register import affine_device
+        from ..register import affine_device, cast_like_scipy
 
         moving = np.asarray(moving)
         if moving.ndim != self._ndim:
             raise ValueError(f"Expected {self._ndim}D array, got {moving.ndim}D")
-        if self._ndim != 3:
-            raise NotImplementedError("the GPU path resamples 3-D volumes only")
         if backend not in ("scipy", "ants"):
             raise ValueError(f"Unknown backend: {backend}")
         if backend == "scipy" and mode != "constant":
             raise NotImplementedError(f"boundary mode {mode!r} is not implemented on the GPU path")
-        if order not in (0, 1):
-            raise NotImplementedError("only interpolation orders 0 and 1 are implemented on the GPU path")
-        out_shape = reference.shape if reference is not None else moving.shape
+        if order not in (0, 1, 3) or (order == 3 and backend != "scipy"):
+            raise NotImplementedError("interpolation orders 0, 1 and 3 (3: SciPy backend) are implemented on the GPU path")
+        if self._ndim == 2 and backend != "scipy":
+            raise NotImplementedError("2-D images are resampled by the SciPy backend only")
+        out_shape = tuple(reference.shape) if reference is not None else tuple(moving.shape)
         inv = np.linalg.inv(self._matrix)
+        vol = moving
+        if self._ndim == 2:  # a 2-D image is the single plane of a (1, Y, X) volume: z is the identity
+            vol = moving[None]
+            inv3 = np.eye(4)
+            inv3[1:, 1:] = inv
+            inv, out_shape = inv3, (1,) + out_shape
         boundary = _lib.BOUNDARY_SCIPY_CONSTANT if backend == "scipy" else _lib.BOUNDARY_ITK
-        out = affine_device(moving, inv, out_shape, "linear" if order == 1 else "nearestneighbor", boundary,
-                            float(cval) if backend == "scipy" else 0.0, device=device).cpu().numpy()
-        if backend == "scipy" and moving.dtype != np.float32:
-            out = out.astype(moving.dtype)
-        return out
+        interp = {0: "nearestneighbor", 1: "linear", 3: "cubic"}[order]
+        out = affine_device(vol, inv, out_shape, interp, boundary, float(cval) if backend == "scipy" else 0.0, device=device)
+        if backend == "scipy":  # SciPy writes into an array of the input's dtype: integers round and saturate
+            out = cast_like_scipy(out, moving.dtype)
+        out = out.cpu().numpy()
+        return out[0] if self._ndim == 2 else out
 
     # -- ANTs parameter packing (core/transform.py:427-495) -------------------------------
     def to_ants(self):

@@ -712,6 +712,10 @@ static int launch_affine(bh_ctx* ctx, const TIN* in, float* out, const AffinePar
 #include "affine_zwalk.inc"
 #include "affine_zoblique.inc"
 
+// spline.hip: prefilter + 64-tap gather (SciPy order 3, mode "constant")
+int affine_cubic(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, int64_t Yi, int64_t Xi, const double matrix[12], float cval,
+                 float* out, int64_t Zo, int64_t Yo, int64_t Xo, const int64_t crop_lo[3]);
+
 }  // namespace bh
 
 extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, int64_t Yi, int64_t Xi,
@@ -723,11 +727,18 @@ extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, 
     BH_REQUIRE(Zi < (1ll << 30) && Yi < (1ll << 30) && Xi < (1ll << 30) && Zo < (1ll << 30) && Yo < (1ll << 30) &&
                    Xo < (1ll << 30),
                "volume too large");
-    BH_REQUIRE(interpolation == BH_INTERP_NEAREST || interpolation == BH_INTERP_LINEAR, "unknown interpolation %d",
-               interpolation);
+    BH_REQUIRE(interpolation == BH_INTERP_NEAREST || interpolation == BH_INTERP_LINEAR || interpolation == BH_INTERP_CUBIC,
+               "unknown interpolation %d", interpolation);
     BH_REQUIRE(boundary >= BH_BOUNDARY_ITK && boundary <= BH_BOUNDARY_ZEROS, "unknown boundary %d", boundary);
+    BH_REQUIRE(interpolation != BH_INTERP_CUBIC || boundary == BH_BOUNDARY_SCIPY_CONSTANT,
+               "cubic B-spline interpolation is defined for the SciPy \"constant\" boundary only (got boundary %d)", boundary);
     for (int i = 0; i < 12; ++i) BH_REQUIRE(matrix[i] == matrix[i], "matrix contains NaN");
     BH_CHECK_HIP(hipSetDevice(ctx->device));
+    if (interpolation == BH_INTERP_CUBIC) {
+        for (int i = 0; i < 12; ++i) BH_REQUIRE(std::fabs(matrix[i]) < 1073741824.0, "matrix entry %d out of range", i);
+        ScopedTimer timer(ctx, T_AFFINE);
+        return affine_cubic(ctx, in, in_dtype, Zi, Yi, Xi, matrix, cval, out, Zo, Yo, Xo, crop_lo);
+    }
     AffineParams p;
     for (int i = 0; i < 12; ++i) {
         p.m[i] = matrix[i];

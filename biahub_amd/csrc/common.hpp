@@ -89,6 +89,7 @@ struct bh_ctx {
     std::map<std::tuple<int64_t, int64_t, int64_t>, bh::FftPlans> plans;
     std::map<std::string, bh::Scratch> scratch;
     int num_cus = 256;
+    int deskew_path = 0;     // how the last bh_deskew filled the overhang: 0 mask pipeline (or no fill), 1 one-pass (deskew_rows.inc)
     int plans_replaced = 0;  // 3-D library plans that failed their self-check and were rebuilt decomposed (context.hip)
     // Richardson-Lucy OTF cache: the OTF in "fc_otf" belongs to the PSF kept in "rl_psf_kept" (compared byte for byte on every
     // call; the hash is informational) / these shapes / this spectrum layout
@@ -138,6 +139,16 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // kept per (device, size) for the next handle of that size, bh_inverse_filter_trim() returns them to the driver (invtf.hip).
 void* filter_pool_take(int device, size_t bytes);
 void filter_pool_give(int device, size_t bytes, void* p);
+
+// Device-resident result of the overhang fill's reductions (fill.hip; the one-pass deskew of deskew.hip writes `fill` before
+// its resampling kernel starts and raises `fallback` when it meets an exact zero that geometry does not explain).
+struct FillStats {
+    double sum_all;               // sum of every voxel (zeros contribute nothing)
+    double sum_shell;             // sum over dilated & ~zero
+    unsigned long long n_masked;  // voxels in the dilated mask
+    float fill;                   // value written
+    int fallback;                 // one-pass deskew: 1 = a data-dependent zero was seen, the mask pipeline re-runs the volume
+};
 
 // |value| and flat index of a running argmax (np.argmax semantics: the FIRST occurrence of the maximum wins)
 struct ArgMax {

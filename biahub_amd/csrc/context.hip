@@ -30,7 +30,32 @@ void set_error(const char* fmt, ...) {
 // for all blocks), BH_ALLOC_VMM_MIN_MB (smallest block built this way), BH_ALLOC_POISON=1, BH_ALLOC_VMM_FREE_VA=1 (dev_free).
 struct VmmBlock {
     size_t size = 0, chunk = 0;
+    int device = 0;  // the device that owns the physical chunks: synchronised (and made current) around the unmap
     std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+// Address ranges of released blocks are RETAINED (dev_free explains why): the totals are reported by bh_alloc_layout, and once
+// more than BH_ALLOC_VMM_VA_CAP_GB (default 16384 = 16 TiB of the 128 TiB a process has) is held back, further gigabyte blocks
+// come from hipMalloc — slower passes, never a wrong result, and the address space cannot run out under a long-lived service
+// that rebuilds its workspace per plate.
+static std::atomic<unsigned long long> g_va_retained_bytes{0}, g_va_retained_ranges{0};
+static void retain_range(size_t size) {
+    g_va_retained_bytes.fetch_add(size);
+    g_va_retained_ranges.fetch_add(1);
+}
+static bool va_budget_left() {
+    static const unsigned long long cap = (unsigned long long)(getenv("BH_ALLOC_VMM_VA_CAP_GB") ? atoll(getenv("BH_ALLOC_VMM_VA_CAP_GB")) : 16384) << 30;
+    return g_va_retained_bytes.load() < cap;
+}
+struct DeviceGuard {  // makes `device` current for the scope and restores what was current before
+    int prev = -1;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) (void)hipSetDevice(device);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
 };
 // every chunk is unmapped by a call of its own, with exactly the range its hipMemMap call had (an unmap spanning several
 // mappings is not something the API promises to take apart)
@@ -66,6 +91,7 @@ static hipError_t vmm_alloc(int device, size_t bytes, size_t chunk, bool shuffle
     VmmBlock blk;
     blk.size = size;
     blk.chunk = chunk;
+    blk.device = device;
     std::vector<size_t> slot(n);
     for (size_t i = 0; i < n; ++i) slot[i] = i;
     if (shuffle) {
@@ -94,10 +120,15 @@ static hipError_t vmm_alloc(int device, size_t bytes, size_t chunk, bool shuffle
     }
     if (e != hipSuccess) {
         // slots are not mapped in address order: unmap whatever is there, chunk by chunk (errors for unmapped slots are expected)
+        (void)hipDeviceSynchronize();
         (void)vmm_unmap_all(va, blk, n);
         (void)hipGetLastError();
         for (auto h : blk.handles) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(va, size);
+        // the partly mapped range is retained like a released block's (dev_free): a retry or the hipMalloc fallback must not be
+        // handed this range again while translations of the aborted mapping may still be cached
+        static const bool free_va = getenv("BH_ALLOC_VMM_FREE_VA") && atoi(getenv("BH_ALLOC_VMM_FREE_VA")) != 0;
+        if (free_va) (void)hipMemAddressFree(va, size);
+        else retain_range(size);
         return e;
     }
     std::lock_guard<std::mutex> lk(g_vmm_mu);
@@ -145,7 +176,12 @@ static hipError_t dev_alloc_raw(int device, size_t bytes, void** out) {
     // thresholds 3 GiB / 2000 MB / 1000 MB / hipMalloc): (256,1024,1024) 43.0 / 43.0 / 46.8 / 43.1 ms, the deskewed config-4
     // volume (2.4-GB buffers) 102.6 / 101.2 / 99.2 / 102.7, (256,2048,2048) (4.4 GB) 172.4 / 167.9 / 166.3 / 172.9
     static const size_t min_bytes = (size_t)(getenv("BH_ALLOC_VMM_MIN_MB") ? atol(getenv("BH_ALLOC_VMM_MIN_MB")) : 2048) << 20;
-    if (chunk_kb > 0 && bytes >= min_bytes) {
+    if (chunk_kb > 0 && bytes >= min_bytes && !va_budget_left()) {
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true))
+            fprintf(stderr, "[bhcore] %llu GiB of address space retained by released blocks (BH_ALLOC_VMM_VA_CAP_GB): gigabyte buffers "
+                            "come from hipMalloc from here on\n", g_va_retained_bytes.load() >> 30);
+    } else if (chunk_kb > 0 && bytes >= min_bytes) {
         const hipError_t e = vmm_alloc(device, bytes, (size_t)chunk_kb << 10, shuffle, out);
         if (e == hipSuccess || e == hipErrorOutOfMemory) return e;
         fprintf(stderr, "[bhcore] virtual-memory allocation of %zu bytes failed (%s): gigabyte buffers come from hipMalloc from here on\n",
@@ -165,6 +201,7 @@ hipError_t dev_free(void* p) {
         blk = std::move(it->second);
         g_vmm.erase(it);
     }
+    DeviceGuard guard(blk.device);  // the block's own device, whatever the calling thread has current
     (void)hipDeviceSynchronize();
     hipError_t e = vmm_unmap_all(p, blk, blk.size / blk.chunk);
     for (auto h : blk.handles) {
@@ -179,6 +216,8 @@ hipError_t dev_free(void* p) {
     if (free_va) {
         const hipError_t ef = hipMemAddressFree(p, blk.size);
         if (ef != hipSuccess && e == hipSuccess) e = ef;
+    } else {
+        retain_range(blk.size);
     }
     (void)hipDeviceSynchronize();
     return e;
@@ -384,6 +423,12 @@ int bh_alloc_layout(int* chunk_kib, int* shuffled, uint64_t* live_blocks, uint64
     return BH_OK;
 }
 
+int bh_alloc_retained(uint64_t* ranges, uint64_t* bytes) {
+    if (ranges) *ranges = bh::g_va_retained_ranges.load();
+    if (bytes) *bytes = bh::g_va_retained_bytes.load();
+    return BH_OK;
+}
+
 // torch.cuda.memory.CUDAPluggableAllocator entry points: the allocator of a torch MemPool whose large blocks are laid out like
 // the library's own workspace (biahub_amd/device.py: volume_pool)
 void* bh_torch_alloc(size_t size, int device, void* stream) {
@@ -402,8 +447,8 @@ void* bh_torch_alloc(size_t size, int device, void* stream) {
 }
 void bh_torch_free(void* ptr, size_t size, int device, void* stream) {
     (void)size;
-    (void)device;
     (void)stream;
+    bh::DeviceGuard guard(device);  // hipFree / the unmap synchronise the block's device, not whatever is current
     (void)bh::dev_free(ptr);
 }
 

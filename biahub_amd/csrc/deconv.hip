@@ -445,6 +445,7 @@ static void pad_before(int64_t p, int64_t S, int* before) { *before = (int)((S -
 struct ConvPlan;
 bool fftconv_supported(int64_t Z, int64_t Y, int64_t X);
 bool fftconv_supported_ex(int64_t Z, int64_t Y, int64_t X, bool radix3);
+bool fftconv_rows_wave_private(int64_t Y, int64_t X);
 int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out);
 size_t fftconv_spectrum_elems(const ConvPlan& pl);
 int fftconv_plan_tag(const ConvPlan& pl);
@@ -653,7 +654,7 @@ static bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
 // convolution, and for the tails of the linear correlation coming out.
 static bool engine_pad_box(const int64_t N[3], const int64_t K[3], int64_t P[3]) {
     const bool radix3 = getenv("BH_FC_NORADIX3") == nullptr;
-    for (int a = 0; a < 3; ++a) {
+    for (int a = 0; a < 3; ++a) {  // (z, y before x: the row choice below looks at the box's y extent)
         // axes the engine transforms as they are wrap by themselves: powers of two, 3 * 2^k and 5 * 2^k
         auto alone = [&](int64_t n) { return fftconv_supported_ex(a == 0 ? n : 64, a == 1 ? n : 64, a == 2 ? n : 64, true); };
         const bool odd_native = (N[a] % 3 == 0 && is_pow2(N[a] / 3)) || (N[a] % 5 == 0 && is_pow2(N[a] / 5));
@@ -670,7 +671,8 @@ static bool engine_pad_box(const int64_t N[3], const int64_t K[3], int64_t P[3])
             // Rows of 1536 / 3072 voxels run the wave-private radix-3 X passes (fftconv_x3.inc) and, with them, the wrap-padded
             // iteration without a fold pass; rows of 5 * 2^k voxels still take the tile X passes, which cost ~1.6x as much per
             // voxel (158 against 98 ms on the config-4 box) — more than the 1.2x larger box.  BH_RL_X5=1: old choice.
-            const bool x3_rows = a == 2 && (p3 == 1536 || p3 == 3072) && getenv("BH_RL_X5") == nullptr;
+            // ... provided those passes are what the plan will enable for this box (its y extent, the A/B switches)
+            const bool x3_rows = a == 2 && (p3 == 1536 || p3 == 3072) && getenv("BH_RL_X5") == nullptr && fftconv_rows_wave_private(P[1], p3);
             if (p5 >= need && alone(p5) && !(x3_rows && alone(p3))) P[a] = p5;
             else if (p3 >= need && alone(p3)) P[a] = p3;
         }
@@ -800,8 +802,7 @@ static int rl_plan(int64_t pz, int64_t py, int64_t px, int64_t Z, int64_t Y, int
     const bool hipfft_forced = be != nullptr && strcmp(be, "hipfft") == 0;
     if (!hipfft_forced && !nopad && !(force && force[0] == '0') && engine_pad_box(N, K, PE)) {
         // (round 3: rows the wave-private X passes take, Y unpadded, run the 8-pass wrap-padded iteration at ~6 Gvox/s)
-        const bool wrap_rows = (PE[2] == 512 || PE[2] == 1024 || PE[2] == 2048 || PE[2] == 1536 || PE[2] == 3072) && PE[1] == N[1] &&
-                               K[2] <= 256 && getenv("BH_RL_NOWRAP") == nullptr;
+        const bool wrap_rows = fftconv_rows_wave_private(PE[1], PE[2]) && PE[1] == N[1] && K[2] <= 256 && getenv("BH_RL_NOWRAP") == nullptr;
         const double cost_engine = (double)PE[0] * PE[1] * PE[2] / (wrap_rows ? 6.0 : 3.9), cost_lib = (double)P[0] * P[1] * P[2] / 1.9;
         if ((force && force[0] == '1') || cost_engine < cost_lib) {
             for (int a = 0; a < 3; ++a) box[a] = PE[a];

@@ -39,6 +39,13 @@ struct DeskewGeom {
     uint32_t* mask0;  // [Za*X][W32] one bit per output voxel (1 = exact zero)
     double* psum;     // per-block partial sums of the outputs
     int W32;          // mask words per output row (even)
+    const int* enable;  // FILL kernels, may be null: device flag, 0 = nothing to do (the conditional pass behind the one-pass path)
+    // one-pass fill (deskew_pers_kernel<NK, 2>): the geometry's zero pattern and its dilation, one bit per (a, x'), WB words per a;
+    // the fill value (already final) and the fallback flag live in *st
+    const uint32_t* gbits;
+    const uint32_t* dgbits;
+    int WB;
+    FillStats* st;
 };
 
 // The reference's sample position along the scan axis, in its float32 operation order:
@@ -98,6 +105,7 @@ __global__ __launch_bounds__(NT) void deskew_kernel(const TIN* __restrict__ in, 
     constexpr int XC = 64 * J;
     constexpr int PITCH = TX + 1;
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [N][ZC][PITCH]
+    if (FILL && g.enable != nullptr && *g.enable == 0) return;
     const int tid = threadIdx.x;
     const int xt0 = blockIdx.x * TX;
     const int xo0 = blockIdx.y * XC;
@@ -337,10 +345,24 @@ __global__ __launch_bounds__(NT) void deskew_kernel(const TIN* __restrict__ in, 
 // A lane owns FOUR CONSECUTIVE x' (one 16-byte store per row instead of four 4-byte ones); their taps fall into at most three
 // consecutive z rows per averaged slice, which are read once and selected per output — 3 N LDS reads per row instead of 8 N.
 // Same float32 sample positions, same per-output operation order as deskew_kernel: bit-identical results.
-template <int NK, bool FILL>
+//
+// FILLM = 0: no fill.  1: the fused prologue of the mask pipeline (zero-mask bits + block sums, exact zeros not stored; fill.hip
+// finishes).  2: ONE-PASS fill — the fill value is final before this kernel starts (*g.st), and WHOLE rows are written:
+//   * which outputs are exact zeros is geometry: (a, x') whose N taps all fall outside the scanned range — the same for every
+//     row of a plane, so the zero mask and its radius-3 dilation are two small bit planes (g.gbits, g.dgbits: deskew_rows.inc);
+//     a sampler lane replaces the outputs inside the dilated pattern by the fill value and stores its 16 bytes as usual;
+//   * tiles whose whole window lies outside the volume are pure fill: the two LOADER wavefronts write them, a quota of rows per
+//     tile interval in front of the next tile's LDS-DMA (they are otherwise idle, and the samplers are bound by their own
+//     instruction stream, so the 9 GB of overhang stores ride beside the sampling instead of behind it);
+//   * an output that is exactly zero although geometry does not say so (a zero run in the data) would have been part of the
+//     reference's mask: the lane raises g.st->fallback and the conditional mask pipeline queued behind this kernel redoes the
+//     volume (bh_deskew).  Camera data, flat-fielded or deconvolved volumes have no such voxels.
+template <int NK, int FILLM>
 __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restrict__ in, float* __restrict__ out, DeskewGeom g,
                                                           int ntx, int nxc) {
 #pragma clang fp contract(off)
+    constexpr bool FILL = FILLM == 1, ROWS = FILLM == 2;
+    if (FILL && g.enable != nullptr && *g.enable == 0) return;
 #ifndef BH_DK_PROBE
 #define BH_DK_PROBE 0  // timing probes with WRONG results: bit 0 = no output stores, bit 1 = no LDS reads in the sampler, bit 2 = no LDS-DMA
 #endif
@@ -392,7 +414,7 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
     };
     // an overhang tile: exact zeros everywhere
     auto zero_tile = [&](const Tile& q) {
-        if (loader) return;
+        if (loader || ROWS) return;
         for (int xl = wave; xl < TX; xl += NWV) {
             const size_t orow_i = (size_t)q.a * g.X + (g.X - 1 - (q.xt0 + xl));
             if (FILL) {
@@ -462,17 +484,58 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
         return t;
     };
 
+    // ROWS: the loaders' own walk over the overhang tiles of this workgroup's range (both loaders keep the same cursor and take
+    // alternate rows): `emit(quota)` writes up to `quota` rows of 256 x' each — one unaligned 16-byte store per lane
+    const float fillv = ROWS ? g.st->fill : 0.0f;
+    long zt = t_begin - 1;
+    int zrow = TX;
+    Tile zq = {};
+    auto emit = [&](int quota) {
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        for (int n = 0; n < quota; ++n) {
+            if (zrow >= TX) {
+                for (++zt; zt < t_end; ++zt) {
+                    zq = tile_of(zt);
+                    if (zq.zero) break;
+                }
+                if (zt >= t_end) {
+                    zt = t_end;  // stays exhausted
+                    return;
+                }
+                zrow = lwave;
+            }
+            const size_t orow_i = (size_t)zq.a * g.X + (g.X - 1 - (zq.xt0 + zrow));
+            float* orow = out + orow_i * g.Xp;
+            const int xo = zq.xo0 + 4 * lane;
+            if (xo + 3 < g.Xp) {
+                *reinterpret_cast<f4u*>(orow + xo) = f4u{fillv, fillv, fillv, fillv};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (xo + j < g.Xp) orow[xo + j] = fillv;
+            }
+            zrow += NLD;
+        }
+    };
+#ifndef BH_DK_QUOTA
+#define BH_DK_QUOTA 48  // rows per loader and tile interval (the overhang is ~1.2 tiles = 75 rows per sampled tile at config 2)
+#endif
+    static_assert(!ROWS || SPLIT, "the one-pass fill needs loader wavefronts");
+    float zmin = 1.0f;  // ROWS: smallest |output| outside the geometric zero pattern seen by this lane
+
     long cur = advance(t_begin - 1);
     int b = 0;
     if (cur < t_end) stage(tile_of(cur), 0);
     int plan_a = -1, plan_xo0 = -1;
     int i0[N][4];
     float w0[N][4], w1[N][4];
+    unsigned gnib = 0u, dgnib = 0u;  // ROWS: this lane's four bits of the geometric zero pattern and of its dilation
     while (cur < t_end) {
         const Tile q = tile_of(cur);
         if (!SPLIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // the loaders' DMA of this tile has landed; the samplers have finished with the other buffer
         const long nxt = advance(cur);
+        if (ROWS && loader) emit(BH_DK_QUOTA);
         if (nxt < t_end) stage(tile_of(nxt), b ^ 1);
         if (loader) {
             cur = nxt;
@@ -500,7 +563,14 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
                     i0[k][j] = k * kstride + rel * PITCH;
                 }
             }
+            if (ROWS) {  // four consecutive x' from a multiple of 4: one nibble of one word
+                const int wi = min(xb4, g.Xp - 1) >> 5, sh = xb4 & 31;
+                gnib = xb4 < g.Xp ? (g.gbits[(size_t)q.a * g.WB + wi] >> sh) & 15u : 15u;
+                dgnib = xb4 < g.Xp ? (g.dgbits[(size_t)q.a * g.WB + wi] >> sh) & 15u : 15u;
+            }
         }
+        // (wave-uniform) most tiles of the scanned range lie clear of the pattern: no select per output there
+        const bool edge_tile = ROWS && __ballot(dgnib != 0u) != 0ull;
         {
             // the taps of the NEXT row are requested before this row is computed and stored (BH_DK_PIPE=0: A/B switch): the
             // sampler's LDS latency is otherwise paid once per row — SQ counters put 38 % of its cycles in waits
@@ -535,7 +605,26 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
 #pragma unroll
                 for (int j = 0; j < 4; ++j) val[j] = (N > 1) ? div_small(acc[j], fN, rN) : acc[j];
                 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-                if (FILL) {
+                if (ROWS) {
+                    if (edge_tile) {
+                        // outside the geometric pattern an exact zero is a data zero; inside the dilated one the fill value goes out
+                        zmin = fminf(zmin, fminf(fminf((gnib & 1u) ? 1.0f : fabsf(val[0]), (gnib & 2u) ? 1.0f : fabsf(val[1])),
+                                                 fminf((gnib & 4u) ? 1.0f : fabsf(val[2]), (gnib & 8u) ? 1.0f : fabsf(val[3]))));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) val[j] = (dgnib >> j & 1u) ? fillv : val[j];
+                    } else {
+                        zmin = fminf(zmin, fminf(fminf(fabsf(val[0]), fabsf(val[1])), fminf(fabsf(val[2]), fabsf(val[3]))));
+                    }
+                    if (BH_DK_PROBE & 1) {
+                        if (val[0] + val[1] + val[2] + val[3] == -12345.0f) orow[xb4] = 1.0f;
+                    } else if (xb4 + 3 < g.Xp) {
+                        *reinterpret_cast<f4u*>(orow + xb4) = f4u{val[0], val[1], val[2], val[3]};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (xb4 + j < g.Xp) orow[xb4 + j] = val[j];
+                    }
+                } else if (FILL) {
                     // zero-mask bits of the 256 outputs: word w (x' = xo0 + 64 w .. + 63) is the nibbles of lanes 16 w .. 16 w + 15,
                     // lane 16 w + i contributing bits 4 i .. 4 i + 3.  A DPP row is those 16 lanes: each lane places its nibble
                     // in the low (i < 8) or high half, four row_shr steps OR the row together, lane 16 w + 15 writes the word.
@@ -597,6 +686,10 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
         cur = nxt;
         b ^= 1;
     }
+    if (ROWS) {
+        if (loader) emit(1 << 30);  // what is left of the overhang tiles
+        if (!loader && __ballot(zmin == 0.0f) != 0ull && lane == 0) atomicOr(&g.st->fallback, 1);
+    }
     if (FILL) {
         __shared__ double wsum[NT / 64];
 #pragma unroll
@@ -610,6 +703,8 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
         }
     }
 }
+
+#include "deskew_rows.inc"
 
 static int deskew_geometry(int64_t Z, int64_t Y, int64_t X, double angle, double ratio, int keep_overhang,
                            int n, DeskewGeom* g, int64_t out_shape[3]) {
@@ -722,10 +817,69 @@ int launch_deskew_pers<float>(bh_ctx* ctx, const float* in, float* out, DeskewGe
     };
     *taken = true;
     switch (g.N) {
-        case 1: return fill ? run(deskew_pers_kernel<1, true>) : run(deskew_pers_kernel<1, false>);
-        case 2: return fill ? run(deskew_pers_kernel<2, true>) : run(deskew_pers_kernel<2, false>);
-        case 3: return fill ? run(deskew_pers_kernel<3, true>) : run(deskew_pers_kernel<3, false>);
-        default: return fill ? run(deskew_pers_kernel<4, true>) : run(deskew_pers_kernel<4, false>);
+        case 1: return fill ? run(deskew_pers_kernel<1, 1>) : run(deskew_pers_kernel<1, 0>);
+        case 2: return fill ? run(deskew_pers_kernel<2, 1>) : run(deskew_pers_kernel<2, 0>);
+        case 3: return fill ? run(deskew_pers_kernel<3, 1>) : run(deskew_pers_kernel<3, 0>);
+        default: return fill ? run(deskew_pers_kernel<4, 1>) : run(deskew_pers_kernel<4, 0>);
+    }
+}
+
+// The one-pass fill (deskew_rows.inc + deskew_pers_kernel<NK, 2>): float32 volumes the persistent kernel takes.  *taken stays false
+// when the shape does not qualify (the mask pipeline then runs unconditionally).  row_sums: optional float64 [Z * Y] row sums of
+// `in` on the device (an operator that has just produced `in` can hand them over), else they are reduced here.
+static int launch_deskew_rows(bh_ctx* ctx, const float* in, float* out, DeskewGeom g, int fill_mode, float fill_value,
+                              const double* row_sums, FillStats* st, bool* taken) {
+    *taken = false;
+    if (getenv("BH_DESKEW_ONEPASS") && atoi(getenv("BH_DESKEW_ONEPASS")) == 0) return BH_OK;
+    if (g.N < 1 || g.N > 4 || (g.X % 64) != 0) return BH_OK;
+    constexpr int XC = 256, TX = 64;
+    g.XC = XC;
+    g.ZC = std::max(max_window(g, XC), 3);
+    g.ZS = TX + 1;
+    const size_t lds = 2 * (size_t)g.N * g.ZC * (TX + 1) * sizeof(float);
+    if (lds + 256 > 160 * 1024) return BH_OK;
+    const int ntx = g.X / TX, nxc = (int)ceil_div(g.Xp, XC);
+    const long ntiles = (long)g.Za * nxc * ntx;
+    const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
+    hipStream_t s = ctx->stream;
+    const int WB = (int)ceil_div(g.Xp, 32);
+    uint32_t *gb, *dgb;
+    double* psum;
+    unsigned long long* pcnt;
+    BH_TRY(get_scratch(ctx, "dk_gbits", (size_t)g.Za * WB * 4, (void**)&gb));
+    BH_TRY(get_scratch(ctx, "dk_dgbits", (size_t)g.Za * WB * 4, (void**)&dgb));
+    BH_TRY(get_scratch(ctx, "dk_psum", (size_t)g.Za * sizeof(double), (void**)&psum));
+    BH_TRY(get_scratch(ctx, "dk_pcnt", (size_t)g.Za * sizeof(unsigned long long), (void**)&pcnt));
+    const int nw = g.Za * WB;
+    hipLaunchKernelGGL(rows::geom_bits_kernel<0>, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, s, g, gb, WB);
+    hipLaunchKernelGGL(rows::dilate_bits_kernel, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, s, gb, dgb, g.Za, g.Xp, WB, 3);
+    if (fill_mode == BH_FILL_MEAN) {
+        if (row_sums == nullptr) {
+            double* R;
+            BH_TRY(get_scratch(ctx, "dk_rowsums", (size_t)g.Z * g.Y * sizeof(double), (void**)&R));
+            hipLaunchKernelGGL(rows::row_sums_kernel<float>, dim3((unsigned)(ctx->num_cus * 8)), dim3(256), 0, s, in, R, (long)g.Z * g.Y, g.X);
+            row_sums = R;
+        }
+        hipLaunchKernelGGL(rows::mean_partial_kernel, dim3((unsigned)g.Za), dim3(256), 0, s, g, dgb, WB, row_sums, psum, pcnt);
+    }
+    hipLaunchKernelGGL(rows::mean_final_kernel, dim3(1), dim3(256), 0, s, psum, pcnt, g.Za, g.N, (long)g.X,
+                       (long)g.Za * g.X * g.Xp, fill_mode, fill_value, st);
+    g.gbits = gb;
+    g.dgbits = dgb;
+    g.WB = WB;
+    g.st = st;
+    auto run = [&](auto kern) -> int {
+        BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, in, out, g, ntx, nxc);
+        BH_CHECK_HIP(hipGetLastError());
+        return BH_OK;
+    };
+    *taken = true;
+    switch (g.N) {
+        case 1: return run(deskew_pers_kernel<1, 2>);
+        case 2: return run(deskew_pers_kernel<2, 2>);
+        case 3: return run(deskew_pers_kernel<3, 2>);
+        default: return run(deskew_pers_kernel<4, 2>);
     }
 }
 
@@ -761,7 +915,7 @@ static int launch_deskew(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g, b
 }
 
 int fill_overhang_impl(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X, int fill_mode,
-                       float fill_value, int iterations, float* mean_out, int fused_partials, int connectivity);
+                       float fill_value, int iterations, float* mean_out, int fused_partials, int connectivity, const int* enable);
 int fill_mask_buffers(bh_ctx* ctx, int64_t rows, int64_t X, uint32_t** m0, int* W32);
 
 }  // namespace bh
@@ -801,6 +955,13 @@ int bh_deskew_shape(int64_t Z, int64_t Y, int64_t X, double ls_angle_deg, double
 int bh_deskew(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, int64_t X, double ls_angle_deg,
               double px_to_scan_ratio, int keep_overhang, int average_n_slices, int fill_mode, float fill_value,
               float* out, float* mean_out) {
+    return bh_deskew_rows(ctx, in, in_dtype, Z, Y, X, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices, fill_mode,
+                          fill_value, out, mean_out, nullptr);
+}
+
+int bh_deskew_rows(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, int64_t X, double ls_angle_deg,
+                   double px_to_scan_ratio, int keep_overhang, int average_n_slices, int fill_mode, float fill_value,
+                   float* out, float* mean_out, const double* row_sums) {
     BH_REQUIRE(ctx != nullptr && in != nullptr && out != nullptr, "NULL argument");
     BH_REQUIRE(Z >= 2, "deskew needs at least 2 scan slices, got Z=%lld", (long long)Z);
     BH_REQUIRE(Z < (1 << 24) && Y < (1 << 24) && X < (1ll << 31), "volume too large for float32 coordinates");
@@ -813,8 +974,24 @@ int bh_deskew(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, i
     // reference :538 — fill only when keep_overhang and (fill == "mean" or fill != 0)
     const bool do_fill = keep_overhang && (fill_mode == BH_FILL_MEAN || (fill_mode == BH_FILL_CONSTANT && fill_value != 0.0f));
     int nblocks = 0;
+    g.enable = nullptr;
+    g.gbits = g.dgbits = nullptr;
+    g.WB = 0;
+    g.st = nullptr;
     if (do_fill) BH_TRY(bh::fill_mask_buffers(ctx, os[0] * os[1], os[2], &g.mask0, &g.W32));
-    {
+    // One-pass fill (float32): the fill value from row sums of the input, whole rows written by the resampling kernel.  The mask
+    // pipeline is queued behind it CONDITIONALLY (a device flag the kernel raises when it meets an exact zero that geometry
+    // does not explain): every kernel of it returns at once otherwise.
+    bool onepass = false;
+    bh::FillStats* st = nullptr;
+    if (do_fill && in_dtype == BH_DT_F32) {
+        BH_TRY(bh::get_scratch(ctx, "fill_stats", sizeof(bh::FillStats), (void**)&st));
+        bh::ScopedTimer t(ctx, bh::T_DESKEW);
+        BH_TRY(bh::launch_deskew_rows(ctx, (const float*)in, out, g, fill_mode, fill_value, row_sums, st, &onepass));
+    }
+    if (onepass) g.enable = &st->fallback;
+    ctx->deskew_path = onepass ? 1 : 0;
+    if (!onepass) {
         bh::ScopedTimer t(ctx, bh::T_DESKEW);
         switch (in_dtype) {
             case BH_DT_F32: BH_TRY(bh::launch_deskew(ctx, (const float*)in, out, g, do_fill, &nblocks)); break;
@@ -823,13 +1000,31 @@ int bh_deskew(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, i
             case BH_DT_I16: BH_TRY(bh::launch_deskew(ctx, (const int16_t*)in, out, g, do_fill, &nblocks)); break;
             default: BH_REQUIRE(false, "unsupported input dtype code %d", in_dtype);
         }
+        if (do_fill) {
+            // the deskew kernel already produced the zero mask and the block sums (and skipped storing zeros)
+            BH_TRY(bh::fill_overhang_impl(ctx, out, os[0], os[1], os[2], fill_mode, fill_value, 3, mean_out, nblocks, 26, nullptr));
+        } else if (mean_out) {
+            *mean_out = 0.0f;
+        }
+    } else {
+        // T_FILL times the conditional pass: a dozen launches that return at once unless the flag is up
+        bh::ScopedTimer t(ctx, bh::T_FILL);
+        BH_TRY(bh::launch_deskew(ctx, (const float*)in, out, g, true, &nblocks));
+        BH_TRY(bh::fill_overhang_impl(ctx, out, os[0], os[1], os[2], fill_mode, fill_value, 3, mean_out, nblocks, 26, g.enable));
     }
-    if (do_fill) {
-        // the deskew kernel already produced the zero mask and the block sums (and skipped storing zeros)
-        BH_TRY(bh::fill_overhang_impl(ctx, out, os[0], os[1], os[2], fill_mode, fill_value, 3, mean_out, nblocks, 26));
-    } else if (mean_out) {
-        *mean_out = 0.0f;
-    }
+    return BH_OK;
+}
+
+int bh_deskew_fill_path(bh_ctx* ctx, int* path) {
+    BH_REQUIRE(ctx != nullptr && path != nullptr, "NULL argument");
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    auto it = ctx->scratch.find("fill_stats");
+    *path = 0;
+    if (ctx->deskew_path == 0 || it == ctx->scratch.end() || it->second.ptr == nullptr) return BH_OK;
+    bh::FillStats h;
+    BH_CHECK_HIP(hipMemcpyAsync(&h, it->second.ptr, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    BH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *path = h.fallback ? 2 : 1;
     return BH_OK;
 }
 

@@ -909,12 +909,19 @@ static int upload(const std::vector<cf>& h, cf** dptr) {
     return BH_OK;
 }
 
+// THE predicate for "rows of X voxels (Y of them per plane) run the wave-private X passes": what fftconv_plan enables, and what
+// the box chooser (engine_pad_box) and the back-end cost model (rl_plan) of deconv.hip assume when they prefer rows of
+// 1536 / 3072 voxels or price a wrap-padded iteration.
+// BH_FC_XW=0 keeps the tile-based X passes for every shape (A/B switch, read per call: plans of both kinds can coexist)
+// rows of 512 / 1024 / 2048 voxels: fftconv_xw.inc; of 1536 / 3072: fftconv_x3.inc (BH_FC_X3=0 keeps those on the tile kernels)
+bool fftconv_rows_wave_private(int64_t Y, int64_t X) {
+    const bool x3_rows = (X == 1536 || X == 3072) && !(getenv("BH_FC_X3") && atoi(getenv("BH_FC_X3")) == 0);
+    return !(getenv("BH_FC_XW") && atoi(getenv("BH_FC_XW")) == 0) && (X == 512 || X == 1024 || X == 2048 || x3_rows) && ((Y / 2) % 4) == 0;
+}
+
 int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
     std::lock_guard<std::mutex> lock(g_plans_mu);
-    // BH_FC_XW=0 keeps the tile-based X passes for every shape (A/B switch, read per call: plans of both kinds can coexist)
-    // rows of 512 / 1024 / 2048 voxels: fftconv_xw.inc; of 1536 / 3072: fftconv_x3.inc (BH_FC_X3=0 keeps those on the tile kernels)
-    const bool x3_rows = (X == 1536 || X == 3072) && !(getenv("BH_FC_X3") && atoi(getenv("BH_FC_X3")) == 0);
-    const bool xw_on = !(getenv("BH_FC_XW") && atoi(getenv("BH_FC_XW")) == 0) && (X == 512 || X == 1024 || X == 2048 || x3_rows) && ((Y / 2) % 4) == 0;
+    const bool xw_on = fftconv_rows_wave_private(Y, X);
     auto key = std::make_tuple(ctx->device * 2 + (xw_on ? 1 : 0), Z, Y, X);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) {
@@ -1096,7 +1103,8 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
     }
     // 512-point Z passes with a spectral product: radix-8 register stages (BH_FC_COLZ=0 keeps the radix-4 LDS steps: A/B switch)
     if (zaxis && pl.colz && p.N == colz::N && (mode == COL_CONV || mode == COL_CORR || mode == COL_FILTER || mode == COL_CONV16 || mode == COL_PCC) &&
-        !(getenv("BH_FC_COLZ") && atoi(getenv("BH_FC_COLZ")) == 0)) {
+        !(getenv("BH_FC_COLZ") && atoi(getenv("BH_FC_COLZ")) == 0) &&
+        p.row_stride * 8 * 64 < (1ll << 32)) {  // colz_kernel's lanes address their rows by 32-bit offsets from scalar row pointers
         p.W = colz::W;
         p.tw = pl.colz;
         p.ncoltiles = (int)ceil_div(p.XP, p.W);

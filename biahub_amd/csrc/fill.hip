@@ -12,13 +12,10 @@
 
 namespace bh {
 
-struct FillStats {       // device-resident
-    double sum_all;      // sum of every voxel (zeros contribute nothing)
-    double sum_shell;    // sum over dilated & ~zero
-    unsigned long long n_masked;  // voxels in the dilated mask
-    float fill;          // value written
-    float pad;
-};
+// `enable` (may be null): a device flag; 0 = this launch has nothing to do.  The one-pass deskew (deskew.hip) queues the mask
+// pipeline behind itself unconditionally and raises the flag only when it met a zero that geometry does not explain.
+#define BH_FILL_ENABLED(enable) \
+    if ((enable) != nullptr && *(enable) == 0) return
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -62,7 +59,8 @@ __global__ __launch_bounds__(256) void mask0_kernel(const float* __restrict__ da
 
 // dilate along x inside each row of W32 words by radius r (< 32)
 __global__ void dilate_x_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int64_t nwords, int W32,
-                                int r) {
+                                int r, const int* __restrict__ enable) {
+    BH_FILL_ENABLED(enable);
     const unsigned int nw = (unsigned int)nwords;  // host: nwords < 2^32 (64-bit divisions are software loops on this part)
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += gridDim.x * blockDim.x) {
         const int wi = (int)(i % (unsigned int)W32);
@@ -80,7 +78,8 @@ __global__ void dilate_x_kernel(const uint32_t* __restrict__ src, uint32_t* __re
 // division per pair instead of two 64-bit ones per word (software loops on this part) — 0.79 -> 0.4 ms per pass on the
 // deskewed config-2 mask (134 M words).
 __global__ void dilate_outer_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int64_t nwords,
-                                    int64_t stride, int len, int r) {
+                                    int64_t stride, int len, int r, const int* __restrict__ enable) {
+    BH_FILL_ENABLED(enable);
     const uint2* __restrict__ s2 = reinterpret_cast<const uint2*>(src);
     uint2* __restrict__ d2 = reinterpret_cast<uint2*>(dst);
     const unsigned int np = (unsigned int)(nwords >> 1), st2 = (unsigned int)(stride >> 1);  // host: nwords < 2^32
@@ -141,7 +140,8 @@ __global__ void dilate_cross_kernel(const uint32_t* __restrict__ src, uint32_t* 
 __global__ __launch_bounds__(256) void shell_kernel(const float* __restrict__ data, const uint32_t* __restrict__ m0,
                                                     const uint32_t* __restrict__ md, double* __restrict__ psum,
                                                     unsigned long long* __restrict__ pcnt, int64_t nwords, int X,
-                                                    int W32) {
+                                                    int W32, const int* __restrict__ enable) {
+    BH_FILL_ENABLED(enable);
     double s = 0.0;
     unsigned long long c = 0;
     const uint2* __restrict__ m02 = reinterpret_cast<const uint2*>(m0);
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(FIN_NT) void finalize_kernel(const double* __restri
                                                        const double* __restrict__ p_shell,
                                                        const unsigned long long* __restrict__ p_cnt, int n_shell,
                                                        FillStats* st, unsigned long long total, int fill_mode,
-                                                       float fill_value) {
+                                                       float fill_value, const int* __restrict__ enable) {
+    BH_FILL_ENABLED(enable);
     __shared__ double sa[FIN_NT], ss[FIN_NT];
     __shared__ unsigned long long sc[FIN_NT];
     double a = 0, s = 0;
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(FIN_NT) void finalize_kernel(const double* __restri
 // before this unit's stores are issued: waiting for them then never waits for a store.
 __global__ __launch_bounds__(256) void apply_fill_kernel(float* __restrict__ data, const uint32_t* __restrict__ md,
                                                          const FillStats* __restrict__ st, int64_t rows, int X,
-                                                         int W32) {
+                                                         int W32, const int* __restrict__ enable) {
+    BH_FILL_ENABLED(enable);
     const float fill = st->fill;
     const float4 fill4 = make_float4(fill, fill, fill, fill);
     const int lane = threadIdx.x & 63;
@@ -307,7 +309,7 @@ int fill_mask_buffers(bh_ctx* ctx, int64_t rows, int64_t X, uint32_t** m0, int* 
 // fused_partials > 0: the zero mask ("fill_m0") and that many block sums ("fill_pall") were already written by
 // the deskew kernel, which also skipped storing exact zeros; otherwise both come from mask0_kernel here.
 int fill_overhang_impl(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X, int fill_mode, float fill_value,
-                       int iterations, float* mean_out, int fused_partials, int connectivity) {
+                       int iterations, float* mean_out, int fused_partials, int connectivity, const int* enable) {
     BH_REQUIRE(iterations >= 0 && iterations < 32, "dilation_iterations must be in [0,31], got %d", iterations);
     BH_REQUIRE(X < (1ll << 31) && Y < (1ll << 31) && Z < (1ll << 31), "volume too large");
     ScopedTimer timer(ctx, T_FILL);
@@ -335,20 +337,21 @@ int fill_overhang_impl(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X
     const int gb = (int)std::min<int64_t>(ceil_div(nwords, tb), (int64_t)ctx->num_cus * 16);
     const uint32_t* md = m0;
     if (iterations > 0 && connectivity == 6) {
+        BH_REQUIRE(enable == nullptr, "the conditional mask pipeline dilates with the 26-connected element only");
         hipLaunchKernelGGL(dilate_cross_kernel, dim3(gb), dim3(tb), 0, s, m0, mA, nwords, W32, (int)Y, (int)Z, iterations);
         md = mA;
     } else if (iterations > 0) {
-        hipLaunchKernelGGL(dilate_x_kernel, dim3(gb), dim3(tb), 0, s, m0, mA, nwords, W32, iterations);
+        hipLaunchKernelGGL(dilate_x_kernel, dim3(gb), dim3(tb), 0, s, m0, mA, nwords, W32, iterations, enable);
         hipLaunchKernelGGL(dilate_outer_kernel, dim3(gb), dim3(tb), 0, s, mA, mB, nwords, (int64_t)W32, (int)Y,
-                           iterations);
+                           iterations, enable);
         hipLaunchKernelGGL(dilate_outer_kernel, dim3(gb), dim3(tb), 0, s, mB, mA, nwords, (int64_t)W32 * Y, (int)Z,
-                           iterations);
+                           iterations, enable);
         md = mA;
     }
-    hipLaunchKernelGGL(shell_kernel, dim3(nblk), dim3(256), 0, s, data, m0, md, p_shell, p_cnt, nwords, (int)X, W32);
+    hipLaunchKernelGGL(shell_kernel, dim3(nblk), dim3(256), 0, s, data, m0, md, p_shell, p_cnt, nwords, (int)X, W32, enable);
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(FIN_NT), 0, s, p_all, n_all, p_shell, p_cnt, nblk, st,
-                       (unsigned long long)(rows * X), fill_mode, fill_value);
-    hipLaunchKernelGGL(apply_fill_kernel, dim3(nblk), dim3(256), 0, s, data, md, st, rows, (int)X, W32);
+                       (unsigned long long)(rows * X), fill_mode, fill_value, enable);
+    hipLaunchKernelGGL(apply_fill_kernel, dim3(nblk), dim3(256), 0, s, data, md, st, rows, (int)X, W32, enable);
     BH_CHECK_HIP(hipGetLastError());
     if (mean_out) {
         FillStats h;
@@ -367,7 +370,7 @@ extern "C" int bh_overhang_fill(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, 
     BH_REQUIRE(Z > 0 && Y > 0 && X > 0, "invalid shape");
     BH_REQUIRE(fill_mode == BH_FILL_CONSTANT || fill_mode == BH_FILL_MEAN, "fill_mode must be CONSTANT or MEAN");
     BH_CHECK_HIP(hipSetDevice(ctx->device));
-    return bh::fill_overhang_impl(ctx, data, Z, Y, X, fill_mode, fill_value, dilation_iterations, mean_out, 0, 26);
+    return bh::fill_overhang_impl(ctx, data, Z, Y, X, fill_mode, fill_value, dilation_iterations, mean_out, 0, 26, nullptr);
 }
 
 extern "C" int bh_overhang_fill_connectivity(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X, int fill_mode,
@@ -377,5 +380,5 @@ extern "C" int bh_overhang_fill_connectivity(bh_ctx* ctx, float* data, int64_t Z
     BH_REQUIRE(fill_mode == BH_FILL_CONSTANT || fill_mode == BH_FILL_MEAN, "fill_mode must be CONSTANT or MEAN");
     BH_REQUIRE(connectivity == 6 || connectivity == 26, "connectivity must be 6 or 26, got %d", connectivity);
     BH_CHECK_HIP(hipSetDevice(ctx->device));
-    return bh::fill_overhang_impl(ctx, data, Z, Y, X, fill_mode, fill_value, dilation_iterations, mean_out, 0, connectivity);
+    return bh::fill_overhang_impl(ctx, data, Z, Y, X, fill_mode, fill_value, dilation_iterations, mean_out, 0, connectivity, nullptr);
 }

@@ -249,10 +249,13 @@ extern "C" int bh_inverse_filter_destroy(bh_filter* f) {
 
 extern "C" int bh_inverse_filter_trim(void) {
     std::lock_guard<std::mutex> lock(g_filter_pool_mu);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
     for (auto& kv : g_filter_pool) {
         (void)hipSetDevice(kv.first.first);
         for (void* p : kv.second) (void)dev_free(p);
     }
+    if (prev >= 0) (void)hipSetDevice(prev);  // the caller's device stays current
     g_filter_pool.clear();
     return BH_OK;
 }

@@ -233,14 +233,32 @@ _PREPARED_RL: "dict[tuple, tuple]" = {}
 
 
 def _prepared_rl(psf_zyx, shape, dev) -> PreparedRichardsonLucy:
-    host = psf_zyx.cpu().numpy() if isinstance(psf_zyx, torch.Tensor) else np.asarray(psf_zyx)
-    key = (id(psf_zyx), tuple(host.shape), shape, str(dev), hash(host.tobytes()))
-    hit = _PREPARED_RL.get(key)
+    # 1. the same object as last time: no copy to the host, no hash (a device tensor would be a synchronisation per call; a host
+    #    array's few kilobytes are hashed anyway, which also catches an array that was modified in place)
+    on_device = isinstance(psf_zyx, torch.Tensor) and psf_zyx.is_cuda
+    ident = ("id", id(psf_zyx), shape, str(dev))
+    hit = _PREPARED_RL.get(ident)
+    host = None
     if hit is not None and hit[0] is psf_zyx:
+        if on_device:
+            return hit[1]
+        host = psf_zyx.numpy() if isinstance(psf_zyx, torch.Tensor) else np.asarray(psf_zyx)
+        if hit[2] == hash(host.tobytes()):
+            return hit[1]
+    # 2. another object with the same contents (a PSF re-read per unit): found by its bytes
+    if host is None:
+        host = psf_zyx.cpu().numpy() if isinstance(psf_zyx, torch.Tensor) else np.asarray(psf_zyx)
+    digest = hash(host.tobytes())
+    content = ("bytes", digest, tuple(host.shape), str(host.dtype), shape, str(dev))
+    hit = _PREPARED_RL.get(content)
+    if hit is not None:
+        _PREPARED_RL[ident] = (psf_zyx, hit[1], digest)
         return hit[1]
-    while len(_PREPARED_RL) >= _PREPARED_MAX:
+    while len(_PREPARED_RL) >= 2 * _PREPARED_MAX:
         old = _PREPARED_RL.pop(next(iter(_PREPARED_RL)))
-        old[1].close()
+        if not any(v[1] is old[1] for v in _PREPARED_RL.values()):
+            old[1].close()
     prep = PreparedRichardsonLucy(psf_zyx, shape, dev)
-    _PREPARED_RL[key] = (psf_zyx, prep)
+    _PREPARED_RL[ident] = (psf_zyx, prep, digest)
+    _PREPARED_RL[content] = (None, prep, digest)
     return prep

@@ -83,14 +83,18 @@ def fast_deskew_zyx(
     keep_overhang: bool,
     average_n_slices: int = 1,
     overhang_fill: Literal["mean"] | float = 0,
+    row_sums: torch.Tensor | None = None,
 ) -> torch.Tensor:
     """Fused deskew of a (Z_scan, Y_tilt, X_coverslip) volume (biahub/deskew.py:456-542).
 
     ``raw_data`` is a tensor already on the GPU (float32 like the reference, or
     uint8/uint16/int16 which the kernel widens on load).  Returns a float32 tensor
     ``(ceil(Y/N), X, Xp)`` on the same device.  One kernel replaces the reference's
-    permute/flip copy, edge pad, grid build, ``grid_sample`` and mean; ``overhang_fill`` other
-    than 0 runs the bit-mask dilation / mean / fill passes of ``csrc/fill.hip``.
+    permute/flip copy, edge pad, grid build, ``grid_sample`` and mean.  ``overhang_fill`` other than 0: float32 volumes
+    take the one-pass fill of ``csrc/deskew_rows.inc`` (fill value from row sums of the input, whole rows written once; the
+    bit-mask pipeline of ``csrc/fill.hip`` re-runs the volume only when the data held exact zeros), other inputs the mask
+    pipeline.  ``row_sums`` (float64 ``(Z, Y)`` on the device: sums over x of ``raw_data``) may be handed in by whoever
+    produced the volume (``PreparedRichardsonLucy.apply(..., row_sums=...)``); it saves the one read that reduces them.
     """
     if not isinstance(raw_data, torch.Tensor):
         raise TypeError("fast_deskew_zyx expects a torch.Tensor on the GPU (use _fast_deskew_czyx for numpy)")
@@ -102,12 +106,26 @@ def fast_deskew_zyx(
                                            average_n_slices)
     mode, value = _fill_args(overhang_fill)
     ctx = get_context(dev)
+    if row_sums is not None and (row_sums.dtype != torch.float64 or tuple(row_sums.shape) != (Z, Y) or row_sums.device != t.device
+                                 or not row_sums.is_contiguous()):
+        raise ValueError("row_sums must be a contiguous float64 (Z, Y) tensor on the volume's device")
     with torch.cuda.device(dev):
         out = device_empty(out_shape, torch.float32, dev)
-        _lib.check(ctx.lib.bh_deskew(ctx.handle, ptr(t), code, Z, Y, X, float(ls_angle_deg),
-                                     float(px_to_scan_ratio), int(bool(keep_overhang)), int(average_n_slices),
-                                     mode, value, ptr(out), None))
+        _lib.check(ctx.lib.bh_deskew_rows(ctx.handle, ptr(t), code, Z, Y, X, float(ls_angle_deg),
+                                          float(px_to_scan_ratio), int(bool(keep_overhang)), int(average_n_slices),
+                                          mode, value, ptr(out), None, ptr(row_sums) if row_sums is not None else None))
     return out
+
+
+def deskew_fill_path(device=None) -> int:
+    """How the last deskew on ``device`` filled the overhang (diagnostic, synchronises): 0 mask pipeline or no fill, 1 one pass,
+    2 one pass followed by the mask pipeline (the data held exact zeros)."""
+    dev = resolve_device(device if device is not None else "cuda")
+    ctx = get_context(dev)
+    path = C.c_int(0)
+    with torch.cuda.device(dev):
+        _lib.check(ctx.lib.bh_deskew_fill_path(ctx.handle, C.byref(path)))
+    return int(path.value)
 
 
 def _host_deskew_zyx(zyx, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices=1, overhang_fill=0,

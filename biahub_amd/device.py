@@ -59,6 +59,7 @@ def resolve_device(device) -> torch.device:
 _POOL = None
 _POOL_ALLOCATOR = None
 _POOL_TLS = threading.local()
+_POOL_LOCK = threading.Lock()  # one pool per process: two threads entering volume_pool for the first time must not both build one
 
 
 @contextlib.contextmanager
@@ -71,13 +72,15 @@ def volume_pool(device=None):
         yield
         return
     if _POOL is None:
-        try:
-            _lib.load()
-            path = str(os.environ.get("BHCORE_LIB", _lib.LIB_PATH))
-            _POOL_ALLOCATOR = torch.cuda.memory.CUDAPluggableAllocator(path, "bh_torch_alloc", "bh_torch_free")
-            _POOL = torch.cuda.MemPool(_POOL_ALLOCATOR.allocator())
-        except (AttributeError, RuntimeError):  # torch without MemPool / pluggable allocators
-            _POOL = False
+        with _POOL_LOCK:
+            if _POOL is None:
+                try:
+                    _lib.load()
+                    path = str(os.environ.get("BHCORE_LIB", _lib.LIB_PATH))
+                    _POOL_ALLOCATOR = torch.cuda.memory.CUDAPluggableAllocator(path, "bh_torch_alloc", "bh_torch_free")
+                    _POOL = torch.cuda.MemPool(_POOL_ALLOCATOR.allocator())
+                except (AttributeError, RuntimeError):  # torch without MemPool / pluggable allocators
+                    _POOL = False
     if _POOL is False:
         yield
         return
@@ -94,7 +97,11 @@ def alloc_layout() -> dict:
     lib = _lib.load()
     kib, shuf, nblk, nbytes = C.c_int(), C.c_int(), C.c_uint64(), C.c_uint64()
     _lib.check(lib.bh_alloc_layout(C.byref(kib), C.byref(shuf), C.byref(nblk), C.byref(nbytes)))
+    rr, rb = C.c_uint64(), C.c_uint64()
+    _lib.check(lib.bh_alloc_retained(C.byref(rr), C.byref(rb)))
+    # retained_*: address ranges of released blocks that are kept reserved (csrc/context.hip dev_free): address space only, no memory
     return {"chunk_kib": kib.value, "shuffled": bool(shuf.value), "live_blocks": int(nblk.value), "live_gb": nbytes.value / 1e9,
+            "retained_va_ranges": int(rr.value), "retained_va_gb": rb.value / 1e9,
             "volume_pool": os.environ.get("BH_VOLUME_POOL", "1") != "0" and _POOL is not False}
 
 
@@ -108,9 +115,19 @@ def release_volume_pool() -> None:
 
 
 def empty(shape, dtype, device) -> torch.Tensor:
-    """``torch.empty`` on the GPU inside ``volume_pool``: where the operators allocate their results."""
-    with volume_pool(device):
-        return torch.empty(tuple(int(n) for n in shape), dtype=dtype, device=device)
+    """``torch.empty`` on the GPU inside ``volume_pool``: where the operators allocate their results.  The pool's cached blocks
+    serve only allocations made inside it, and torch does not release a private pool's blocks on its own out-of-memory retry:
+    on OOM the pool and torch's cache are given back to the driver and the allocation is tried once more (``BH_VOLUME_POOL=0``
+    trades the layout for one shared cache)."""
+    shape = tuple(int(n) for n in shape)
+    try:
+        with volume_pool(device):
+            return torch.empty(shape, dtype=dtype, device=device)
+    except torch.cuda.OutOfMemoryError:
+        release_volume_pool()
+        torch.cuda.empty_cache()
+        with volume_pool(device):
+            return torch.empty(shape, dtype=dtype, device=device)
 
 
 def empty_like(t: torch.Tensor) -> torch.Tensor:

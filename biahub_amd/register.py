@@ -17,7 +17,8 @@ from . import _lib
 from .device import as_device_volume, get_context, ptr, resolve_device, to_host
 from .device import empty as device_empty, empty_like as device_empty_like
 
-_INTERP = {"linear": _lib.INTERP_LINEAR, "nearestneighbor": _lib.INTERP_NEAREST}
+# "cubic": SciPy's order-3 B-spline (prefilter + 64 taps) — only with BOUNDARY_SCIPY_CONSTANT; the two ANTs names as before
+_INTERP = {"linear": _lib.INTERP_LINEAR, "nearestneighbor": _lib.INTERP_NEAREST, "cubic": _lib.INTERP_CUBIC}
 
 
 def get_3D_rescaling_matrix(start_shape_zyx, scaling_factor_zyx=(1, 1, 1), end_shape_zyx=None):
@@ -91,6 +92,24 @@ def affine_device(vol, matrix, output_shape_zyx, interpolation="linear", boundar
             _lib.check(ctx.lib.bh_affine(ctx.handle, ptr(t), code, Zi, Yi, Xi, m12, _INTERP[interpolation],
                                          int(boundary), float(cval), ptr(out), shape[0], shape[1], shape[2], lo))
     return out
+
+
+def cast_like_scipy(t: torch.Tensor, dtype) -> torch.Tensor:
+    """SciPy's conversion of an interpolated value into the output dtype (ni_interpolation.c, CASE_INTERP_OUT_*): floating
+    types are cast; integers round half away from zero (unsigned: negatives -> 0) and saturate at the type's range."""
+    dtype = np.dtype(dtype)
+    if not np.issubdtype(dtype, np.integer):
+        return t if dtype == np.float32 else t.to(getattr(torch, dtype.name))
+    info = np.iinfo(dtype)
+    r = torch.where(t > 0, torch.floor(t + 0.5), torch.ceil(t - 0.5) if info.min < 0 else torch.zeros_like(t))
+    r = r.clamp_(float(info.min), float(info.max))
+    tdt = {"uint8": torch.uint8, "int8": torch.int8, "int16": torch.int16, "uint16": torch.uint16, "int32": torch.int32,
+           "int64": torch.int64}.get(dtype.name)
+    if tdt is None:
+        raise TypeError(f"unsupported output dtype {dtype}")
+    if tdt == torch.uint16:  # no float -> uint16 cast kernel in this torch build: through int32
+        return r.to(torch.int32).to(torch.uint16)
+    return r.to(tdt)
 
 
 def largest_interior_rectangle(mask2d: np.ndarray):
@@ -171,16 +190,25 @@ def apply_affine_transform(
     """Apply a 4x4 ZYX affine, optionally crop (biahub/register.py:202-281).
 
     4-D input recurses per channel (:241-252); NaN -> 0 before resampling (:254, fused into the
-    kernel load); ``method`` accepts "ants" (ITK boundary rule) or "scipy" (the reference's raw
-    ``scipy.ndimage.affine_transform`` call, :271-272: spline order 3 there — not implemented, raises);
-    anything else raises ``ValueError("Unknown method ...")`` (:275).  Only the cropped sub-box is
-    computed (the reference warps the full grid and slices, :278-279).
+    kernel load); ``method`` accepts "ants" (ITK boundary rule) or "scipy" — the reference's raw
+    ``scipy.ndimage.affine_transform(zyx_data, matrix, output_shape_zyx)`` (:271-272): cubic B-spline, SciPy "constant"
+    boundary, and ``output_shape_zyx`` lands in SciPy's ``offset`` slot, which a homogeneous matrix overrides, so the
+    result keeps the INPUT's shape and dtype (reproduced, not fixed); anything else raises
+    ``ValueError("Unknown method ...")`` (:275).  Only the cropped sub-box is computed (the reference warps the full grid
+    and slices, :278-279).
     """
-    if method == "scipy":
-        raise NotImplementedError("method='scipy' (cubic spline) is not implemented on the GPU path")
-    if method != "ants":
+    if method not in ("ants", "scipy"):
         raise ValueError(f"Unknown method {method}")
     zyx_data = np.asarray(zyx_data)
+    if method == "scipy" and zyx_data.ndim != 4:
+        Zs, Ys, Xs = (int(s) for s in zyx_data.shape)
+        lo, shape = (0, 0, 0), (Zs, Ys, Xs)
+        if crop_output_slicing is not None:
+            b = [_slice_bounds(s, n) for s, n in zip(crop_output_slicing, (Zs, Ys, Xs))]
+            lo, shape = tuple(v[0] for v in b), tuple(v[1] for v in b)
+        dev = resolve_device(device)
+        out = affine_device(zyx_data, matrix, (Zs, Ys, Xs), "cubic", _lib.BOUNDARY_SCIPY_CONSTANT, 0.0, lo, shape, dev)
+        return to_host(cast_like_scipy(out, zyx_data.dtype))
     Z, Y, X = (int(s) for s in output_shape_zyx)
     lo, shape = (0, 0, 0), (Z, Y, X)
     if crop_output_slicing is not None:

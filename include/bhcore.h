@@ -89,6 +89,7 @@ extern "C" {
 /* affine interpolation (register.py:207 "linear" | "nearestneighbor") */
 #define BH_INTERP_NEAREST 0
 #define BH_INTERP_LINEAR 1
+#define BH_INTERP_CUBIC 3 /* cubic B-spline with SciPy's prefilter (scipy order=3); boundary BH_BOUNDARY_SCIPY_CONSTANT only */
 
 /* affine boundary rule */
 #define BH_BOUNDARY_ITK 0            /* inside iff -0.5 <= c < N-0.5, neighbours clamped (ANTs/ITK) */
@@ -104,7 +105,11 @@ int bh_device_count(int* count);
 /* Device memory laid out like the library's own workspace (blocks of 2 GiB and more: 2-MiB physical chunks mapped in a
  * shuffled order through the HIP virtual-memory API; smaller ones: hipMalloc).  The signatures are the ones
  * torch.cuda.memory.CUDAPluggableAllocator binds (biahub_amd/device.py: volume_pool); any host may call them directly. */
-int bh_alloc_layout(int* chunk_kib, int* shuffled, uint64_t* live_blocks, uint64_t* live_bytes); /* diagnostics; any pointer may be NULL */
+int bh_alloc_layout(int* chunk_kib, int* shuffled, uint64_t* live_blocks, uint64_t* live_bytes);
+/* Address ranges of released virtual-memory blocks are retained, not returned (a range reserved again right after its release
+ * was seen to deliver the old mapping's pages): how many ranges and bytes of address space that is.  Past
+ * BH_ALLOC_VMM_VA_CAP_GB (default 16 TiB) further gigabyte blocks come from hipMalloc. */
+int bh_alloc_retained(uint64_t* ranges, uint64_t* bytes); /* diagnostics; any pointer may be NULL */
 void* bh_torch_alloc(size_t size, int device, void* hip_stream);
 void bh_torch_free(void* ptr, size_t size, int device, void* hip_stream);
 
@@ -187,6 +192,17 @@ int bh_deskew_shape(int64_t Z, int64_t Y, int64_t X, double ls_angle_deg, double
 int bh_deskew(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, int64_t X,
               double ls_angle_deg, double px_to_scan_ratio, int keep_overhang, int average_n_slices,
               int fill_mode, float fill_value, float* out, float* mean_out);
+
+/* bh_deskew with the row sums of the input handed in: row_sums (device, may be NULL) = float64 [Z * Y], row_sums[z * Y + y] =
+ * sum over x of in[z, y, x].  With a "mean" fill of a float32 volume the fill value is derived from them before the resampling
+ * kernel starts (which then writes whole rows, fill included, in one pass); an operator that has just produced `in` can
+ * reduce them on the way (bh_richardson_lucy_apply_rows), otherwise bh_deskew reduces them itself in one read of `in`. */
+int bh_deskew_rows(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, int64_t X,
+                   double ls_angle_deg, double px_to_scan_ratio, int keep_overhang, int average_n_slices,
+                   int fill_mode, float fill_value, float* out, float* mean_out, const double* row_sums);
+/* Diagnostic (synchronises): how the last bh_deskew of this context filled the overhang — 0 mask pipeline (or no fill),
+ * 1 one pass, 2 one pass followed by the mask pipeline because the data held exact zeros that geometry does not explain. */
+int bh_deskew_fill_path(bh_ctx* ctx, int* path);
 
 /* The same operator on HOST memory, on the calling process's CPU threads (no context, no GPU): what `--cluster debug` with
  * the reference's default `device: cpu` needs (biahub/settings.py:348-383, biahub/deskew.py:762-766; BASELINE config 1).
@@ -371,6 +387,12 @@ int bh_average_patches(bh_ctx* ctx, const float* in, int64_t Z, int64_t Y, int64
 int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, int64_t Yi, int64_t Xi,
               const double matrix[12], int interpolation, int boundary, float cval, float* out,
               int64_t Zo, int64_t Yo, int64_t Xo, const int64_t crop_lo[3]);
+
+/* Cubic B-spline coefficients of a volume (the prefilter of scipy.ndimage.affine_transform(order=3, mode="constant"):
+ * biahub/core/transform.py:374-396, biahub/register.py:271-272): per axis the recursive inverse of the sampled cubic
+ * B-spline with mirror boundaries; axes of length 1 are left alone; NaN inputs read as 0.  in: (Z,Y,X) of in_dtype;
+ * coef: float32 (Z,Y,X), distinct from in.  bh_affine(BH_INTERP_CUBIC) runs this into the context's scratch itself. */
+int bh_spline_prefilter(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t Y, int64_t X, float* coef);
 
 /* ---- bit-exact crop / flip --------------------------------------------------------- */
 /* (C, Zi, Yi, Xi) of itemsize bytes -> (C, Zo, Yo, Xo) starting at lo, optionally flipped along

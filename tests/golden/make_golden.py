@@ -16,6 +16,8 @@ Fixtures written:
   average_n_slices.npz    _average_n_slices known answers
   transfer_function.npz   compute_tranfser_function (odd/even psf x odd/even volume)
   transform_scipy.npz     core.transform.Transform.apply (SciPy), orders 0/1
+  transform_spline.npz    Transform.apply(order=3) (3-D and 2-D, cval, reference grid, integer dtypes) and the raw
+                          register.apply_affine_transform(method="scipy") call (cubic spline, output = input shape)
   phase_cross_corr.npz    estimate_stabilization.phase_cross_corr (three normalisations)
   estimate_crop.npz       estimate_crop.estimate_crop_one_position on in-memory arrays (LIR from biahub_amd's restatement)
   legacy_fill.npz         deskew._fill_overhang_with_mean (legacy 6-connected SciPy dilation)
@@ -337,6 +339,69 @@ def concatenate_vectors():
     print("concatenate.json written")
 
 
+def spline_vectors():
+    """core/transform.py:374-396 Transform.apply with order=3 (and the integer-dtype rounding of orders 1 / 3), and
+    register.py:256-272 apply_affine_transform(method="scipy"): SciPy's cubic B-spline resampling -> transform_spline.npz."""
+    import biahub.register as R
+    from biahub.core.transform import Transform
+
+    rng = np.random.default_rng(20261005)
+    sp = {}
+
+    def rot(deg_z, deg_y, scale, shift):
+        a, b = np.deg2rad(deg_z), np.deg2rad(deg_y)
+        Rz = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        M = np.eye(4)
+        M[:3, :3] = scale * (Rz @ Ry)
+        M[:3, 3] = shift
+        return M
+
+    # 3-D, two shapes, rotation + fractional shift
+    for j, (shape, M) in enumerate([((12, 16, 20), rot(7.0, 0.0, 1.02, (0.4, 1.75, -2.25))),
+                                    ((9, 33, 14), rot(-11.0, 4.0, 0.97, (-0.6, 2.3, 1.15))),
+                                    ((5, 6, 7), rot(3.0, 0.0, 1.0, (0.25, -0.5, 0.75)))]):
+        mov = rng.random(shape, dtype=np.float32) * 1000
+        t = Transform(M)
+        sp[f"mov{j}"], sp[f"M{j}"] = mov, M
+        sp[f"o3_{j}"] = t.apply(mov, order=3)
+        sp[f"o3_cval_{j}"] = t.apply(mov, order=3, cval=37.5)
+    ref = np.zeros((10, 20, 18), dtype=np.float32)
+    sp["o3_ref_0"] = Transform(sp["M0"]).apply(sp["mov0"], reference=ref, order=3, cval=-2.0)
+    # identity and integer shift: the spline interpolates the samples
+    sp["o3_identity"] = Transform(np.eye(4)).apply(sp["mov0"], order=3)
+    sp["o3_shift_int"] = Transform.from_translation([-3.0, 1.0, 4.0]).apply(sp["mov0"], order=3)
+    # integer dtypes: SciPy rounds (and clamps) the float64 result into the input dtype
+    u16 = (rng.random((12, 16, 20)) * 4000 + 100).astype(np.uint16)
+    u16[3:5, 4:9, 6:12] = 65535  # overshoot above the type's range
+    u16[8:10, 2:5, 3:7] = 0      # and below it
+    sp["u16"] = u16
+    sp["u16_o3"] = Transform(sp["M0"]).apply(u16, order=3)
+    sp["u16_o1"] = Transform(sp["M0"]).apply(u16, order=1)
+    i16 = (rng.random((12, 16, 20)) * 6000 - 3000).astype(np.int16)
+    sp["i16"] = i16
+    sp["i16_o3"] = Transform(sp["M0"]).apply(i16, order=3)
+    sp["i16_o1"] = Transform(sp["M0"]).apply(i16, order=1)
+    # 2-D images
+    th = np.deg2rad(9.0)
+    M2 = np.array([[np.cos(th), -np.sin(th), 1.3], [np.sin(th), np.cos(th), -2.7], [0, 0, 1.0]])
+    img = rng.random((24, 31), dtype=np.float32) * 100
+    sp["img2d"], sp["M2d"] = img, M2
+    sp["img2d_o3"] = Transform(M2).apply(img, order=3, cval=5.0)
+    sp["img2d_o1"] = Transform(M2).apply(img, order=1)
+    # the raw register.py:271-272 call: pull matrix, order 3, output shape = input shape whatever output_shape_zyx says
+    Mp = rot(5.0, 0.0, 1.01, (0.3, -1.2, 2.6))
+    vol = rng.random((10, 18, 22), dtype=np.float32) * 500
+    vol[2, 3, 4] = np.nan  # np.nan_to_num(nan=0) comes first (:254)
+    sp["reg_vol"], sp["reg_M"] = vol, Mp
+    sp["reg_out"] = R.apply_affine_transform(vol, Mp, (12, 20, 24), method="scipy")
+    sp["reg_out_crop"] = R.apply_affine_transform(vol, Mp, (10, 18, 22), method="scipy",
+                                                  crop_output_slicing=(slice(1, 9), slice(2, 15), slice(3, 20)))
+    sp["reg_u16"] = u16
+    sp["reg_u16_out"] = R.apply_affine_transform(u16, sp["M0"], u16.shape, method="scipy")
+    np.savez_compressed(HERE / "transform_spline.npz", **sp)
+
+
 def deskew_transform_matrix_vectors():
     """biahub/deskew.py:180-210 — _get_transform_matrix over a grid of (angle, ratio), incl. the example settings."""
     import biahub.deskew as D
@@ -356,6 +421,10 @@ def main():
     if sys.argv[1:] == ["estimate_crop"]:
         load_reference()
         estimate_crop_vectors()
+        return 0
+    if sys.argv[1:] == ["spline"]:
+        load_reference()
+        spline_vectors()
         return 0
     if sys.argv[1:] == ["legacy_fill"]:
         load_reference()
@@ -506,6 +575,7 @@ def main():
     tr["points_out"] = t.apply_points(pts)
     tr["shift_int"] = Transform.from_translation([-3.0, 1.0, 4.0]).apply(np.ones((10, 10, 10), np.float32))
     np.savez_compressed(HERE / "transform_scipy.npz", **tr)
+    spline_vectors()
 
     # ---- 6b. phase cross-correlation (estimate_stabilization.py:199-256) ---------------
     import biahub.estimate_stabilization as ES

@@ -136,6 +136,61 @@ def test_deskew_persistent_kernel_equals_tile_kernel(gpu, monkeypatch):
                 assert torch.equal(new, old), (shape, fill)
 
 
+@pytest.mark.parametrize("shape,n,angle,ratio", [
+    ((64, 256, 256), 3, 36.17, 0.371),   # BASELINE config 1
+    ((200, 40, 320), 3, 36.17, 0.371),   # several x' chunks, windows leaving the volume on both sides
+    ((33, 17, 192), 4, 36.17, 0.371),    # N = 4, ragged last slab
+    ((31, 50, 64), 1, 45.0, 0.9),
+    ((40, 30, 128), 2, 30.0, 0.25),
+])
+def test_deskew_one_pass_fill(gpu, monkeypatch, shape, n, angle, ratio):
+    """float32 volumes with whole 64-column tiles fill the overhang in ONE pass (csrc/deskew_rows.inc): the zero pattern and
+    its dilation from geometry, the mean from row sums of the input, whole rows written by the resampling kernel.  Against the
+    oracle (the reference's mask / dilate / mean / where on the finished volume, deskew.py:339-368), against the mask pipeline
+    (BH_DESKEW_ONEPASS=0: same voxels bit for bit outside the fill, the fill value to float32 rounding), with row sums handed
+    in, and with data zeros, where the conditional mask pipeline behind the kernel must take over (path 2)."""
+    from biahub_amd.deskew import deskew_fill_path, fast_deskew_zyx
+
+    rng = np.random.default_rng(sum(shape) + n)
+    vol = (rng.random(shape, dtype=np.float32) * 900 + 50).astype(np.float32)
+    t = torch.from_numpy(vol).to(gpu)
+    for fill in ("mean", 123.5):
+        kw = dict(ls_angle_deg=angle, px_to_scan_ratio=ratio, keep_overhang=True, average_n_slices=n, overhang_fill=fill)
+        want = O.fast_deskew_zyx(vol, angle, ratio, True, n, fill)
+        got = fast_deskew_zyx(t, **kw)
+        assert deskew_fill_path(gpu) == 1, (shape, fill)
+        assert rel_err(got.cpu().numpy(), want) <= DESKEW_TOL, (shape, fill)
+        monkeypatch.setenv("BH_DESKEW_ONEPASS", "0")
+        old = fast_deskew_zyx(t, **kw)
+        assert deskew_fill_path(gpu) == 0
+        monkeypatch.delenv("BH_DESKEW_ONEPASS")
+        same = got == old
+        fv_new, fv_old = got[~same], old[~same]  # differ only where the fill value went, by its rounding
+        if fill == "mean":
+            assert fv_new.numel() == 0 or (fv_new.unique().numel() == 1 and fv_old.unique().numel() == 1)
+            assert float((got - old).abs().max()) <= 1e-6 * float(old.abs().max()), (shape, fill)
+        else:
+            assert bool(same.all()), (shape, fill)
+    # row sums handed in by the caller: same result as reducing them here
+    rs = t.to(torch.float64).sum(dim=2).contiguous()
+    kw = dict(ls_angle_deg=angle, px_to_scan_ratio=ratio, keep_overhang=True, average_n_slices=n, overhang_fill="mean")
+    a, b = fast_deskew_zyx(t, **kw), fast_deskew_zyx(t, row_sums=rs, **kw)
+    assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())
+    # data zeros (a dark block): part of the reference's mask -> the kernel raises its flag, the mask pipeline redoes the volume
+    vz = vol.copy()
+    vz[shape[0] // 3: shape[0] // 3 + 6, : min(20, shape[1]), 8:40] = 0.0
+    for fill in ("mean", 123.5):
+        want = O.fast_deskew_zyx(vz, angle, ratio, True, n, fill)
+        got = fast_deskew_zyx(torch.from_numpy(vz).to(gpu), angle, ratio, True, n, fill)
+        path = deskew_fill_path(gpu)
+        zeros_in_signal = bool(((O.fast_deskew_zyx(vz, angle, ratio, True, n, 0) == 0) & (O.fast_deskew_zyx(vol, angle, ratio, True, n, 0) != 0)).any())
+        assert path == (2 if zeros_in_signal else 1), (shape, fill, path)
+        assert rel_err(got.cpu().numpy(), want) <= DESKEW_TOL, (shape, fill)
+    # and a clean volume afterwards takes the one-pass path again (the flag is re-armed per call)
+    got = fast_deskew_zyx(t, **kw)
+    assert deskew_fill_path(gpu) == 1
+
+
 def test_host_deskew_equals_gpu_deskew(gpu):
     """libbhcore's host implementation of the operator (bh_host_deskew, what `device: cpu` runs without a GPU) restates the
     kernels' float32 arithmetic operation by operation: bit-identical without a fill, the fill value to float32 rounding."""
@@ -659,6 +714,77 @@ def test_affine_scipy_mode_golden(gpu):
     assert rel_err(t.apply(z["moving"], reference=ref, order=1, cval=3.0), z["order1_ref"]) <= 1e-5
     assert np.array_equal(Transform.from_translation([-3.0, 1.0, 4.0]).apply(np.ones((10, 10, 10), np.float32)),
                           z["shift_int"])
+
+
+def test_affine_cubic_spline_golden(gpu):
+    """Transform.apply(order=3) and apply_affine_transform(method="scipy") against the reference's own outputs
+    (core/transform.py:374-396, register.py:271-272; tests/golden/transform_spline.npz): <= 1e-5 of the volume's maximum."""
+    from biahub_amd.core.transform import Transform
+    from biahub_amd.register import apply_affine_transform
+
+    z = np.load(GOLDEN / "transform_spline.npz")
+    for j in range(3):
+        t = Transform(z[f"M{j}"])
+        got = t.apply(z[f"mov{j}"], order=3)
+        assert got.dtype == np.float32 and got.shape == z[f"o3_{j}"].shape
+        assert rel_err(got, z[f"o3_{j}"]) <= 1e-5, j
+        assert rel_err(t.apply(z[f"mov{j}"], order=3, cval=37.5), z[f"o3_cval_{j}"]) <= 1e-5, j
+    ref = np.zeros((10, 20, 18), np.float32)
+    assert rel_err(Transform(z["M0"]).apply(z["mov0"], reference=ref, order=3, cval=-2.0), z["o3_ref_0"]) <= 1e-5
+    assert rel_err(Transform(np.eye(4)).apply(z["mov0"], order=3), z["o3_identity"]) <= 1e-5
+    assert rel_err(Transform.from_translation([-3.0, 1.0, 4.0]).apply(z["mov0"], order=3), z["o3_shift_int"]) <= 1e-5
+    # integer dtypes: SciPy rounds half away from zero and saturates; float32 accumulation here may flip a value that lies
+    # within 1e-3 of a half-integer
+    for k in ("u16", "i16"):
+        for order in (1, 3):
+            got = Transform(z["M0"]).apply(z[k], order=order)
+            want = z[f"{k}_o{order}"]
+            assert got.dtype == want.dtype
+            d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+            assert d.max() <= 1 and (d != 0).mean() < 2e-3, (k, order, d.max(), (d != 0).mean())
+    # 2-D images ride as the single plane of a volume
+    assert rel_err(Transform(z["M2d"]).apply(z["img2d"], order=3, cval=5.0), z["img2d_o3"]) <= 1e-5
+    assert rel_err(Transform(z["M2d"]).apply(z["img2d"], order=1), z["img2d_o1"]) <= 1e-5
+    # the raw register.py:271-272 call: output = input shape whatever output_shape_zyx says; NaN -> 0 first; crop after
+    got = apply_affine_transform(z["reg_vol"], z["reg_M"], (12, 20, 24), method="scipy")
+    assert got.shape == z["reg_out"].shape and rel_err(got, z["reg_out"]) <= 1e-5
+    crop = (slice(1, 9), slice(2, 15), slice(3, 20))
+    got = apply_affine_transform(z["reg_vol"], z["reg_M"], (10, 18, 22), method="scipy", crop_output_slicing=crop)
+    assert got.shape == z["reg_out_crop"].shape and rel_err(got, z["reg_out_crop"]) <= 1e-5
+    got = apply_affine_transform(z["reg_u16"], z["M0"], z["reg_u16"].shape, method="scipy")
+    d = np.abs(got.astype(np.int64) - z["reg_u16_out"].astype(np.int64))
+    assert got.dtype == np.uint16 and d.max() <= 1 and (d != 0).mean() < 2e-3
+    with pytest.raises(ValueError, match="Unknown method"):
+        apply_affine_transform(z["reg_vol"], z["reg_M"], (10, 18, 22), method="cupy")
+
+
+def test_affine_cubic_spline_vs_oracle_sizes(gpu):
+    """Prefilter blocks, run-ins and row chunks at sizes beyond the goldens: axes shorter than the run-in, longer than one
+    block, rows longer than one LDS chunk, a strongly oblique matrix; the prefilter alone against the oracle's float64 one."""
+    from biahub_amd import _lib
+    from biahub_amd.device import get_context, ptr
+    from biahub_amd.register import affine_device
+
+    rng = np.random.default_rng(11)
+    for shape in [(3, 150, 70), (70, 9, 200), (2, 5, 4500), (130, 66, 40)]:
+        vol = rng.random(shape, dtype=np.float32) * 100 + 5
+        t = torch.from_numpy(vol).to(gpu)
+        coef = torch.empty_like(t)
+        ctx = get_context(gpu)
+        _lib.check(ctx.lib.bh_spline_prefilter(ctx.handle, ptr(t), _lib.DT_F32, *shape, ptr(coef)))
+        want = O.spline_prefilter(vol)
+        assert rel_err(coef.cpu().numpy(), want) <= 2e-6, shape
+    vol = rng.random((40, 50, 60), dtype=np.float32) * 1000
+    th = np.deg2rad(25.0)
+    M = np.array([[np.cos(th), 0, np.sin(th), 3.3], [0.05, 0.98, 0, -1.2], [-np.sin(th), 0.02, np.cos(th), 9.7], [0, 0, 0, 1.0]])
+    got = affine_device(vol, M, (44, 48, 70), "cubic", _lib.BOUNDARY_SCIPY_CONSTANT, 12.5).cpu().numpy()
+    want = O.spline_affine_pull(vol, M, (44, 48, 70), 12.5)
+    assert rel_err(got, want) <= 1e-5
+    lo, shp = (3, 5, 7), (20, 30, 40)
+    sub = affine_device(vol, M, (44, 48, 70), "cubic", _lib.BOUNDARY_SCIPY_CONSTANT, 12.5, lo, shp).cpu().numpy()
+    assert np.array_equal(sub, got[3:23, 5:35, 7:47])
+    with pytest.raises(Exception, match="constant"):
+        affine_device(vol, M, vol.shape, "cubic", _lib.BOUNDARY_ITK)
 
 
 def test_stabilization_transform(gpu):

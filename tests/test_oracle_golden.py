@@ -75,6 +75,35 @@ def test_scipy_affine_oracle_matches_reference():
                           z["shift_int"])
 
 
+def test_spline_oracle_matches_reference_and_scipy():
+    """SciPy's cubic-spline resampling restated (oracle spline_*): the reference's own Transform.apply(order=3) and
+    apply_affine_transform(method="scipy") outputs (core/transform.py:374-396, register.py:271-272), and scipy itself."""
+    import scipy.ndimage as ndi
+
+    z = np.load(GOLDEN / "transform_spline.npz")
+    for j in range(3):
+        mov, M = z[f"mov{j}"], z[f"M{j}"]
+        assert rel_err(O.transform_apply_spline(mov, M), z[f"o3_{j}"]) <= 1e-6
+        assert rel_err(O.transform_apply_spline(mov, M, cval=37.5), z[f"o3_cval_{j}"]) <= 1e-6
+    assert rel_err(O.transform_apply_spline(z["mov0"], z["M0"], (10, 20, 18), -2.0), z["o3_ref_0"]) <= 1e-6
+    assert rel_err(O.transform_apply_spline(z["mov0"], np.eye(4)), z["o3_identity"]) <= 1e-6
+    sh = np.array([[1, 0, 0, -3.0], [0, 1, 0, 1.0], [0, 0, 1, 4.0], [0, 0, 0, 1]])
+    assert rel_err(O.transform_apply_spline(z["mov0"], sh), z["o3_shift_int"]) <= 1e-6
+    for k in ("u16", "i16"):  # integers: round half away from zero, saturate
+        assert np.array_equal(O.transform_apply_spline(z[k], z["M0"]), z[k + "_o3"])
+    assert rel_err(O.transform_apply_spline(z["img2d"], z["M2d"], cval=5.0), z["img2d_o3"]) <= 1e-6
+    assert rel_err(O.apply_affine_transform_scipy(z["reg_vol"], z["reg_M"], (12, 20, 24)), z["reg_out"]) <= 1e-6
+    crop = (slice(1, 9), slice(2, 15), slice(3, 20))
+    assert rel_err(O.apply_affine_transform_scipy(z["reg_vol"], z["reg_M"], None, crop), z["reg_out_crop"]) <= 1e-6
+    assert np.array_equal(O.apply_affine_transform_scipy(z["reg_u16"], z["M0"]), z["reg_u16_out"])
+    # the prefilter against scipy's, incl. axes of length 1 and 2
+    rng = np.random.default_rng(3)
+    for shape in [(5,), (2,), (7, 3), (6, 9, 11), (1, 5, 4), (40, 3, 2)]:
+        v = rng.random(shape)
+        np.testing.assert_allclose(O.spline_prefilter(v), ndi.spline_filter(v, 3, output=np.float64, mode="mirror"),
+                                   rtol=0, atol=1e-13)
+
+
 def test_itk_mode_reference_tests():
     # tests/test_affine.py:26-59 restated for the ITK boundary mode of the oracle
     ones = np.ones((10, 10, 10))
