@@ -192,9 +192,25 @@ def ops_suite(vol, psf, dev, ctx):
                                  "note": "torch copy_ of the same volume into a second buffer: the out-of-place streaming rate on this part"}
     del x
     rec("affine_nearest_f32", lambda: affine_device(vol, M, shape, "nearestneighbor"), _lib.T_AFFINE, 8 * V)
+    rec("affine_cubic_f32", lambda: affine_device(vol, M, shape, "cubic", _lib.BOUNDARY_SCIPY_CONSTANT), _lib.T_AFFINE, 8 * V,
+        "SciPy order 3 (Transform.apply(order=3), apply_affine_transform(method='scipy')): three prefilter passes + 64-tap gather; "
+        "bytes by 4 (V_in + V_out) like the other warps, the prefilter's passes are not in the model")
     v16 = vol.to(torch.uint16)
     rec("affine_linear_u16_in", lambda: affine_device(v16, M, shape, "linear"), _lib.T_AFFINE, 6 * V, "2 V_in + 4 V_out")
     rec("flat_field_u16", lambda: flat_field_device(v16), _lib.T_FLATFIELD, 8 * V, "two 2-byte reads (median, apply) + one f32 write")
+    # deskew + mean fill of a resident float32 volume on its own (no operator in front to hand over row sums): row-sum read,
+    # resampling with whole-row stores, and the conditional mask pipeline that returns at once
+    out_shape, _ = get_deskewed_data_shape(shape, DESKEW["ls_angle_deg"], DESKEW["px_to_scan_ratio"], True, DESKEW["average_n_slices"])
+    dk_bytes = 4.0 * (V + float(np.prod(out_shape)))
+    ms_pair = 0.0
+    for _ in range(3):
+        r = fast_deskew_zyx(vol, **DESKEW)
+        ms_pair = ctx.elapsed_ms(_lib.T_DESKEW) + ctx.elapsed_ms(_lib.T_FILL)
+        del r
+    out["deskew_fill_pair"] = {"ms": ms_pair, "algorithmic_bytes": dk_bytes, "GBps": dk_bytes / ms_pair / 1e6,
+                               "frac": dk_bytes / ms_pair / 1e6 / HBM_PEAK_GBS,
+                               "note": "deskew with overhang_fill='mean' standalone: geometry bits + row sums of the input (one read) + "
+                                       "one-pass resampling kernel + the conditional mask pipeline; 4 (V + V_out)"}
     del v16
     tf = transfer_function_device(psf, shape, dev)
     rec("tikhonov", lambda: tikhonov_zyx(vol, tf, 1e-3), _lib.T_TIKHONOV, 50 * V, "50 V: 2 FFTs (3-pass model) + real filter")
@@ -238,6 +254,28 @@ def ops_suite(vol, psf, dev, ctx):
     # Richardson-Lucy on DESKEWED volumes — BASELINE config 4 in its literal order (deskew -> deconvolve), and what the
     # reference's own pipeline does with its FFT reconstruction (nextflow/mantis-v2.nf:116-125): awkward row lengths, the
     # engine at a wrap-padded box.  Prepared handle, per-volume wall time of the third call.
+    # a measured PSF (estimate-psf) is never point-symmetric: the complex transfer function, two complex Z-pass products
+    try:
+        g = torch.Generator(device=dev).manual_seed(9)
+        apsf = psf * (1.0 + 0.2 * torch.rand(psf.shape, generator=g, device=dev))
+        apsf = apsf / apsf.sum()
+        with PreparedRichardsonLucy(apsf, shape, dev) as h:
+            res = torch.empty_like(vol)
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                h(vol, 10, 1e-6, out=res)
+                torch.cuda.synchronize(dev)
+                ms = (time.perf_counter() - t0) * 1e3
+            assert not h.otf_is_real
+            out["rl10_asymmetric_psf"] = {"ms": ms, "otf_is_real": h.otf_is_real, "voxels_per_s": V / ms * 1e3, "algorithmic_bytes": 1120 * V,
+                                          "GBps": 1120 * V / ms / 1e6, "frac": 1120 * V / ms / 1e6 / HBM_PEAK_GBS,
+                                          "note": "10 iterations with the COMPLEX transfer function of a PSF that is not point-symmetric "
+                                                  "(the headline's Gaussian is: one float per bin in the Z passes)"}
+        del res, apsf
+    except RuntimeError as e:
+        out["rl10_asymmetric_psf"] = {"skipped": str(e)[:200]}
+    ctx.release_workspace()
     for name, dshape in (("rl10_deskewed_config4_volume", (342, 1024, 1517)), ("rl10_deskewed_config2_volume", (683, 2048, 3034))):
         try:
             g = torch.Generator(device=dev).manual_seed(5)
@@ -424,11 +462,15 @@ def main():
     # region; every step applies it (bh_richardson_lucy_apply: no host synchronisation of its own)
     rl_prepared = PreparedRichardsonLucy(psf, shape, dev)
 
+    # the last R-L update pass leaves the row sums of its result behind (one float64 per row): the deskew's mean fill is derived
+    # from them, so the fill costs no pass of its own over the volume (csrc/deskew_rows.inc)
+    row_sums = torch.empty(shape[:2], dtype=torch.float64, device=dev)
+
     def step():
         vol = vols[nstep[0] % len(vols)]
         nstep[0] += 1
-        rl = rl_prepared(vol, args.iterations, 1e-6)
-        return fast_deskew_zyx(rl, **DESKEW)
+        rl, rs = rl_prepared(vol, args.iterations, 1e-6, row_sums=row_sums)
+        return fast_deskew_zyx(rl, row_sums=rs, **DESKEW)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -495,7 +537,8 @@ def main():
         rl_bytes_1pass = 48.0 * V       # SURVEY.md §8d lower bound: every FFT one read + one write
         dk_bytes = 4.0 * (V + V_out)    # read every input voxel once, write every output voxel once
         rl_moved, rl_src = pmc_traffic("rl_iteration", shape)
-        dk_moved, dk_src = pmc_traffic("deskew_kernel", shape)
+        dk_moved, dk_src = pmc_traffic("deskew_pair", shape)
+        pair_s = deskew_s + fill_s
         result = {
             "metric": "voxels/s for deskew+10-iter R-L deconv, 2048^2x512 f32",
             "value": world * args.steps * V / dt,
@@ -511,7 +554,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"1 position/GPU: R-L {args.iterations} it (PSF {PSF_SHAPE}) then deskew "
-                            f"{shape}->{tuple(out_shape)} (36.17 deg, 0.371, N=3, fill mean), input resident in HBM; two "
+                            f"{shape}->{tuple(out_shape)} (36.17 deg, 0.371, N=3, fill mean; the fill value derived from row sums the last R-L pass reduces), input resident in HBM; two "
                             "distinct positions alternate over the steps; the transfer function of the plate's PSF is prepared "
                             "once before the timed region (bh_richardson_lucy_create, as the reference computes it once per plate)",
                 "raw_shape_zyx": list(shape),
@@ -538,19 +581,25 @@ def main():
                 "frac_moved": (rl_moved / rl_iter_s / 1e9 / HBM_PEAK_GBS) if rl_moved else None,
             },
             "roofline_deskew": {
-                "kernel": "deskew_pers_kernel (fused shear-interpolate + N-mean + fill prologue; persistent, double-buffered LDS, "
-                          "loader / sampler wavefronts)",
+                # the PAIR: everything bh_deskew launches for "deskew with a mean fill" — geometry bits, the fill value from the
+                # row sums R-L's last pass left behind, deskew_pers_kernel<3, 2> writing whole rows (fill included), and the
+                # conditional mask pipeline behind it (returns at once unless the data held exact zeros)
+                "kernel": "deskew + overhang fill as one pass: deskew_pers_kernel<NK, 2> (fused shear-interpolate + N-mean, whole rows "
+                          "incl. the fill value; persistent, double-buffered LDS, loader wavefronts also write the overhang tiles) + "
+                          "csrc/deskew_rows.inc (geometry bits, mean from row sums) + the conditional mask pipeline",
                 "bound": "hbm",
-                "achieved": dk_bytes / deskew_s / 1e9,
+                "achieved": dk_bytes / pair_s / 1e9,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": dk_bytes / deskew_s / 1e9 / HBM_PEAK_GBS,
+                "frac": dk_bytes / pair_s / 1e9 / HBM_PEAK_GBS,
                 "traffic": dk_moved,
                 "traffic_source": dk_src,
-                "frac_moved": (dk_moved / deskew_s / 1e9 / HBM_PEAK_GBS) if dk_moved else None,
+                "frac_moved": (dk_moved / pair_s / 1e9 / HBM_PEAK_GBS) if dk_moved else None,
                 "algorithmic_bytes": dk_bytes,
-                "ms": deskew_s * 1e3,
+                "ms": pair_s * 1e3,
+                "deskew_ms": deskew_s * 1e3,
                 "fill_passes_ms": fill_s * 1e3,
+                "row_sums": "from the last Richardson-Lucy update pass (bh_richardson_lucy_apply_rows)",
             },
             "workspace_gb": ctx.workspace_bytes() / 1e9,
             "alloc_layout": __import__("biahub_amd.device", fromlist=["alloc_layout"]).alloc_layout(),

@@ -75,6 +75,7 @@ SIGNATURES = {
     "bh_richardson_lucy": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _f32, _vp]),
     "bh_richardson_lucy_create": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, C.POINTER(_vp)]),
     "bh_richardson_lucy_apply": (_int, [_vp, _vp, _vp, _int, _f32, _vp]),
+    "bh_richardson_lucy_apply_rows": (_int, [_vp, _vp, _vp, _int, _f32, _vp, _vp, C.POINTER(_int)]),
     "bh_richardson_lucy_destroy": (_int, [_vp]),
     "bh_richardson_lucy_info": (_int, [_vp, C.POINTER(_i64), C.POINTER(_int), C.POINTER(_int), C.POINTER(C.c_uint64)]),
     "bh_alloc_layout": (_int, [C.POINTER(_int), C.POINTER(_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -446,6 +446,8 @@ struct ConvPlan;
 bool fftconv_supported(int64_t Z, int64_t Y, int64_t X);
 bool fftconv_supported_ex(int64_t Z, int64_t Y, int64_t X, bool radix3);
 bool fftconv_rows_wave_private(int64_t Y, int64_t X);
+void fftconv_arm_rowsums(ConvPlan& pl, double* dst);
+bool fftconv_rowsums_taken(ConvPlan& pl);
 int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out);
 size_t fftconv_spectrum_elems(const ConvPlan& pl);
 int fftconv_plan_tag(const ConvPlan& pl);
@@ -1222,7 +1224,14 @@ int bh_richardson_lucy_create(bh_ctx* ctx, const float* psf, int64_t pz, int64_t
 }
 
 int bh_richardson_lucy_apply(bh_ctx* ctx, const bh_rl* h, const float* in, int iterations, float eps, float* out) {
+    return bh_richardson_lucy_apply_rows(ctx, h, in, iterations, eps, out, nullptr, nullptr);
+}
+
+int bh_richardson_lucy_apply_rows(bh_ctx* ctx, const bh_rl* h, const float* in, int iterations, float eps, float* out,
+                                  double* row_sums, int* produced) {
+    if (produced) *produced = 0;
     BH_REQUIRE(ctx && h && in && out, "NULL argument");
+    BH_REQUIRE(row_sums == nullptr || produced != nullptr, "row_sums needs `produced`");
     BH_REQUIRE(iterations >= 0, "iterations must be >= 0");
     BH_REQUIRE(ctx->device == h->device, "the handle belongs to device %d, the context to device %d", h->device, ctx->device);
     BH_CHECK_HIP(hipSetDevice(ctx->device));
@@ -1243,7 +1252,13 @@ int bh_richardson_lucy_apply(bh_ctx* ctx, const bh_rl* h, const float* in, int i
         return BH_OK;
     }
     ScopedTimer timer(ctx, T_RL_TOTAL);
-    if (h->backend == BH_RL_ENGINE) return rl_engine_run(ctx, h->plan, d, h->otf, h->otf_real, iterations, eps, out);
+    if (h->backend == BH_RL_ENGINE) {
+        // the last update pass can leave the row sums of its result behind (what a deskew with a mean fill wants of this volume)
+        if (row_sums) fftconv_arm_rowsums(*h->plan, row_sums);
+        const int st = rl_engine_run(ctx, h->plan, d, h->otf, h->otf_real, iterations, eps, out);
+        if (row_sums) *produced = fftconv_rowsums_taken(*h->plan) && st == BH_OK ? 1 : 0;
+        return st;
+    }
     return rl_padded_run(ctx, h->plan, d, h->otf, h->otf_real, h->N, h->K, h->box, iterations, eps, out);
 }
 

@@ -23,6 +23,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace bh {
@@ -98,10 +99,14 @@ __device__ __forceinline__ float div_small(float a, float n, float rn) {
 // J = outputs per lane per row, so one wave covers the whole XC = 64*J output chunk and the NT/64
 // waves take different rows.  LDS tile is [k][z][TX+1]: the odd row pitch makes both the staging
 // stores (lanes along x) and the compute loads (lanes along z) bank-conflict free.
-template <typename TIN, int TX, int J, int NK, int NT, bool DMA, bool FILL>
+// FILLM: 0 no fill; 1 the fused prologue of the mask pipeline (zero-mask bits + block sums, zeros not stored); 2 the one-pass
+// fill (see deskew_pers_kernel below: the fill value is final in *g.st, whole rows are written, the dilated geometric zero
+// pattern g.dgbits says where the fill value goes, an exact zero outside g.gbits raises g.st->fallback).
+template <typename TIN, int TX, int J, int NK, int NT, bool DMA, int FILLM>
 __global__ __launch_bounds__(NT) void deskew_kernel(const TIN* __restrict__ in, float* __restrict__ out,
                                                     DeskewGeom g) {
 #pragma clang fp contract(off)
+    constexpr bool FILL = FILLM == 1, ROWS = FILLM == 2;
     constexpr int XC = 64 * J;
     constexpr int PITCH = TX + 1;
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [N][ZC][PITCH]
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(NT) void deskew_kernel(const TIN* __restrict__ in, 
                     if (lane0 == 0 && xo0 + 64 * j < g.Xp)
                         *reinterpret_cast<unsigned long long*>(g.mask0 + orow_i * g.W32 + (xo0 + 64 * j) / 32) = bits;
                 } else if (xo < g.Xp) {
-                    orow[xo] = 0.0f;
+                    orow[xo] = ROWS ? g.st->fill : 0.0f;
                 }
             }
         }
@@ -260,6 +265,19 @@ __global__ __launch_bounds__(NT) void deskew_kernel(const TIN* __restrict__ in, 
     const float fN = (float)N;
     const float rN = 1.0f / fN;
     double tsum = 0.0;
+    // ROWS: this lane's bits of the geometric zero pattern and of its dilation (the same for every row of the plane)
+    bool gz[J], dgz[J];
+    float fillv = 0.0f, zmin = 1.0f;
+    if (ROWS) {
+        fillv = g.st->fill;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int xo = min(xbase + 64 * j, g.Xp - 1);
+            const size_t wi = (size_t)a * g.WB + (xo >> 5);
+            gz[j] = (g.gbits[wi] >> (xo & 31)) & 1u;
+            dgz[j] = (g.dgbits[wi] >> (xo & 31)) & 1u;
+        }
+    }
     for (int xl = wave; xl < TX; xl += NT / 64) {
         const int x = xt0 + xl;
         if (x >= g.X) break;
@@ -312,11 +330,17 @@ __global__ __launch_bounds__(NT) void deskew_kernel(const TIN* __restrict__ in, 
                     orow[xo] = val;
                     tsum += (double)val;
                 }
+            } else if (ROWS) {
+                if (xo < g.Xp) {
+                    if (!gz[j]) zmin = fminf(zmin, fabsf(val));  // an exact zero that geometry does not explain: a data zero
+                    orow[xo] = dgz[j] ? fillv : val;
+                }
             } else if (xo < g.Xp) {
                 orow[xo] = val;
             }
         }
     }
+    if (ROWS && __ballot(zmin == 0.0f) != 0ull && lane == 0) atomicOr(&g.st->fallback, 1);
     if (FILL) {
         __shared__ double wsum[NT / 64];
 #pragma unroll
@@ -440,7 +464,7 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
         }
     };
     // LDS-DMA of a tile's z window into buffer b: one 256-byte row segment per instruction, rows outside [0, Z) zero-filled
-    auto stage = [&](const Tile& q, int b) {
+    auto stage = [&](const Tile& q, int b, bool wait = true) {
         if (SPLIT && !loader) return;
         float* base = tile + b * bufstride;
         const int za = max(0, -q.zlo), zb = min(q.zcnt, g.Z - q.zlo);
@@ -467,7 +491,16 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
         }
         // landed before this wavefront reaches the barrier that publishes the buffer (unsplit: waited for at the barrier instead,
         // behind the sampling of the current tile)
-        if (SPLIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (SPLIT && wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // ROWS: the loaders issue the next tile's LDS-DMA first, then their quota of overhang rows, and wait for the DMA alone: loads
+    // and stores retire through one in-order counter, so "all but the n youngest" with n = the store instructions issued since
+    // (a lower bound of them: waiting for a store or two too many is harmless, for a load too few would not be)
+    auto wait_dma_behind = [&](int nstores) {
+        if (nstores >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+        else if (nstores >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (nstores >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     // next tile of this workgroup that needs staging; overhang tiles on the way are finished on the spot
     // A workgroup walks a CONTIGUOUS range of tiles: x tiles run fastest, so 32 consecutive tiles share their (a, x'-chunk)
@@ -490,8 +523,11 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
     long zt = t_begin - 1;
     int zrow = TX;
     Tile zq = {};
-    auto emit = [&](int quota) {
+    // returns how many rows went out as ONE full 16-byte store instruction (a lower bound of the store instructions issued: a row
+    // of the ragged last x' chunk issues between none and five)
+    auto emit = [&](int quota) -> int {
         typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        int full = 0;
         for (int n = 0; n < quota; ++n) {
             if (zrow >= TX) {
                 for (++zt; zt < t_end; ++zt) {
@@ -500,14 +536,17 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
                 }
                 if (zt >= t_end) {
                     zt = t_end;  // stays exhausted
-                    return;
+                    return full;
                 }
                 zrow = lwave;
             }
             const size_t orow_i = (size_t)zq.a * g.X + (g.X - 1 - (zq.xt0 + zrow));
             float* orow = out + orow_i * g.Xp;
             const int xo = zq.xo0 + 4 * lane;
-            if (xo + 3 < g.Xp) {
+            if (zq.xo0 + XC <= g.Xp) {  // (wave-uniform) a whole chunk: one instruction
+                *reinterpret_cast<f4u*>(orow + xo) = f4u{fillv, fillv, fillv, fillv};
+                ++full;
+            } else if (xo + 3 < g.Xp) {
                 *reinterpret_cast<f4u*>(orow + xo) = f4u{fillv, fillv, fillv, fillv};
             } else {
 #pragma unroll
@@ -516,9 +555,11 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
             }
             zrow += NLD;
         }
+        return full;
     };
 #ifndef BH_DK_QUOTA
-#define BH_DK_QUOTA 48  // rows per loader and tile interval (the overhang is ~1.2 tiles = 75 rows per sampled tile at config 2)
+#define BH_DK_QUOTA 48  // rows per loader and tile interval (the overhang is ~1.2 tiles = 75 rows per sampled tile at config 2); <= 48:
+                        // the wait below counts them in vmcnt (6 bits)
 #endif
     static_assert(!ROWS || SPLIT, "the one-pass fill needs loader wavefronts");
     float zmin = 1.0f;  // ROWS: smallest |output| outside the geometric zero pattern seen by this lane
@@ -535,8 +576,12 @@ __global__ __launch_bounds__(512) void deskew_pers_kernel(const float* __restric
         if (!SPLIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // the loaders' DMA of this tile has landed; the samplers have finished with the other buffer
         const long nxt = advance(cur);
-        if (ROWS && loader) emit(BH_DK_QUOTA);
-        if (nxt < t_end) stage(tile_of(nxt), b ^ 1);
+        if (ROWS && loader) {
+            if (nxt < t_end) stage(tile_of(nxt), b ^ 1, false);
+            wait_dma_behind(emit(BH_DK_QUOTA));
+        } else if (nxt < t_end) {
+            stage(tile_of(nxt), b ^ 1);
+        }
         if (loader) {
             cur = nxt;
             b ^= 1;
@@ -745,7 +790,7 @@ static int max_window(const DeskewGeom& g, int XC) {
 }
 
 template <typename TIN, int TX, int J, int NT, bool DMA>
-static int launch_deskew_cfg(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g, bool fill, int* nblocks) {
+static int launch_deskew_cfg(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g, int fill, int* nblocks) {  // fill: FILLM
     constexpr int XC = 64 * J;
     g.XC = XC;
     g.ZC = max_window(g, XC);
@@ -758,7 +803,7 @@ static int launch_deskew_cfg(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom 
     BH_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "deskew grid too large (%u,%u,%u)", grid.x, grid.y, grid.z);
     const size_t nblk = (size_t)grid.x * grid.y * grid.z;
     if (nblocks) *nblocks = (int)nblk;
-    if (fill) {
+    if (fill == 1) {
         BH_REQUIRE(nblk < (1ull << 31), "deskew grid too large for the fused fill");
         BH_TRY(get_scratch(ctx, "fill_pall", nblk * sizeof(double), (void**)&g.psum));
     }
@@ -770,13 +815,17 @@ static int launch_deskew_cfg(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom 
         BH_CHECK_HIP(hipGetLastError());
         return BH_OK;
     };
+#define BH_DK_CASE(NKV)                                                                    \
+    return fill == 2 ? run(deskew_kernel<TIN, TX, J, NKV, NT, DMA, 2>)                      \
+                     : (fill == 1 ? run(deskew_kernel<TIN, TX, J, NKV, NT, DMA, 1>) : run(deskew_kernel<TIN, TX, J, NKV, NT, DMA, 0>))
     switch (g.N) {
-        case 1: return fill ? run(deskew_kernel<TIN, TX, J, 1, NT, DMA, true>) : run(deskew_kernel<TIN, TX, J, 1, NT, DMA, false>);
-        case 2: return fill ? run(deskew_kernel<TIN, TX, J, 2, NT, DMA, true>) : run(deskew_kernel<TIN, TX, J, 2, NT, DMA, false>);
-        case 3: return fill ? run(deskew_kernel<TIN, TX, J, 3, NT, DMA, true>) : run(deskew_kernel<TIN, TX, J, 3, NT, DMA, false>);
-        case 4: return fill ? run(deskew_kernel<TIN, TX, J, 4, NT, DMA, true>) : run(deskew_kernel<TIN, TX, J, 4, NT, DMA, false>);
-        default: return fill ? run(deskew_kernel<TIN, TX, J, 0, NT, DMA, true>) : run(deskew_kernel<TIN, TX, J, 0, NT, DMA, false>);
+        case 1: BH_DK_CASE(1);
+        case 2: BH_DK_CASE(2);
+        case 3: BH_DK_CASE(3);
+        case 4: BH_DK_CASE(4);
+        default: BH_DK_CASE(0);
     }
+#undef BH_DK_CASE
 }
 
 // LDS bytes of a (TX, J) configuration for this geometry
@@ -824,13 +873,9 @@ int launch_deskew_pers<float>(bh_ctx* ctx, const float* in, float* out, DeskewGe
     }
 }
 
-// The one-pass fill (deskew_rows.inc + deskew_pers_kernel<NK, 2>): float32 volumes the persistent kernel takes.  *taken stays false
-// when the shape does not qualify (the mask pipeline then runs unconditionally).  row_sums: optional float64 [Z * Y] row sums of
-// `in` on the device (an operator that has just produced `in` can hand them over), else they are reduced here.
-static int launch_deskew_rows(bh_ctx* ctx, const float* in, float* out, DeskewGeom g, int fill_mode, float fill_value,
-                              const double* row_sums, FillStats* st, bool* taken) {
+// the persistent kernel in its one-pass form (g.gbits / g.dgbits / g.st set by launch_deskew_rows)
+static int launch_deskew_rows_pers(bh_ctx* ctx, const float* in, float* out, DeskewGeom g, bool* taken) {
     *taken = false;
-    if (getenv("BH_DESKEW_ONEPASS") && atoi(getenv("BH_DESKEW_ONEPASS")) == 0) return BH_OK;
     if (g.N < 1 || g.N > 4 || (g.X % 64) != 0) return BH_OK;
     constexpr int XC = 256, TX = 64;
     g.XC = XC;
@@ -841,36 +886,9 @@ static int launch_deskew_rows(bh_ctx* ctx, const float* in, float* out, DeskewGe
     const int ntx = g.X / TX, nxc = (int)ceil_div(g.Xp, XC);
     const long ntiles = (long)g.Za * nxc * ntx;
     const int grid = (int)std::min<long>(ntiles, ctx->num_cus);
-    hipStream_t s = ctx->stream;
-    const int WB = (int)ceil_div(g.Xp, 32);
-    uint32_t *gb, *dgb;
-    double* psum;
-    unsigned long long* pcnt;
-    BH_TRY(get_scratch(ctx, "dk_gbits", (size_t)g.Za * WB * 4, (void**)&gb));
-    BH_TRY(get_scratch(ctx, "dk_dgbits", (size_t)g.Za * WB * 4, (void**)&dgb));
-    BH_TRY(get_scratch(ctx, "dk_psum", (size_t)g.Za * sizeof(double), (void**)&psum));
-    BH_TRY(get_scratch(ctx, "dk_pcnt", (size_t)g.Za * sizeof(unsigned long long), (void**)&pcnt));
-    const int nw = g.Za * WB;
-    hipLaunchKernelGGL(rows::geom_bits_kernel<0>, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, s, g, gb, WB);
-    hipLaunchKernelGGL(rows::dilate_bits_kernel, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, s, gb, dgb, g.Za, g.Xp, WB, 3);
-    if (fill_mode == BH_FILL_MEAN) {
-        if (row_sums == nullptr) {
-            double* R;
-            BH_TRY(get_scratch(ctx, "dk_rowsums", (size_t)g.Z * g.Y * sizeof(double), (void**)&R));
-            hipLaunchKernelGGL(rows::row_sums_kernel<float>, dim3((unsigned)(ctx->num_cus * 8)), dim3(256), 0, s, in, R, (long)g.Z * g.Y, g.X);
-            row_sums = R;
-        }
-        hipLaunchKernelGGL(rows::mean_partial_kernel, dim3((unsigned)g.Za), dim3(256), 0, s, g, dgb, WB, row_sums, psum, pcnt);
-    }
-    hipLaunchKernelGGL(rows::mean_final_kernel, dim3(1), dim3(256), 0, s, psum, pcnt, g.Za, g.N, (long)g.X,
-                       (long)g.Za * g.X * g.Xp, fill_mode, fill_value, st);
-    g.gbits = gb;
-    g.dgbits = dgb;
-    g.WB = WB;
-    g.st = st;
     auto run = [&](auto kern) -> int {
         BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, in, out, g, ntx, nxc);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, ctx->stream, in, out, g, ntx, nxc);
         BH_CHECK_HIP(hipGetLastError());
         return BH_OK;
     };
@@ -884,10 +902,10 @@ static int launch_deskew_rows(bh_ctx* ctx, const float* in, float* out, DeskewGe
 }
 
 template <typename TIN>
-static int launch_deskew(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g, bool fill, int* nblocks) {
-    {
+static int launch_deskew(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g, int fill, int* nblocks) {  // fill: FILLM of the kernels
+    if (fill != 2) {
         bool taken = false;
-        BH_TRY(launch_deskew_pers<TIN>(ctx, in, out, g, fill, nblocks, &taken));
+        BH_TRY(launch_deskew_pers<TIN>(ctx, in, out, g, fill != 0, nblocks, &taken));
         if (taken) return BH_OK;
     }
     // Candidates (TX, J, threads, LDS-DMA staging) from fastest measured (profiles/, tools/tune_deskew.py:
@@ -912,6 +930,54 @@ static int launch_deskew(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g, b
         case 3: return launch_deskew_cfg<TIN, 64, 1, 256, true>(ctx, in, out, g, fill, nblocks);
         default: return launch_deskew_cfg<TIN, 32, 1, 256, false>(ctx, in, out, g, fill, nblocks);
     }
+}
+
+// The one-pass fill (deskew_rows.inc): geometry bits, the fill value from the row sums of the input, then ONE resampling kernel
+// that writes whole rows — the tile kernel (any dtype, any shape) or the persistent kernel (float32, whole 64-column tiles,
+// N <= 4: BH_DESKEW_ROWS_KERNEL=pers; measured slower at config 2, 6.3 against 5.2 ms: two loader wavefronts per CU write the
+// 9 GB of overhang tiles there, whole workgroups here).  row_sums: optional float64 [Z * Y] row sums of `in` on the device (an
+// operator that has just produced `in` can hand them over), else they are reduced here in one read of `in`.
+template <typename TIN>
+static int launch_deskew_rows(bh_ctx* ctx, const TIN* in, float* out, DeskewGeom g, int fill_mode, float fill_value,
+                              const double* row_sums, FillStats* st, bool* taken) {
+    *taken = false;
+    if (getenv("BH_DESKEW_ONEPASS") && atoi(getenv("BH_DESKEW_ONEPASS")) == 0) return BH_OK;
+    hipStream_t s = ctx->stream;
+    const int WB = (int)ceil_div(g.Xp, 32);
+    uint32_t *gb, *dgb;
+    double* psum;
+    unsigned long long* pcnt;
+    BH_TRY(get_scratch(ctx, "dk_gbits", (size_t)g.Za * WB * 4, (void**)&gb));
+    BH_TRY(get_scratch(ctx, "dk_dgbits", (size_t)g.Za * WB * 4, (void**)&dgb));
+    BH_TRY(get_scratch(ctx, "dk_psum", (size_t)g.Za * sizeof(double), (void**)&psum));
+    BH_TRY(get_scratch(ctx, "dk_pcnt", (size_t)g.Za * sizeof(unsigned long long), (void**)&pcnt));
+    const int nw = g.Za * WB;
+    hipLaunchKernelGGL(rows::geom_bits_kernel<0>, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, s, g, gb, WB);
+    hipLaunchKernelGGL(rows::dilate_bits_kernel, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, s, gb, dgb, g.Za, g.Xp, WB, 3);
+    if (fill_mode == BH_FILL_MEAN) {
+        if (row_sums == nullptr) {
+            double* R;
+            BH_TRY(get_scratch(ctx, "dk_rowsums", (size_t)g.Z * g.Y * sizeof(double), (void**)&R));
+            hipLaunchKernelGGL(rows::row_sums_kernel<TIN>, dim3((unsigned)(ctx->num_cus * 8)), dim3(256), 0, s, in, R, (long)g.Z * g.Y, g.X);
+            row_sums = R;
+        }
+        hipLaunchKernelGGL(rows::mean_partial_kernel, dim3((unsigned)g.Za), dim3(256), 0, s, g, dgb, WB, row_sums, psum, pcnt);
+    }
+    hipLaunchKernelGGL(rows::mean_final_kernel, dim3(1), dim3(256), 0, s, psum, pcnt, g.Za, g.N, (long)g.X,
+                       (long)g.Za * g.X * g.Xp, fill_mode, fill_value, st);
+    BH_CHECK_HIP(hipGetLastError());
+    g.gbits = gb;
+    g.dgbits = dgb;
+    g.WB = WB;
+    g.st = st;
+    *taken = true;
+    const char* kern = getenv("BH_DESKEW_ROWS_KERNEL");
+    if (kern && strcmp(kern, "pers") == 0 && std::is_same<TIN, float>::value) {
+        bool pers = false;
+        BH_TRY(launch_deskew_rows_pers(ctx, reinterpret_cast<const float*>(in), out, g, &pers));
+        if (pers) return BH_OK;
+    }
+    return launch_deskew(ctx, in, out, g, 2, nullptr);
 }
 
 int fill_overhang_impl(bh_ctx* ctx, float* data, int64_t Z, int64_t Y, int64_t X, int fill_mode,
@@ -984,21 +1050,29 @@ int bh_deskew_rows(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t
     // does not explain): every kernel of it returns at once otherwise.
     bool onepass = false;
     bh::FillStats* st = nullptr;
-    if (do_fill && in_dtype == BH_DT_F32) {
+    if (do_fill) {
         BH_TRY(bh::get_scratch(ctx, "fill_stats", sizeof(bh::FillStats), (void**)&st));
         bh::ScopedTimer t(ctx, bh::T_DESKEW);
-        BH_TRY(bh::launch_deskew_rows(ctx, (const float*)in, out, g, fill_mode, fill_value, row_sums, st, &onepass));
+        switch (in_dtype) {
+            case BH_DT_F32: BH_TRY(bh::launch_deskew_rows(ctx, (const float*)in, out, g, fill_mode, fill_value, row_sums, st, &onepass)); break;
+            case BH_DT_U16: BH_TRY(bh::launch_deskew_rows(ctx, (const uint16_t*)in, out, g, fill_mode, fill_value, row_sums, st, &onepass)); break;
+            case BH_DT_U8: BH_TRY(bh::launch_deskew_rows(ctx, (const uint8_t*)in, out, g, fill_mode, fill_value, row_sums, st, &onepass)); break;
+            case BH_DT_I16: BH_TRY(bh::launch_deskew_rows(ctx, (const int16_t*)in, out, g, fill_mode, fill_value, row_sums, st, &onepass)); break;
+            default: BH_REQUIRE(false, "unsupported input dtype code %d", in_dtype);
+        }
     }
     if (onepass) g.enable = &st->fallback;
     ctx->deskew_path = onepass ? 1 : 0;
     if (!onepass) {
-        bh::ScopedTimer t(ctx, bh::T_DESKEW);
-        switch (in_dtype) {
-            case BH_DT_F32: BH_TRY(bh::launch_deskew(ctx, (const float*)in, out, g, do_fill, &nblocks)); break;
-            case BH_DT_U16: BH_TRY(bh::launch_deskew(ctx, (const uint16_t*)in, out, g, do_fill, &nblocks)); break;
-            case BH_DT_U8: BH_TRY(bh::launch_deskew(ctx, (const uint8_t*)in, out, g, do_fill, &nblocks)); break;
-            case BH_DT_I16: BH_TRY(bh::launch_deskew(ctx, (const int16_t*)in, out, g, do_fill, &nblocks)); break;
-            default: BH_REQUIRE(false, "unsupported input dtype code %d", in_dtype);
+        {
+            bh::ScopedTimer t(ctx, bh::T_DESKEW);
+            switch (in_dtype) {
+                case BH_DT_F32: BH_TRY(bh::launch_deskew(ctx, (const float*)in, out, g, do_fill ? 1 : 0, &nblocks)); break;
+                case BH_DT_U16: BH_TRY(bh::launch_deskew(ctx, (const uint16_t*)in, out, g, do_fill ? 1 : 0, &nblocks)); break;
+                case BH_DT_U8: BH_TRY(bh::launch_deskew(ctx, (const uint8_t*)in, out, g, do_fill ? 1 : 0, &nblocks)); break;
+                case BH_DT_I16: BH_TRY(bh::launch_deskew(ctx, (const int16_t*)in, out, g, do_fill ? 1 : 0, &nblocks)); break;
+                default: BH_REQUIRE(false, "unsupported input dtype code %d", in_dtype);
+            }
         }
         if (do_fill) {
             // the deskew kernel already produced the zero mask and the block sums (and skipped storing zeros)
@@ -1009,7 +1083,12 @@ int bh_deskew_rows(bh_ctx* ctx, const void* in, int in_dtype, int64_t Z, int64_t
     } else {
         // T_FILL times the conditional pass: a dozen launches that return at once unless the flag is up
         bh::ScopedTimer t(ctx, bh::T_FILL);
-        BH_TRY(bh::launch_deskew(ctx, (const float*)in, out, g, true, &nblocks));
+        switch (in_dtype) {
+            case BH_DT_F32: BH_TRY(bh::launch_deskew(ctx, (const float*)in, out, g, 1, &nblocks)); break;
+            case BH_DT_U16: BH_TRY(bh::launch_deskew(ctx, (const uint16_t*)in, out, g, 1, &nblocks)); break;
+            case BH_DT_U8: BH_TRY(bh::launch_deskew(ctx, (const uint8_t*)in, out, g, 1, &nblocks)); break;
+            default: BH_TRY(bh::launch_deskew(ctx, (const int16_t*)in, out, g, 1, &nblocks)); break;
+        }
         BH_TRY(bh::fill_overhang_impl(ctx, out, os[0], os[1], os[2], fill_mode, fill_value, 3, mean_out, nblocks, 26, g.enable));
     }
     return BH_OK;

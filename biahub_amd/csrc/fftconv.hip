@@ -84,6 +84,28 @@ __device__ __forceinline__ cf cmulc(cf a, cf b) {  // a * conj(b)
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 #endif
 }
+// a - i b and a + i b as ONE packed add each: v_pk_add_f32 takes either half of each source for each half of the result and can
+// negate it.  The compiler's own lowering materialises (-i) b with two moves first — a fifth of the register FFT stages'
+// instructions were such moves (fftconv_xw.inc reg_fft, fftconv_colz.inc fwd8p / inv8p fold every rotation by -i / +i into
+// the add or subtract that consumes it).
+__host__ __device__ __forceinline__ cf add_mi(cf a, cf b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    v2f_t av = {a.x, a.y}, bv = {b.x, b.y}, r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(av), "v"(bv));
+    return make_float2(r.x, r.y);
+#else
+    return make_float2(a.x + b.y, a.y - b.x);
+#endif
+}
+__host__ __device__ __forceinline__ cf add_pi(cf a, cf b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    v2f_t av = {a.x, a.y}, bv = {b.x, b.y}, r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(av), "v"(bv));
+    return make_float2(r.x, r.y);
+#else
+    return make_float2(a.x - b.y, a.y + b.x);
+#endif
+}
 __device__ __forceinline__ cf cconj(cf a) { return make_float2(a.x, -a.y); }
 __device__ __forceinline__ cf mul_mi(cf a) { return make_float2(a.y, -a.x); }  // a * (-i)
 __device__ __forceinline__ cf mul_pi(cf a) { return make_float2(-a.y, a.x); }  // a * (+i)
@@ -831,6 +853,10 @@ struct ConvPlan {
     int xr = BH_FC_XR;                        // rows per X-pass tile: which instantiation of the X passes runs
     // wave-private X passes (fftconv_xw.inc) for rows of 1024 / 2048 voxels: their tables, and the stored column of every
     // bit-reversed position (they keep the spectrum row in their own column order)
+    // set by bh_richardson_lucy_apply_rows for the duration of one call: where the LAST update pass leaves the row sums of the
+    // estimate it stores (xw::Params::rowsum); rl_rowsums_done says that a pass took it
+    double* rl_rowsums = nullptr;
+    bool rl_rowsums_done = false;
     bool xw = false;
     bool x3 = false;  // rows of 1536 / 3072 voxels: the radix-3 kernels of fftconv_x3.inc (same role, tables and column map)
     cf* xw_tab = nullptr;
@@ -1034,6 +1060,18 @@ int fftconv_plan(bh_ctx* ctx, int64_t Z, int64_t Y, int64_t X, ConvPlan** out) {
 }
 
 int fftconv_plan_tag(const ConvPlan& pl) { return pl.xw ? 1 : 0; }
+// the last update pass of the next fftconv_richardson_lucy leaves the float64 row sums of its result at `dst` (wave-private X
+// passes of 512 / 1024 / 2048-voxel rows only); fftconv_rowsums_taken says whether a pass did, and disarms the plan
+void fftconv_arm_rowsums(ConvPlan& pl, double* dst) {
+    pl.rl_rowsums = dst;
+    pl.rl_rowsums_done = false;
+}
+bool fftconv_rowsums_taken(ConvPlan& pl) {
+    const bool done = pl.rl_rowsums_done;
+    pl.rl_rowsums = nullptr;
+    pl.rl_rowsums_done = false;
+    return done;
+}
 
 size_t fftconv_spectrum_elems(const ConvPlan& pl) {
     return (size_t)pl.d.Z * pl.d.Y * pl.d.XP + 64;  // slack: a ragged last column tile reads past its row
@@ -1259,6 +1297,7 @@ static int launch_xw(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, con
                      const float* aux, float eps, bool fuse_fwd, const double* norm_mean = nullptr) {
     xw::Params p;
     p.norm_mean = norm_mean;
+    p.rowsum = nullptr;
     p.S_out = nullptr;
     p.wz = p.wx = xw::Params::Wrap{0, 0, 0, 0};
     p.in = in;
@@ -1275,6 +1314,10 @@ static int launch_xw(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, con
                      : epi == XE_STORE ? xw::INV_STORE
                      : epi == XE_RATIO ? (fuse_fwd ? xw::FUSED_RATIO : xw::INV_RATIO)
                                        : (fuse_fwd ? xw::FUSED_UPDATE : xw::INV_UPDATE);
+    if (mode == xw::INV_UPDATE && !pl.x3 && pl.rl_rowsums != nullptr) {
+        p.rowsum = pl.rl_rowsums;
+        const_cast<ConvPlan&>(pl).rl_rowsums_done = true;
+    }
     if (pl.x3) return pl.d.M == 1536 ? launch_x3_m<9>(ctx, p, mode) : launch_x3_m<8>(ctx, p, mode);
     return pl.d.M == 1024 ? launch_xw_m<10>(ctx, p, mode) : (pl.d.M == 512 ? launch_xw_m<9>(ctx, p, mode) : launch_xw_m<8>(ctx, p, mode));
 }
@@ -1283,6 +1326,7 @@ static int launch_xw(bh_ctx* ctx, const ConvPlan& pl, bool inverse, int epi, con
 static int launch_xw_argmax(bh_ctx* ctx, const ConvPlan& pl, cf* S, ArgMax* partial, int* npartial) {
     xw::Params p;
     p.norm_mean = nullptr;
+    p.rowsum = nullptr;
     p.S_out = nullptr;
     p.wz = p.wx = xw::Params::Wrap{0, 0, 0, 0};
     p.in = nullptr;
@@ -1661,6 +1705,7 @@ static int launch_x3_wrap(bh_ctx* ctx, const ConvPlan& pl, int mode, const cf* S
                           float eps, xw::Params::Wrap wz, xw::Params::Wrap wx) {
     xw::Params p;
     p.norm_mean = nullptr;
+    p.rowsum = nullptr;
     p.in = nullptr;
     p.S = const_cast<cf*>(S_in);
     p.S_out = S_out;

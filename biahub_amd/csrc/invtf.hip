@@ -78,14 +78,15 @@ __global__ void sum_finish_kernel(double* part, int nblocks, int64_t n) {
 }
 // padded[z + pad] = n(x)[z], n(x) = normalise ? x / mean - 1 : x.  The padding planes follow waveorder 3.0.5's
 // util.pad_zyx_along_z (recalled; parity unpinned): with z_padding < Z they mirror the volume's own edge planes (plane pad - 1 - z
-// below, plane Z - 1 - k for the k-th plane above), otherwise they are constant 0.
+// below, plane Z - 1 - k for the k-th plane above), otherwise they are constant 0.  UNVERIFIED against waveorder (absent from
+// the reference tree): BH_INVTF_ZPAD=zeros restores constant-zero pad planes (the rounds-1-2 behaviour), read per call.
 __global__ __launch_bounds__(256) void normalize_pad_kernel(const float* __restrict__ x, float* __restrict__ padded, int64_t nin,
                                                             int64_t plane, int64_t pad, int64_t ntotal,
-                                                            const double* __restrict__ mean, int normalize) {
+                                                            const double* __restrict__ mean, int normalize, int mirror_planes) {
     const float inv = normalize ? (float)(1.0 / *mean) : 1.0f;
     const float sub = normalize ? 1.0f : 0.0f;
     const int64_t Z = nin / plane;
-    const bool mirror = pad < Z;
+    const bool mirror = pad < Z && mirror_planes;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ntotal; i += (int64_t)gridDim.x * 256) {
         const int64_t zp = i / plane, r = i - zp * plane;
         int64_t z = zp - pad;
@@ -279,8 +280,10 @@ static int inverse_filter_apply_impl(bh_ctx* ctx, const bh_filter* f, const floa
     if (staged_input) {
         BH_TRY(get_scratch(ctx, "itf_padded", Vp * sizeof(float), (void**)&padded));
         if (!part) BH_TRY(get_scratch(ctx, "itf_partials", (nb + 1) * sizeof(double), (void**)&part));
+        const char* zp = getenv("BH_INVTF_ZPAD");
+        const int mirror_planes = !(zp && strcmp(zp, "zeros") == 0);
         hipLaunchKernelGGL(normalize_pad_kernel, grid_for(ctx, Vp), dim3(256), 0, s, in, padded, V, plane, z_padding, Vp,
-                           (const double*)(part + nb), normalize ? 1 : 0);
+                           (const double*)(part + nb), normalize ? 1 : 0, mirror_planes);
         BH_CHECK_HIP(hipGetLastError());
         src = padded;
     }

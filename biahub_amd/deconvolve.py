@@ -174,16 +174,31 @@ class PreparedRichardsonLucy:
         self.otf_is_real = bool(is_real.value)
         self.otf_bytes = int(nbytes.value)
 
-    def __call__(self, zyx, iterations: int = 10, eps: float = 1e-6, out: torch.Tensor | None = None) -> torch.Tensor:
+    def __call__(self, zyx, iterations: int = 10, eps: float = 1e-6, out: torch.Tensor | None = None,
+                 row_sums: torch.Tensor | None = None):
+        """The deconvolved volume.  With ``row_sums`` (a float64 ``(Z, Y)`` device tensor) the call returns
+        ``(volume, row_sums or None)``: the last update pass also reduces ``sum over x`` of every row it stores when the back-end
+        can (``None`` comes back when it cannot) — hand them to ``fast_deskew_zyx(..., row_sums=...)`` and its overhang fill
+        needs no pass of its own over the volume."""
+        import ctypes
+
         d, _ = _f32_device(zyx, self.device)
         if tuple(d.shape) != self.shape:
             raise ValueError(f"volume shape {tuple(d.shape)} != the shape this handle was prepared for {self.shape}")
+        if row_sums is not None and (row_sums.dtype != torch.float64 or tuple(row_sums.shape) != self.shape[:2]
+                                     or not row_sums.is_contiguous() or row_sums.device != d.device):
+            raise ValueError("row_sums must be a contiguous float64 (Z, Y) tensor on the volume's device")
         ctx = get_context(self.device)
         with torch.cuda.device(self.device):
             if out is None:
                 out = device_empty_like(d)
-            _lib.check(ctx.lib.bh_richardson_lucy_apply(ctx.handle, self._handle, ptr(d), int(iterations), float(eps), ptr(out)))
-        return out
+            if row_sums is None:
+                _lib.check(ctx.lib.bh_richardson_lucy_apply(ctx.handle, self._handle, ptr(d), int(iterations), float(eps), ptr(out)))
+                return out
+            produced = ctypes.c_int(0)
+            _lib.check(ctx.lib.bh_richardson_lucy_apply_rows(ctx.handle, self._handle, ptr(d), int(iterations), float(eps), ptr(out),
+                                                             ptr(row_sums), ctypes.byref(produced)))
+        return out, (row_sums if produced.value else None)
 
     def close(self) -> None:
         if self._handle:

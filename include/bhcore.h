@@ -301,6 +301,11 @@ typedef struct bh_rl bh_rl;
 int bh_richardson_lucy_create(bh_ctx* ctx, const float* psf, int64_t pz, int64_t py, int64_t px, int64_t Z, int64_t Y,
                               int64_t X, bh_rl** out);
 int bh_richardson_lucy_apply(bh_ctx* ctx, const bh_rl* handle, const float* in, int iterations, float eps, float* out);
+/* bh_richardson_lucy_apply that also reduces the row sums of its result: row_sums (device, float64 [Z * Y], may be NULL) receives
+ * sum over x of out[z, y, x] from the last update pass when the handle's back-end can do so (*produced = 1; the fused engine on
+ * rows of 512 / 1024 / 2048 voxels), and is left untouched otherwise (*produced = 0).  bh_deskew_rows takes them. */
+int bh_richardson_lucy_apply_rows(bh_ctx* ctx, const bh_rl* h, const float* in, int iterations, float eps, float* out,
+                                  double* row_sums, int* produced);
 int bh_richardson_lucy_destroy(bh_rl* handle);
 /* box / backend as bh_richardson_lucy_plan; otf_is_real: the PSF is point-symmetric, one float per bin is kept; any
  * output pointer may be NULL. */

@@ -200,3 +200,56 @@ def test_rank0_failure_reaches_every_rank(tmp_path):
     assert out[0][2].startswith("own: ")                       # rank 0 sees its own exception
     assert out[1][2].startswith("Rank0Error: rank 0 failed")   # rank 1 is told, instead of waiting in a barrier
     assert all(o[3] < 30 for o in out)
+
+
+def test_four_rank_plate_rehearsal_cli_on_cpu(tmp_path):
+    """The first 8-GPU run, rehearsed with what a box without a GPU has: `torchrun --nproc-per-node 4 -m biahub_amd deskew` on an
+    8-position plate over gloo, `device: cpu` (libbhcore's host deskew) — the same sharding, plate lay-out, barrier and status
+    gather as on GPUs (reference fan-out: biahub/deskew.py:715-749).  One plate writer (rank 0 lays the plate out, the others
+    wait), disjoint shards that cover the plate, every position right, one job-id log."""
+    import json
+    import os
+    import re
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    import numpy as np
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the CLI would take it; the GPU suite runs the 2-rank form (test_cli_two_ranks_under_torchrun)")
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_io_cli import DESKEW_YML, make_plate
+
+    from biahub_amd import io
+    from oracle import oracle_np as O
+
+    src = tmp_path / "in.zarr"
+    keys = [(row, str(col), "0") for row in "AB" for col in (1, 2, 3, 4)]
+    data = make_plate(src, positions=keys, shape=(1, 1, 12, 16, 20))
+    cfg = tmp_path / "deskew.yml"
+    cfg.write_text(DESKEW_YML)
+    out = tmp_path / "deskewed.zarr"
+    env = dict(os.environ, BH_DIST_BACKEND="gloo", PYTHONPATH=str(Path(__file__).resolve().parent.parent), OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "biahub_amd", "deskew", "-i", *[str(src.joinpath(*k)) for k in keys],
+           "-c", str(cfg), "-o", str(out), "--cluster", "debug"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    shares = re.findall(r"\[rank (\d)/4\] deskew: device (\S+), (\d) of 8 position\(s\)", res.stderr)
+    assert sorted(int(r) for r, _, _ in shares) == [0, 1, 2, 3] and all(n == "2" for _, _, n in shares), res.stderr
+    done = re.findall(r"Deskew complete: (\S+)", res.stdout)
+    assert sorted(done) == sorted(str(src.joinpath(*k)) for k in keys)  # every position exactly once: the shards are disjoint
+    # one writer of the plate-level metadata: it lists all eight wells once, and the job-id log has one line per position
+    meta = json.loads((out / ".zattrs").read_text()) if (out / ".zattrs").exists() else json.loads((out / "zarr.json").read_text())
+    text = json.dumps(meta)
+    for row, col, _ in keys:
+        assert text.count(f'"{row}/{col}"') >= 1
+    assert len((tmp_path / "slurm_output" / "submitit_jobs_ids.log").read_text().splitlines()) == 8
+    for k in keys:
+        got = io.open_ome_zarr(out.joinpath(*k)).data[0, 0]
+        want = O.fast_deskew_zyx(data[k + (0, 0)].astype(np.float32), 36.17, 0.371, True, 3, "mean")
+        assert np.abs(got - want).max() <= 1e-5 * want.max()

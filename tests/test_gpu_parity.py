@@ -142,9 +142,11 @@ def test_deskew_persistent_kernel_equals_tile_kernel(gpu, monkeypatch):
     ((33, 17, 192), 4, 36.17, 0.371),    # N = 4, ragged last slab
     ((31, 50, 64), 1, 45.0, 0.9),
     ((40, 30, 128), 2, 30.0, 0.25),
+    ((48, 100, 70), 3, 36.17, 0.371),    # X not a tile multiple, Y % N != 0
+    ((40, 33, 65), 5, 20.0, 0.5),        # generic-N kernel
 ])
 def test_deskew_one_pass_fill(gpu, monkeypatch, shape, n, angle, ratio):
-    """float32 volumes with whole 64-column tiles fill the overhang in ONE pass (csrc/deskew_rows.inc): the zero pattern and
+    """The overhang is filled in ONE pass (csrc/deskew_rows.inc): the zero pattern and
     its dilation from geometry, the mean from row sums of the input, whole rows written by the resampling kernel.  Against the
     oracle (the reference's mask / dilate / mean / where on the finished volume, deskew.py:339-368), against the mask pipeline
     (BH_DESKEW_ONEPASS=0: same voxels bit for bit outside the fill, the fill value to float32 rounding), with row sums handed
@@ -171,6 +173,20 @@ def test_deskew_one_pass_fill(gpu, monkeypatch, shape, n, angle, ratio):
             assert float((got - old).abs().max()) <= 1e-6 * float(old.abs().max()), (shape, fill)
         else:
             assert bool(same.all()), (shape, fill)
+    # the persistent kernel's one-pass form (float32, whole 64-column tiles, N <= 4) against the tile kernel's
+    if shape[2] % 64 == 0 and n <= 4:
+        kwm = dict(ls_angle_deg=angle, px_to_scan_ratio=ratio, keep_overhang=True, average_n_slices=n, overhang_fill="mean")
+        a = fast_deskew_zyx(t, **kwm)
+        monkeypatch.setenv("BH_DESKEW_ROWS_KERNEL", "pers")
+        b = fast_deskew_zyx(t, **kwm)
+        monkeypatch.delenv("BH_DESKEW_ROWS_KERNEL")
+        assert deskew_fill_path(gpu) == 1 and torch.equal(a, b), shape
+    # uint16 camera counts take the same path (widened on load, row sums reduced from the integers)
+    u16 = torch.from_numpy((vol * 40).astype(np.uint16)).to(gpu)
+    got16 = fast_deskew_zyx(u16, angle, ratio, True, n, "mean")
+    assert deskew_fill_path(gpu) == 1
+    want16 = O.fast_deskew_zyx((vol * 40).astype(np.uint16).astype(np.float32), angle, ratio, True, n, "mean")
+    assert rel_err(got16.cpu().numpy(), want16) <= DESKEW_TOL, shape
     # row sums handed in by the caller: same result as reducing them here
     rs = t.to(torch.float64).sum(dim=2).contiguous()
     kw = dict(ls_angle_deg=angle, px_to_scan_ratio=ratio, keep_overhang=True, average_n_slices=n, overhang_fill="mean")
@@ -189,6 +205,33 @@ def test_deskew_one_pass_fill(gpu, monkeypatch, shape, n, angle, ratio):
     # and a clean volume afterwards takes the one-pass path again (the flag is re-armed per call)
     got = fast_deskew_zyx(t, **kw)
     assert deskew_fill_path(gpu) == 1
+
+
+def test_richardson_lucy_hands_row_sums_to_deskew(gpu):
+    """bh_richardson_lucy_apply_rows: the last update pass of the fused engine (rows of 512 / 1024 / 2048 voxels) also reduces the
+    row sums of the estimate it stores; bh_deskew_rows derives the mean fill from them.  Other back-ends report "not produced"."""
+    from biahub_amd.deconvolve import PreparedRichardsonLucy
+    from biahub_amd.deskew import deskew_fill_path, fast_deskew_zyx
+
+    psf = torch.from_numpy(O.gaussian_psf((9, 5, 5), (1.5, 1.0, 1.0))).to(gpu)
+    for shape, expect in (((32, 64, 512), True), ((16, 32, 1024), True), ((32, 64, 128), False), ((20, 36, 100), False)):
+        vol = torch.from_numpy(O.synthetic_volume(shape, seed=sum(shape), n_blobs=12)).to(gpu)
+        rs = torch.full(shape[:2], -1.0, dtype=torch.float64, device=gpu)
+        with PreparedRichardsonLucy(psf, shape, gpu) as prep:
+            plain = prep(vol, 3, 1e-6)
+            est, got = prep(vol, 3, 1e-6, row_sums=rs)
+        assert torch.equal(plain, est)
+        assert (got is not None) == expect, (shape, prep.backend)
+        if got is None:
+            assert bool((rs == -1.0).all())
+            continue
+        want = est.to(torch.float64).sum(dim=2)
+        assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()), shape
+        if shape[2] % 64 == 0:
+            kw = dict(ls_angle_deg=36.17, px_to_scan_ratio=0.371, keep_overhang=True, average_n_slices=3, overhang_fill="mean")
+            a, b = fast_deskew_zyx(est, **kw), fast_deskew_zyx(est, row_sums=got, **kw)
+            assert deskew_fill_path(gpu) == 1
+            assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())
 
 
 def test_host_deskew_equals_gpu_deskew(gpu):

@@ -54,8 +54,17 @@ col = {k: v for k, v in rows.items() if "col_pass_kernel<" in k or "colw_kernel<
 for k, v in col.items():
     per_it = round(v[0] / n_it)          # launches of this kernel per iteration (the OTF build adds a stray call or two)
     it += per_it * (v[1] + v[2]) * 1e9
-rec = {"shape": shape, "unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KiB counters x1024)", "rl_iteration": it,
-       "deskew_kernel": moved("deskew_pers_kernel<" if any("deskew_pers_kernel<" in k for k in rows) else "deskew_kernel<"),
+# deskew + overhang fill as bh_deskew launches them: the resampling kernel plus every kernel of csrc/deskew_rows.inc and csrc/fill.hip
+# that ran beside it (the conditional mask pipeline moves nothing when the one-pass path took the volume), per deskew call
+dk_key = "deskew_pers_kernel<" if any("deskew_pers_kernel<" in k for k in rows) else "deskew_kernel<"
+n_dk = max(v[0] for k, v in rows.items() if dk_key in k)
+pair = 0.0
+for k, v in rows.items():
+    if any(t in k for t in ("deskew_pers_kernel<", "deskew_kernel<", "rows::", "dilate_", "shell_kernel", "apply_fill_kernel", "finalize_kernel",
+                            "mask0_kernel")):
+        pair += v[0] / n_dk * (v[1] + v[2]) * 1e9
+rec = {"shape": shape, "unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KiB counters x1024)", "rl_iteration": it, "deskew_pair": pair,
+       "deskew_kernel": max((v[1] + v[2]) * 1e9 for k, v in rows.items() if dk_key in k),
        "per_kernel_gb": {k[:60]: round(v[1] + v[2], 3) for k, v in rows.items()},
        "source": f"{prefix}_pmc_hbm_traffic.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of "
                  "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-ops`, summed over the 8 passes of one "
@@ -65,4 +74,4 @@ rec = {"shape": shape, "unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, Ki
 open(prefix + "_pmc_hbm_traffic.txt", "w").write("\n".join(lines) + "\n")
 json.dump(rec, open(prefix + "_pmc_hbm_traffic.json", "w"), indent=1)
 print("\n".join(lines[:14]))
-print("rl_iteration GB:", it / 1e9, " deskew GB:", rec["deskew_kernel"] / 1e9)
+print("rl_iteration GB:", it / 1e9, " deskew kernel GB:", rec["deskew_kernel"] / 1e9, " deskew + fill pair GB:", pair / 1e9)
