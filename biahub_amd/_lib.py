@@ -49,6 +49,9 @@ SIGNATURES = {
     "bh_bits_unpack": (_int, [_vp, _vp, _i64, _vp]),
     "bh_blosc_unfilter": (_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _int]),
     "bh_blosc_filter": (_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _int]),
+    "bh_blosc_lz4_bound": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    "bh_blosc_lz4_compress": (_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _int, _vp, _vp]),
+    "bh_lz4_decompress_streams": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp]),
     "bh_host_blosc_unfilter": (_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _int]),
     "bh_host_blosc_filter": (_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _int]),
     "bh_deskew_shape": (_int, [_i64, _i64, _i64, _f64, _f64, _int, _int, _f64, C.POINTER(_i64), C.POINTER(_f64)]),

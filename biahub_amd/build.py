@@ -12,7 +12,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 INCLUDE = PKG.parent / "include"
 LIB = PKG / "libbhcore.so"
-SOURCES = ["context.hip", "deskew.hip", "fill.hip", "deconv.hip", "fftconv.hip", "affine.hip", "spline.hip", "copy.hip", "regmetric.hip", "flatfield.hip", "psf.hip", "binning.hip", "codec.hip", "mask.hip", "invtf.hip", "host_deskew.hip"]
+SOURCES = ["context.hip", "deskew.hip", "fill.hip", "deconv.hip", "fftconv.hip", "affine.hip", "spline.hip", "copy.hip", "regmetric.hip", "flatfield.hip", "psf.hip", "binning.hip", "codec.hip", "lz4.hip", "mask.hip", "invtf.hip", "host_deskew.hip"]
 ARCH = "gfx950"
 
 

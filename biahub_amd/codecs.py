@@ -391,6 +391,88 @@ def filter_device(src, dst, blocksize: int, typesize: int, mode: int) -> None:
     _device_filter("bh_blosc_filter", src, dst, blocksize, typesize, mode)
 
 
+def blosc_lz4_compress_device(filtered, nframes: int, cbytes: int, blocksize: int, typesize: int, mode: int):
+    """Blosc-1 frames (inner codec lz4) of ``nframes`` chunks of ``cbytes`` bytes each, ON the GPU (``bh_blosc_lz4_compress``).
+    ``filtered``: uint8 device tensor of ``nframes * cbytes`` bytes already permuted block by block (``filter_device`` with this
+    ``blocksize``).  Returns ``(packed, offsets)``: the frames in one uint8 device tensor and a host list of ``nframes + 1``
+    offsets (frame f = ``packed[offsets[f]: ...]``, its own length in its header; the last entry is the total) — only the
+    compressed bytes need to cross PCIe.  Synchronises once (the offsets are read back)."""
+    import ctypes
+
+    import torch
+
+    from . import _lib
+    from .device import get_context, ptr
+
+    if filtered.dtype != torch.uint8 or not filtered.is_cuda or not filtered.is_contiguous() or filtered.numel() != nframes * cbytes:
+        raise ValueError("need a contiguous uint8 device tensor of nframes * cbytes bytes")
+    if cbytes < _BLOSC_MIN_BUFFERSIZE:
+        raise ValueError("chunks below 128 bytes are stored raw by Blosc: compress them on the host")
+    ctx = get_context(filtered.device)
+    bound = int(ctx.lib.bh_blosc_lz4_bound(int(nframes), int(cbytes), int(blocksize)))
+    packed = torch.empty(bound, dtype=torch.uint8, device=filtered.device)
+    foff = torch.empty(nframes + 1, dtype=torch.int64, device=filtered.device)
+    with torch.cuda.device(filtered.device):
+        _lib.check(ctx.lib.bh_blosc_lz4_compress(ctx.handle, ptr(filtered), int(nframes), int(cbytes), int(blocksize), int(typesize),
+                                                 int(mode), ptr(packed), ptr(foff)))
+    return packed, [int(v) for v in foff.cpu().tolist()]
+
+
+def blosc_lz4_stream_table(buf) -> tuple["BloscHeader", np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+    """The LZ4 streams of a Blosc-1 frame with the lz4 inner codec: ``(header, soff, csize, doff, dlen)`` — stream i is
+    ``csize[i]`` bytes at ``buf[soff[i]:]`` and decodes to ``dlen[i]`` still-permuted bytes at offset ``doff[i]`` of the chunk
+    (a block is one stream, or ``typesize`` streams when its writer split it).  Host-side parsing only."""
+    h = BloscHeader(buf)
+    if h.codec != "lz4" or h.memcpyed:
+        raise ValueError("not a compressed Blosc frame with the lz4 inner codec")
+    mv = memoryview(buf)
+    nblocks = -(-h.nbytes // h.blocksize)
+    bstarts = struct.unpack_from(f"<{nblocks}i", mv, 16)
+    dont_split = bool(h.flags & 0x10)
+    soff, csize, doff, dlen = [], [], [], []
+    for b in range(nblocks):
+        o0 = b * h.blocksize
+        bsize = min(h.blocksize, h.nbytes - o0)
+        split = (not dont_split and h.typesize <= _BLOSC_MAX_SPLITS and h.blocksize // h.typesize >= _BLOSC_MIN_BUFFERSIZE
+                 and bsize == h.blocksize)
+        nsplits = h.typesize if split else 1
+        ne = bsize // nsplits
+        pos = bstarts[b]
+        for j in range(nsplits):
+            (cb,) = struct.unpack_from("<i", mv, pos)
+            pos += 4
+            if cb < 0 or pos + cb > len(mv):
+                raise ValueError("corrupt blosc stream")
+            soff.append(pos)
+            csize.append(cb)
+            doff.append(o0 + j * ne)
+            dlen.append(ne)
+            pos += cb
+    return h, np.asarray(soff, np.uint64), np.asarray(csize, np.uint32), np.asarray(doff, np.uint64), np.asarray(dlen, np.uint32)
+
+
+def blosc_lz4_decode_blocks_device(frame, out_dev, device=None) -> "BloscHeader":
+    """The device half of reading a Blosc-lz4 frame: ``frame`` (bytes-like, the whole frame as read from the store) is uploaded
+    COMPRESSED and its LZ4 streams are decoded by ``bh_lz4_decompress_streams`` into ``out_dev`` (uint8 device tensor of
+    ``header.nbytes`` still-permuted bytes; ``unfilter_device`` finishes).  Raises on a corrupt stream."""
+    import torch
+
+    from . import _lib
+    from .device import get_context, ptr
+
+    h, soff, csize, doff, dlen = blosc_lz4_stream_table(frame)
+    if out_dev.dtype != torch.uint8 or not out_dev.is_cuda or out_dev.numel() != h.nbytes or not out_dev.is_contiguous():
+        raise ValueError("output must be a contiguous uint8 device tensor of header.nbytes bytes")
+    dev = out_dev.device
+    fr = torch.frombuffer(bytearray(memoryview(frame)[: h.cbytes]), dtype=torch.uint8).to(dev)
+    tabs = [torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a.view(np.int32)).to(dev) for a in (soff, csize, doff, dlen)]
+    ctx = get_context(dev)
+    with torch.cuda.device(dev):
+        _lib.check(ctx.lib.bh_lz4_decompress_streams(ctx.handle, ptr(fr), ptr(tabs[0]), ptr(tabs[1]), ptr(tabs[2]), ptr(tabs[3]),
+                                                     int(len(csize)), ptr(out_dev)))
+    return h
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # zarr compressor configurations -> (decode, encode)
 # ---------------------------------------------------------------------------------------------------------------

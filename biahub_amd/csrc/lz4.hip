@@ -1,0 +1,382 @@
+// LZ4 block compression / decompression of Blosc-1 blocks on gfx950, and the assembly of Blosc frames on the device.
+//
+// The stores either side of the path are iohub's: zarr chunks holding Blosc-1 frames (numcodecs.Blosc; reference
+// biahub/deskew.py:608-640, settings.py:43,460).  Round 1-3 ran the byte permutations of the container on the GPU
+// (csrc/codec.hip) and left the entropy coder to host threads, so a compressed store moved every RAW byte across PCIe and cost
+// ~0.55 s of zstd per 2-GB volume.  Here the block codec itself runs on the device — LZ4, which the Blosc container carries as
+// one of its inner codecs (format 1; numcodecs / c-blosc read it like any other) — so only compressed bytes cross PCIe:
+//   compress:  one WAVEFRONT per Blosc block (256 KiB of already permuted bytes).  Per step the 64 lanes hash the four bytes at
+//              64 consecutive positions into a wave-private LDS table (4096 x 4 B), test the candidates they find, the earliest
+//              match is extended 256 bytes per step by dword compares and ballots, literals and match go out cooperatively.
+//              A greedy matcher without lazy evaluation or back-extension: bit-shuffled float / uint16 volumes are long runs in
+//              the high bit planes and noise in the low ones — the runs are what there is to win.
+//   frames:    per chunk, an exclusive scan of the block sizes gives the block start table; one kernel writes header, table and
+//              payloads of every frame into one packed buffer (frames at 16-byte aligned offsets), so ONE download carries it.
+//   decompress: one wavefront per block walks the token stream (lane 0's bytes broadcast), literals and matches are copied 64
+//              lanes wide (a match that overlaps its own output is periodic in its offset: dst[i] = src[i mod offset]).
+// The format is the LZ4 block format (token, literal length extension, literals, 2-byte offset, match length extension; last
+// five bytes literals, last match starts >= 12 bytes before the end), so c-blosc decodes what this writes and this decodes
+// what c-blosc writes (tests/test_codecs.py against the real library's streams).
+#include "common.hpp"
+
+namespace bh {
+
+namespace lz4 {
+
+constexpr int HASH_LOG = 12, HASH_SIZE = 1 << HASH_LOG;
+constexpr int WAVES = 4;            // wavefronts per workgroup, one block each (4 x 16 KiB of hash tables = the 64 KiB static LDS limit)
+constexpr int MFLIMIT = 12, LASTLITERALS = 5, MINMATCH = 4;
+constexpr unsigned NOPOS = 0xFFFFFFFFu;
+
+__device__ __forceinline__ unsigned ld32(const uint8_t* p) {
+    unsigned v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ void st32(uint8_t* p, unsigned v) { __builtin_memcpy(p, &v, 4); }
+
+// copy n bytes (any alignment, non-overlapping), the wavefront together: 256 bytes per step as dwords, the tail by bytes
+__device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, unsigned n, int lane) {
+    unsigned i = 0;
+    for (; i + 256 <= n; i += 256) st32(dst + i + 4 * lane, ld32(src + i + 4 * lane));
+    for (unsigned j = i + lane; j < n; j += 64) dst[j] = src[j];
+}
+
+// a length >= 15 continues behind its nibble as bytes that add up to (len - 15): 255, 255, ..., rest
+__device__ __forceinline__ unsigned ext_bytes(unsigned len) { return len >= 15 ? (len - 15) / 255 + 1 : 0; }
+__device__ __forceinline__ void put_ext(uint8_t* dst, unsigned len, int lane) {  // len >= 15
+    const unsigned r = len - 15, n255 = r / 255;
+    for (unsigned j = lane; j < n255; j += 64) dst[j] = 255;
+    if (lane == 0) dst[n255] = (uint8_t)(r - 255 * n255);
+}
+
+// sizes[b] = compressed bytes of block b written at dst + b * slot (== the block's length when it does not shrink: the block
+// is then copied raw, which is how the Blosc container marks a stored block)
+__global__ __launch_bounds__(64 * WAVES) void compress_kernel(const uint8_t* __restrict__ src, uint64_t nbytes, uint32_t blocksize,
+                                                             uint8_t* __restrict__ dst, uint64_t slot, uint32_t* __restrict__ sizes,
+                                                             uint32_t nblocks) {
+    __shared__ unsigned table_all[WAVES][HASH_SIZE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned* table = table_all[wave];
+    for (uint32_t b = blockIdx.x * WAVES + wave; b < nblocks; b += gridDim.x * WAVES) {
+        const uint8_t* in = src + (uint64_t)b * blocksize;
+        const unsigned n = (unsigned)min((uint64_t)blocksize, nbytes - (uint64_t)b * blocksize);
+        uint8_t* out = dst + (uint64_t)b * slot;
+        for (int i = lane; i < HASH_SIZE; i += 64) table[i] = NOPOS;
+        unsigned ip = 0, anchor = 0, op = 0;
+        bool fits = true;
+        const unsigned mflimit = n > MFLIMIT ? n - MFLIMIT : 0;   // a match starts before this position
+        const unsigned matchlimit = n > LASTLITERALS ? n - LASTLITERALS : 0;  // and ends at or before this one
+        while (fits && ip + 64 <= mflimit) {
+            const unsigned p = ip + lane;
+            const unsigned v = ld32(in + p);
+            const unsigned h = (v * 2654435761u) >> (32 - HASH_LOG);
+            const unsigned cand = table[h];
+            table[h] = p;  // reads of the step come before its writes (one wavefront's LDS operations execute in order)
+            // 1 <= p - cand <= 65535: after a short match the window starts again inside positions the table already holds, so a
+            // lane can find ITSELF (or a position ahead of it: the unsigned difference then wraps and fails the test too)
+            bool ok = cand != NOPOS && p - cand - 1u < 65535u;
+            ok = ok && ld32(in + (ok ? cand : 0)) == v;
+            // every match of the window is taken in turn: the ballot of this step stays valid for the lanes behind a match's end
+            unsigned long long m = __ballot(ok);
+            const unsigned wend = ip + 64;
+            unsigned next_ip = wend;
+            while (m != 0ull) {
+                const int first = __builtin_ctzll(m);
+                const unsigned mp = ip + first;
+                const unsigned mc = (unsigned)__builtin_amdgcn_readlane((int)cand, first);
+                // extend: dwords 1.. of the match, 256 bytes per step
+                unsigned len = MINMATCH;
+                for (;;) {
+                    const unsigned q = mp + len + 4 * lane;
+                    const bool in_range = q + 4 <= matchlimit;
+                    const unsigned a = in_range ? ld32(in + q) : 0u, c = in_range ? ld32(in + (mc + len + 4 * lane)) : 1u;
+                    const unsigned x = a ^ c;
+                    const unsigned long long neq = __ballot(x != 0u || !in_range);
+                    if (neq == 0ull) {
+                        len += 256;
+                        continue;
+                    }
+                    const int fl = __builtin_ctzll(neq);
+                    len += 4 * fl;
+                    // the lane that stopped the run: a differing byte inside its dword, or the end of the comparable range
+                    const unsigned qf = mp + len;
+                    if (qf + 4 <= matchlimit) {
+                        const unsigned xf = (unsigned)__builtin_amdgcn_readlane((int)x, fl);
+                        len += (unsigned)__builtin_ctz(xf) >> 3;
+                    } else {
+                        while (mp + len < matchlimit && in[mp + len] == in[mc + len]) ++len;  // at most three bytes (uniform loop)
+                    }
+                    break;
+                }
+                // sequence: token, literal length bytes, literals, offset, match length bytes
+                const unsigned lit = mp - anchor, ml = len - MINMATCH;
+                const unsigned need = 1 + ext_bytes(lit) + lit + 2 + ext_bytes(ml);
+                if (op + need + (n - (mp + len)) / 255 + 16 >= n) {  // would not shrink: stored instead
+                    fits = false;
+                    break;
+                }
+                if (lane == 0) out[op] = (uint8_t)((min(lit, 15u) << 4) | min(ml, 15u));
+                ++op;
+                if (lit >= 15) {
+                    put_ext(out + op, lit, lane);
+                    op += ext_bytes(lit);
+                }
+                wave_copy(out + op, in + anchor, lit, lane);
+                op += lit;
+                if (lane == 0) {
+                    const unsigned off = mp - mc;
+                    out[op] = (uint8_t)(off & 255u);
+                    out[op + 1] = (uint8_t)(off >> 8);
+                }
+                op += 2;
+                if (ml >= 15) {
+                    put_ext(out + op, ml, lane);
+                    op += ext_bytes(ml);
+                }
+                const unsigned end = mp + len;
+                anchor = end;
+                if (end >= wend) {
+                    next_ip = end;
+                    break;
+                }
+                m &= ~0ull << (end - ip);  // the lanes behind this match
+            }
+            ip = next_ip;
+        }
+        unsigned csize = n;
+        if (fits) {
+            const unsigned lit = n - anchor;
+            const unsigned need = 1 + ext_bytes(lit) + lit;
+            if (op + need < n) {
+                if (lane == 0) out[op] = (uint8_t)(min(lit, 15u) << 4);
+                ++op;
+                if (lit >= 15) {
+                    put_ext(out + op, lit, lane);
+                    op += ext_bytes(lit);
+                }
+                wave_copy(out + op, in + anchor, lit, lane);
+                op += lit;
+                csize = op;
+            } else {
+                fits = false;
+            }
+        }
+        if (!fits) wave_copy(out, in, n, lane);  // stored block
+        if (lane == 0) sizes[b] = csize;
+    }
+}
+
+// Blosc-1 frames of `nframes` chunks of `cbytes` permuted bytes each (the last block of a chunk may be short), blocks never
+// split (flag 0x10): frame f = 16-byte header, nb block starts, then per block an int32 size and the payload.
+//   scan_kernel : one workgroup per frame — block starts (exclusive scan of 4 + size) and the frame's total
+//   offsets     : frame f starts at foff[f] (16-byte aligned) in the packed output; foff[nframes] = total bytes
+__global__ __launch_bounds__(256) void frame_scan_kernel(const uint32_t* __restrict__ sizes, uint32_t nb, uint32_t* __restrict__ bstarts,
+                                                         uint32_t* __restrict__ fbytes) {
+    __shared__ uint32_t part[256];
+    const uint32_t f = blockIdx.x;
+    const uint32_t* s = sizes + (uint64_t)f * nb;
+    uint32_t* bs = bstarts + (uint64_t)f * nb;
+    const uint32_t per = (nb + 255) / 256, b0 = threadIdx.x * per, b1 = min(nb, b0 + per);
+    uint32_t acc = 0;
+    for (uint32_t b = b0; b < b1; ++b) acc += 4 + s[b];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 16 + 4 * nb;
+        for (int i = 0; i < 256; ++i) {
+            const uint32_t t = part[i];
+            part[i] = run;
+            run += t;
+        }
+        fbytes[f] = run;
+    }
+    __syncthreads();
+    uint32_t pos = part[threadIdx.x];
+    for (uint32_t b = b0; b < b1; ++b) {
+        bs[b] = pos;
+        pos += 4 + s[b];
+    }
+}
+__global__ void frame_offsets_kernel(const uint32_t* __restrict__ fbytes, uint32_t nframes, uint64_t* __restrict__ foff) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (uint32_t f = 0; f < nframes; ++f) {
+            foff[f] = run;
+            run += ((uint64_t)fbytes[f] + 15) & ~(uint64_t)15;
+        }
+        foff[nframes] = run;
+    }
+}
+// one wavefront per block copies its payload into place; the first wavefront of a frame also writes header and table
+__global__ __launch_bounds__(256) void frame_pack_kernel(const uint8_t* __restrict__ slots, uint64_t slot, const uint32_t* __restrict__ sizes,
+                                                         const uint32_t* __restrict__ bstarts, const uint32_t* __restrict__ fbytes,
+                                                         const uint64_t* __restrict__ foff, uint32_t nb, uint32_t nframes, uint32_t cbytes,
+                                                         uint32_t blocksize, uint32_t typesize, uint32_t flags, uint8_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (uint64_t)nframes * nb) return;
+    const uint32_t f = (uint32_t)(w / nb), b = (uint32_t)(w - (uint64_t)f * nb);
+    uint8_t* fr = out + foff[f];
+    if (b == 0) {
+        if (lane == 0) {
+            fr[0] = 2;  // blosc format version
+            fr[1] = 1;  // inner codec format version
+            fr[2] = (uint8_t)flags;
+            fr[3] = (uint8_t)typesize;
+            st32(fr + 4, cbytes);
+            st32(fr + 8, blocksize);
+            st32(fr + 12, fbytes[f]);
+        }
+        for (uint32_t j = lane; j < nb; j += 64) st32(fr + 16 + 4 * j, bstarts[(uint64_t)f * nb + j]);
+    }
+    const uint32_t cs = sizes[w], pos = bstarts[w];
+    if (lane == 0) st32(fr + pos, cs);
+    wave_copy(fr + pos + 4, slots + w * slot, cs, lane);
+}
+
+// ---- decompression: one wavefront per LZ4 stream --------------------------------------------------------------------------
+// stream i: csize[i] bytes at src + soff[i] -> dlen[i] bytes at dst + doff[i]; csize == dlen marks a stored stream (Blosc keeps what
+// does not shrink raw).  A Blosc block is one stream, or `typesize` streams when the writer split it.  status[0] is raised on a
+// corrupt stream.
+__global__ __launch_bounds__(256) void decompress_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ soff,
+                                                         const uint32_t* __restrict__ csize, const uint64_t* __restrict__ doff,
+                                                         const uint32_t* __restrict__ dlen, uint32_t nstreams, uint8_t* __restrict__ dst,
+                                                         int* __restrict__ status) {
+    const int lane = threadIdx.x & 63;
+    for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nstreams; b += gridDim.x * 4) {
+        const uint8_t* in = src + soff[b];
+        const unsigned cs = csize[b];
+        uint8_t* out = dst + doff[b];
+        const unsigned n = dlen[b];
+        if (cs == n) {
+            wave_copy(out, in, n, lane);
+            continue;
+        }
+        unsigned ip = 0, op = 0;
+        bool bad = false;
+        while (ip < cs) {
+            // token and length extensions: every lane reads the same bytes (broadcast loads)
+            const unsigned tok = in[ip++];
+            unsigned lit = tok >> 4;
+            if (lit == 15) {
+                unsigned s;
+                do {
+                    if (ip >= cs) { bad = true; break; }
+                    s = in[ip++];
+                    lit += s;
+                } while (s == 255);
+            }
+            if (bad || ip + lit > cs || op + lit > n) { bad = true; break; }
+            wave_copy(out + op, in + ip, lit, lane);
+            ip += lit;
+            op += lit;
+            if (ip >= cs) break;  // the last sequence has no match
+            if (ip + 2 > cs) { bad = true; break; }
+            const unsigned off = (unsigned)in[ip] | ((unsigned)in[ip + 1] << 8);
+            ip += 2;
+            unsigned ml = tok & 15u;
+            if (ml == 15) {
+                unsigned s;
+                do {
+                    if (ip >= cs) { bad = true; break; }
+                    s = in[ip++];
+                    ml += s;
+                } while (s == 255);
+            }
+            ml += MINMATCH;
+            if (bad || off == 0 || off > op || op + ml > n) { bad = true; break; }
+            // a match reads what earlier sequences stored — other lanes' stores of a moment ago: they are waited for (the
+            // counter covers this wavefront's stores) and read past the vector cache, whose lines may predate them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint8_t* from = out + op - off;
+            if (off >= ml) {
+                for (unsigned j = lane; j < ml; j += 64) out[op + j] = __hip_atomic_load(from + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                for (unsigned j = lane; j < ml; j += 64)  // periodic in the offset
+                    out[op + j] = __hip_atomic_load(from + j % off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            op += ml;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if ((bad || op != n) && lane == 0) atomicExch(status, 1);
+    }
+}
+
+}  // namespace lz4
+
+}  // namespace bh
+
+extern "C" {
+
+// src: nframes * cbytes permuted bytes (chunks back to back); out: packed Blosc frames; foff (device, nframes + 1 uint64): the
+// frames' offsets in `out` and the total.  out must hold bh_blosc_lz4_bound(nframes, cbytes, blocksize) bytes.
+uint64_t bh_blosc_lz4_bound(uint32_t nframes, uint32_t cbytes, uint32_t blocksize) {
+    const uint64_t nb = (cbytes + (uint64_t)blocksize - 1) / blocksize;
+    return (uint64_t)nframes * ((16 + 8 * nb + cbytes + 15) & ~(uint64_t)15);
+}
+
+int bh_blosc_lz4_compress(bh_ctx* ctx, const void* src, uint32_t nframes, uint32_t cbytes, uint32_t blocksize, uint32_t typesize,
+                          int shuffle_mode, void* out, uint64_t* foff) {
+    using namespace bh;
+    BH_REQUIRE(ctx && src && out && foff, "NULL argument");
+    BH_REQUIRE(nframes > 0 && cbytes >= 128 && blocksize >= 128 && blocksize <= (1u << 30), "invalid frame geometry");
+    BH_REQUIRE(typesize >= 1 && typesize <= 255, "invalid typesize %u", typesize);
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    const uint32_t nb = (uint32_t)(((uint64_t)cbytes + blocksize - 1) / blocksize);
+    BH_REQUIRE((uint64_t)nframes * nb < (1ull << 31), "too many blocks");
+    const uint32_t nblocks = nframes * nb;
+    const uint64_t slot = ((uint64_t)blocksize + 15) & ~(uint64_t)15;
+    uint8_t* slots;
+    uint32_t *sizes, *bstarts, *fbytes;
+    BH_TRY(get_scratch(ctx, "lz4_slots", (uint64_t)nblocks * slot, (void**)&slots));
+    BH_TRY(get_scratch(ctx, "lz4_sizes", (uint64_t)nblocks * 4, (void**)&sizes));
+    BH_TRY(get_scratch(ctx, "lz4_bstarts", (uint64_t)nblocks * 4, (void**)&bstarts));
+    BH_TRY(get_scratch(ctx, "lz4_fbytes", (uint64_t)nframes * 4, (void**)&fbytes));
+    hipStream_t s = ctx->stream;
+    const int grid = (int)std::min<uint64_t>(((uint64_t)nblocks + lz4::WAVES - 1) / lz4::WAVES, (uint64_t)ctx->num_cus * 2);
+    if (cbytes % blocksize == 0) {
+        hipLaunchKernelGGL(lz4::compress_kernel, dim3(grid), dim3(64 * lz4::WAVES), 0, s, (const uint8_t*)src, (uint64_t)nframes * cbytes,
+                           blocksize, slots, slot, sizes, nblocks);
+    } else {  // every frame ends in a short block: frames one by one
+        for (uint32_t f = 0; f < nframes; ++f)
+            hipLaunchKernelGGL(lz4::compress_kernel, dim3(std::min<int>(grid, (int)((nb + lz4::WAVES - 1) / lz4::WAVES))), dim3(64 * lz4::WAVES), 0,
+                               s, (const uint8_t*)src + (uint64_t)f * cbytes, (uint64_t)cbytes, blocksize, slots + (uint64_t)f * nb * slot, slot,
+                               sizes + (uint64_t)f * nb, nb);
+    }
+    hipLaunchKernelGGL(lz4::frame_scan_kernel, dim3(nframes), dim3(256), 0, s, sizes, nb, bstarts, fbytes);
+    hipLaunchKernelGGL(lz4::frame_offsets_kernel, dim3(1), dim3(64), 0, s, fbytes, nframes, foff);
+    const uint32_t flags = 0x10u | (1u << 5) | (shuffle_mode == BH_BLOSC_SHUFFLE ? 0x1u : (shuffle_mode == BH_BLOSC_BITSHUFFLE ? 0x4u : 0u));
+    hipLaunchKernelGGL(lz4::frame_pack_kernel, dim3((unsigned)(((uint64_t)nblocks + 3) / 4)), dim3(256), 0, s, slots, slot, sizes, bstarts, fbytes,
+                       foff, nb, nframes, cbytes, blocksize, typesize, flags, (uint8_t*)out);
+    BH_CHECK_HIP(hipGetLastError());
+    return BH_OK;
+}
+
+// LZ4 streams back to bytes on the device: stream i = csize[i] bytes at src + soff[i] -> dlen[i] bytes at dst + doff[i] (four
+// device arrays of nstreams entries; csize == dlen marks a stored stream).  The caller parses the Blosc frame's block table on
+// the host (a block is one stream, or typesize streams when split).  Synchronises (the status word is read back):
+// BH_ERR_INVALID on a corrupt stream.
+int bh_lz4_decompress_streams(bh_ctx* ctx, const void* src, const uint64_t* soff, const uint32_t* csize, const uint64_t* doff,
+                              const uint32_t* dlen, uint32_t nstreams, void* dst) {
+    using namespace bh;
+    BH_REQUIRE(ctx && src && soff && csize && doff && dlen && dst, "NULL argument");
+    BH_REQUIRE(nstreams > 0, "no streams");
+    BH_CHECK_HIP(hipSetDevice(ctx->device));
+    int* status;
+    BH_TRY(get_scratch(ctx, "lz4_status", sizeof(int), (void**)&status));
+    hipStream_t s = ctx->stream;
+    BH_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), s));
+    const int grid = (int)std::min<uint64_t>(((uint64_t)nstreams + 3) / 4, (uint64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(lz4::decompress_kernel, dim3(grid), dim3(256), 0, s, (const uint8_t*)src, soff, csize, doff, dlen, nstreams,
+                       (uint8_t*)dst, status);
+    BH_CHECK_HIP(hipGetLastError());
+    int h = 0;
+    BH_CHECK_HIP(hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, s));
+    BH_CHECK_HIP(hipStreamSynchronize(s));
+    BH_REQUIRE(h == 0, "corrupt LZ4 stream");
+    return BH_OK;
+}
+
+}  // extern "C"

@@ -455,6 +455,8 @@ class ZarrArray:
         stage = torch.empty(len(plan) * cbytes, dtype=torch.uint8, pin_memory=True)
         stage_np = stage.numpy()
         heads: list = [None] * len(plan)
+        frames: dict = {}  # chunks whose LZ4 blocks are decoded on the GPU: the compressed frame travels instead of the raw bytes
+        lz4_dev = os.environ.get("BH_LZ4_DEVICE", "1") != "0"
 
         def one(i):
             zi, kz, z0, _ = plan[i]
@@ -473,6 +475,11 @@ class ZarrArray:
                         return
                     fh.seek(off)
                     buf = fh.read(nb)
+            h0 = codecs.BloscHeader(buf)
+            if lz4_dev and h0.codec == "lz4" and not h0.memcpyed and h0.nbytes == cbytes:
+                heads[i] = h0
+                frames[i] = bytes(buf[: h0.cbytes])
+                return
             h, _ = codecs.blosc_decode_blocks(buf, out=stage_np[i * cbytes:(i + 1) * cbytes])
             heads[i] = h
 
@@ -490,6 +497,8 @@ class ZarrArray:
                 continue
             mode = codecs.BLOSC_NOSHUFFLE if h.memcpyed else h.shuffle_mode
             src = dstage[i * cbytes:(i + 1) * cbytes]
+            if i in frames:  # LZ4 blocks -> permuted bytes on the device (csrc/lz4.hip), in the slot the host decoder would have filled
+                codecs.blosc_lz4_decode_blocks_device(frames[i], src)
             if dst.numel() == cbytes:
                 codecs.unfilter_device(src, dst, h.blocksize, h.typesize, mode)
             else:  # the last chunk overhangs the array: un-shuffle all of it, keep the planes inside
@@ -539,8 +548,26 @@ class ZarrArray:
                 full[: src.numel()] = src
                 src = full
             codecs.filter_device(src, dstage[i * cbytes:(i + 1) * cbytes], bsz, ts, mode)
-        host = to_host(dstage)
         per_file: dict = {}
+        if cfg.get("cname", "zstd") == "lz4" and cbytes >= 128 and os.environ.get("BH_LZ4_DEVICE", "1") != "0":
+            # the block codec runs on the GPU too (csrc/lz4.hip): only the finished frames cross PCIe, the I/O threads just write
+            packed, offs = codecs.blosc_lz4_compress_device(dstage, len(plan), cbytes, bsz, ts, mode)
+            hostp = to_host(packed[: offs[-1]])
+
+            def put(i):
+                zi, kz, z0, _ = plan[i]
+                nb = int(np.frombuffer(hostp[offs[i] + 12: offs[i] + 16], np.uint32)[0])  # the frame's own length (header)
+                blob = hostp[offs[i]: offs[i] + nb].tobytes()
+                if kz is None:
+                    self._write_file(self._chunk_path((t, c, zi, 0, 0)), blob)
+                else:
+                    per_file.setdefault(zi, {})[(0, 0, kz, 0, 0)] = blob
+
+            _io_map(put, range(len(plan)))
+            for zi, pieces in per_file.items():
+                self._write_shard(self._chunk_path((t, c, zi, 0, 0)), pieces)
+            return
+        host = to_host(dstage)
 
         def one(i):
             zi, kz, z0, _ = plan[i]

@@ -173,6 +173,24 @@ int bh_blosc_unfilter(bh_ctx* ctx, const void* src, void* dst, uint64_t nbytes, 
                       int mode);
 int bh_blosc_filter(bh_ctx* ctx, const void* src, void* dst, uint64_t nbytes, uint32_t blocksize, uint32_t typesize,
                     int mode);
+/* ---- chunk codec: LZ4 blocks inside the Blosc-1 container, on the device ---------------- */
+/* Blosc frames of `nframes` chunks: src = nframes * cbytes bytes ALREADY permuted block by block (bh_blosc_filter with this
+ * blocksize), chunk after chunk.  Every block is LZ4-compressed by one wavefront (stored raw when it does not shrink), and the
+ * frames — 16-byte header, block start table, per block an int32 size and its payload; blocks never split (flag 0x10), inner
+ * codec lz4 — are packed into `out` at 16-byte aligned offsets: foff (device, nframes + 1 entries) receives the offset of every
+ * frame and, last, the total.  `out` must hold bh_blosc_lz4_bound() bytes.  c-blosc >= 1.15 / numcodecs read the frames.  Does
+ * not synchronise. */
+uint64_t bh_blosc_lz4_bound(uint32_t nframes, uint32_t cbytes, uint32_t blocksize);
+int bh_blosc_lz4_compress(bh_ctx* ctx, const void* src, uint32_t nframes, uint32_t cbytes, uint32_t blocksize, uint32_t typesize,
+                          int shuffle_mode, void* out, uint64_t* foff);
+/* LZ4 streams back to bytes on the device: stream i is csize[i] bytes at src + soff[i] and decodes to dlen[i] bytes at
+ * dst + doff[i] (device arrays of nstreams entries; csize == dlen marks a stored stream).  The caller reads the Blosc frame's
+ * block table on the host — a block is one stream, or `typesize` streams when its writer split it (c-blosc 1.21 splits lz4
+ * blocks, this library's writer does not) — and the result is still permuted: bh_blosc_unfilter finishes.  Synchronises;
+ * BH_ERR_INVALID on a corrupt stream. */
+int bh_lz4_decompress_streams(bh_ctx* ctx, const void* src, const uint64_t* soff, const uint32_t* csize, const uint64_t* doff,
+                              const uint32_t* dlen, uint32_t nstreams, void* dst);
+
 /* The same two permutations on host memory, on the calling thread (no context, no GPU): for volumes that stay on the
  * host.  Re-entrant; callers parallelise over chunks. */
 int bh_host_blosc_unfilter(const void* src, void* dst, uint64_t nbytes, uint32_t blocksize, uint32_t typesize, int mode);

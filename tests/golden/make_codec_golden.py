@@ -55,6 +55,17 @@ def main():
         cases.append((f"clevel0_u2_s{shuffle}", image(5000, "u2"), b"zstd", 0, shuffle, 0))
         cases.append((f"zeros_u2_s{shuffle}", np.zeros(20000, np.uint16), b"zstd", 1, shuffle, 0))
         cases.append((f"zeros_blosclz_u2_s{shuffle}", np.zeros(20000, np.uint16), b"blosclz", 5, shuffle, 0))
+    # LZ4 at the sizes the device codec (csrc/lz4.hip) meets: several 64-KiB / 256-KiB blocks, c-blosc splitting them into
+    # `typesize` streams, long runs (match lengths far beyond one extension byte), stored streams beside compressed ones
+    cases.append(("lz4big_u2_s2", image(300_000, "u2"), b"lz4", 1, 2, 0))
+    cases.append(("lz4big_f4_s2", image(200_000, "f4"), b"lz4", 1, 2, 262144))
+    cases.append(("lz4big_u2_s1", image(250_001, "u2"), b"lz4", 5, 1, 65536))
+    runs = np.zeros(400_000, np.uint16)
+    runs[::50_001] = 777
+    cases.append(("lz4runs_u2_s2", runs, b"lz4", 1, 2, 0))
+    mixed = np.concatenate([image(150_000, "u2"), rng.integers(0, 65536, 150_000, dtype=np.uint16)])
+    cases.append(("lz4mixed_u2_s2", mixed, b"lz4", 1, 2, 131072))
+    cases.append(("lz4mixed_u2_s0", mixed, b"lz4", 1, 0, 131072))
     # a chunk the size iohub writes for one camera plane (uint16 128x256), default numcodecs settings of iohub
     cases.append(("plane_u2_zstd1_bitshuffle", image(128 * 256, "u2").reshape(128, 256), b"zstd", 1, 2, 0))
 

@@ -1555,6 +1555,118 @@ def test_blosc_device_unfilter_on_c_blosc_streams(gpu):
 
 
 @pytest.mark.gpu
+def test_lz4_device_decodes_c_blosc_streams(gpu):
+    """csrc/lz4.hip, decoder: every lz4 stream the real c-blosc 1.21.0 wrote (tests/golden/blosc_streams.npz: split and unsplit
+    blocks, stored splits, short last blocks, match lengths of hundreds of kilobytes) decodes on the GPU to the bytes the host
+    decoder gives, and un-shuffles to the original."""
+    from biahub_amd import codecs
+
+    z = np.load(GOLDEN / "blosc_streams.npz")
+    names = sorted(k[: -len("__blosc")] for k in z.files if k.endswith("__blosc"))
+    done = 0
+    for n in names:
+        stream = z[f"{n}__blosc"].tobytes()
+        h = codecs.BloscHeader(stream)
+        if h.codec != "lz4" or h.memcpyed or h.nbytes == 0:
+            continue
+        _, want = codecs.blosc_decode_blocks(stream)
+        out = torch.empty(h.nbytes, dtype=torch.uint8, device=gpu)
+        codecs.blosc_lz4_decode_blocks_device(stream, out)
+        assert np.array_equal(out.cpu().numpy(), want), n
+        raw = torch.empty_like(out)
+        codecs.unfilter_device(out, raw, h.blocksize, h.typesize, h.shuffle_mode)
+        assert np.array_equal(raw.cpu().numpy(), z[f"{n}__raw"]), n
+        done += 1
+    assert done >= 12
+    # a damaged stream is reported, not decoded into garbage: the runs volume is a handful of long matches — zero their offsets
+    bad = bytearray(z["lz4runs_u2_s2__blosc"].tobytes())
+    h, soff, csize, _, dlen = codecs.blosc_lz4_stream_table(bytes(bad))
+    i = int(np.argmax(csize != dlen))  # the first compressed stream
+    for k in range(int(soff[i]), int(soff[i]) + int(csize[i])):
+        bad[k] = 0x0F if bad[k] else 0  # every token now announces a match after no literals, every offset reads 0 or 0x0f0f
+    with pytest.raises(Exception, match="corrupt"):
+        codecs.blosc_lz4_decode_blocks_device(bytes(bad), torch.empty(h.nbytes, dtype=torch.uint8, device=gpu))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,mode", [("u2", 2), ("f4", 2), ("u2", 1), ("u1", 0)])
+def test_lz4_device_compressor_frames(gpu, dtype, mode):
+    """csrc/lz4.hip, compressor + frame assembly: Blosc-lz4 frames made ON the GPU (permute -> LZ4 blocks -> packed frames) are
+    read back by the host decoder, by the device decoder and — where this image has it — by the real c-blosc; compressible
+    chunks shrink, incompressible ones come out as stored blocks, a short last block and a last frame of pure zeros included."""
+    import ctypes
+    import os
+
+    from biahub_amd import codecs
+
+    rng = np.random.default_rng(12)
+    ts = np.dtype(dtype).itemsize
+    n_el = 190_000  # per chunk: 380 / 760 KB -> two or three 256-KiB blocks, the last one short
+    x = np.arange(n_el)
+    chunks = [
+        (300 + 200 * np.sin(x / 37.0) + rng.poisson(2, n_el)).astype(dtype),     # camera-like: compressible
+        rng.integers(0, 256, n_el * ts, dtype=np.uint8).view(dtype),                # noise in every bit: incompressible
+        np.zeros(n_el, dtype),                                                      # one long run
+        np.where(x % 5000 < 4000, 1234, x % 251).astype(dtype),                     # runs and ramps
+    ]
+    raw = np.concatenate([c.view(np.uint8) for c in chunks])
+    cbytes = n_el * ts
+    bsz = codecs.default_blocksize(ts)
+    src = torch.from_numpy(raw).to(gpu)
+    filt = torch.empty_like(src)
+    for i in range(len(chunks)):
+        codecs.filter_device(src[i * cbytes:(i + 1) * cbytes], filt[i * cbytes:(i + 1) * cbytes], bsz, ts, mode)
+    packed, offs = codecs.blosc_lz4_compress_device(filt, len(chunks), cbytes, bsz, ts, mode)
+    host = packed[: offs[-1]].cpu().numpy()
+    lib = ctypes.CDLL("/opt/conda/lib/libblosc.so.1") if os.path.exists("/opt/conda/lib/libblosc.so.1") else None
+    if lib is not None:
+        lib.blosc_decompress_ctx.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    sizes = []
+    for i, c in enumerate(chunks):
+        frame = host[offs[i]: offs[i + 1]]
+        h = codecs.BloscHeader(frame.tobytes())
+        assert (h.nbytes, h.blocksize, h.typesize, h.codec, h.shuffle_mode) == (cbytes, bsz, ts, "lz4", mode if ts > 1 or mode != 1 else 0)
+        stream = frame[: h.cbytes].tobytes()
+        assert np.array_equal(codecs.blosc_decompress(stream), c.view(np.uint8)), i      # host decoder (pyarrow's lz4)
+        out = torch.empty(cbytes, dtype=torch.uint8, device=gpu)
+        codecs.blosc_lz4_decode_blocks_device(stream, out)                                  # device decoder
+        assert torch.equal(out, filt[i * cbytes:(i + 1) * cbytes]), i
+        if lib is not None:                                                                 # the real library
+            buf = np.frombuffer(stream, np.uint8).copy()
+            back = np.empty(cbytes, np.uint8)
+            assert lib.blosc_decompress_ctx(buf.ctypes.data, back.ctypes.data, back.size, 1) == cbytes, i
+            assert np.array_equal(back, c.view(np.uint8)), i
+        sizes.append(h.cbytes)
+    assert sizes[0] < 0.8 * cbytes and sizes[2] < 0.02 * cbytes and sizes[3] < 0.3 * cbytes, sizes
+    nb = -(-cbytes // bsz)
+    assert cbytes + 16 + 4 * nb <= sizes[1] <= cbytes + 16 + 8 * nb, sizes  # noise: every block stored
+
+
+@pytest.mark.gpu
+def test_zarr_device_volume_io_lz4(gpu, tmp_path, monkeypatch):
+    """A Blosc-lz4 store written from the device carries compressed bytes only across PCIe (csrc/lz4.hip) and reads back through
+    every reader: host, device (LZ4 on the GPU), and with BH_LZ4_DEVICE=0 the host entropy coder writes what the device reads."""
+    from biahub_amd import io
+
+    shape = (1, 2, 21, 256, 320)  # 21 planes in chunks of 8: the last chunk overhangs; 1.3-MB chunks = five 256-KiB blocks
+    comp = {"id": "blosc", "cname": "lz4", "clevel": 1, "shuffle": 2, "blocksize": 0}
+    io.create_empty_position(tmp_path / "p", ["a", "b"], shape, chunks=(1, 1, 8, 256, 320), dtype=np.uint16, version="0.4", compressor=comp)
+    arr = io.open_ome_zarr(tmp_path / "p").data
+    rng = np.random.default_rng(2)
+    v0 = (rng.poisson(4, shape[2:]) + 100).astype(np.uint16)
+    v1 = (rng.poisson(9, shape[2:]) + 300).astype(np.uint16)
+    arr.write_volume_device(0, 0, torch.from_numpy(v0).to(gpu))   # device LZ4 -> host reader, device reader
+    assert np.array_equal(arr.read_volume(0, 0), v0)
+    assert np.array_equal(arr.read_volume_device(0, 0, gpu).cpu().numpy(), v0)
+    monkeypatch.setenv("BH_LZ4_DEVICE", "0")
+    arr.write_volume_device(0, 1, torch.from_numpy(v1).to(gpu))   # host LZ4 (pyarrow) ...
+    monkeypatch.delenv("BH_LZ4_DEVICE")
+    assert np.array_equal(arr.read_volume_device(0, 1, gpu).cpu().numpy(), v1)   # ... -> device decoder
+    f = tmp_path / "p" / "0" / "0/0/0/0/0"
+    assert f.stat().st_size < 8 * 256 * 320 * 2 // 2  # it really is compressed
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("version,shards_ratio,shuffle", [("0.4", None, 2), ("0.4", None, 1), ("0.5", None, 2), ("0.5", (1, 1, 2, 1, 1), 2)])
 def test_zarr_device_volume_io(gpu, tmp_path, version, shards_ratio, shuffle):
     """write_volume_device / read_volume_device (GPU-side shuffle) interoperate with the host reader / writer."""
