@@ -29,7 +29,9 @@ from .utils.paths import get_output_paths, sbatch_to_submitit
 def _output_compressor():
     """Chunk compressor of the stores this CLI creates.  Default: what iohub gives the reference's outputs — Blosc with
     zstd level 1 and bit shuffle (NGFF 0.4: numcodecs ``Blosc``; 0.5: the zarr v3 ``blosc`` codec).  BH_ZARR_COMPRESSOR =
-    none | blosc | zstd | zlib overrides it."""
+    none | blosc | blosc-lz4 | zstd | zlib overrides it.  ``blosc-lz4`` keeps the container and the bit shuffle and swaps the
+    inner codec for lz4 — any Blosc reader (numcodecs, iohub) takes it — which lets the GPU run the block codec too
+    (csrc/lz4.hip): a device-resident result then crosses PCIe compressed and the host only writes files."""
     import os
 
     kind = os.environ.get("BH_ZARR_COMPRESSOR", "blosc").lower()
@@ -37,9 +39,11 @@ def _output_compressor():
         return None
     if kind == "blosc":
         return "blosc"
+    if kind in ("blosc-lz4", "blosc_lz4", "lz4"):
+        return {"id": "blosc", "cname": "lz4", "clevel": 1, "shuffle": 2, "blocksize": 0}
     if kind in ("zstd", "zlib", "gzip"):
         return {"id": kind, "level": 1}
-    raise click.UsageError(f"BH_ZARR_COMPRESSOR={kind!r}: expected none, blosc, zstd, zlib or gzip")
+    raise click.UsageError(f"BH_ZARR_COMPRESSOR={kind!r}: expected none, blosc, blosc-lz4, zstd, zlib or gzip")
 
 _MULTI = {"-i", "--input-position-dirpaths", "-s", "--source-position-dirpaths", "-t", "--target-position-dirpaths"}
 
@@ -158,7 +162,7 @@ def _config(f):
 def deskew_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor, config_filepath, cluster, init_only,
                resume):
     """Deskew oblique light-sheet positions (reference: ``biahub deskew``)."""
-    from .deskew import _fast_deskew_czyx, get_deskewed_data_shape
+    from .deskew import _fast_deskew_czyx, _fast_deskew_czyx_device, get_deskewed_data_shape
 
     settings = yaml_to_model(config_filepath, DeskewSettings)
     with open_ome_zarr(input_position_dirpaths[0]) as ds:
@@ -184,8 +188,10 @@ def deskew_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor
               overhang_fill=settings.overhang_fill, device=_deskew_device(settings.device),
               extra_metadata={"biahub-deskew": settings.model_dump()})
     outs = get_output_paths(input_position_dirpaths, output_dirpath)
+    # on a GPU the result stays in HBM until the store has permuted (and, for lz4 stores, compressed) it
+    op = _fast_deskew_czyx if str(kw["device"]).startswith("cpu") else _fast_deskew_czyx_device
     _run_positions("deskew", input_position_dirpaths, outs,
-                   lambda s, d: process_single_position(_fast_deskew_czyx, s, d, resume=resume,
+                   lambda s, d: process_single_position(op, s, d, resume=resume,
                                                         resume_token=settings_fingerprint(settings), **kw),
                    Path(output_dirpath).parent)
 

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(const uint8_t* __restri
             fr[2] = (uint8_t)flags;
             fr[3] = (uint8_t)typesize;
             st32(fr + 4, cbytes);
-            st32(fr + 8, blocksize);
+            st32(fr + 8, min(blocksize, cbytes));  // c-blosc refuses a block size beyond the buffer (a chunk smaller than one block)
             st32(fr + 12, fbytes[f]);
         }
         for (uint32_t j = lane; j < nb; j += 64) st32(fr + 16 + 4 * j, bstarts[(uint64_t)f * nb + j]);

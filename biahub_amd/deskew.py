@@ -175,6 +175,23 @@ def _fast_deskew_czyx(data, device="cuda", num_splits=1, **kwargs):
     return to_host(fast_deskew_zyx(t, **kwargs))[None]
 
 
+def _fast_deskew_czyx_device(data, device="cuda", num_splits=1, **kwargs):
+    """``_fast_deskew_czyx`` with the result left ON the GPU: a float32 ``(1, Z', Y', X')`` device tensor instead of a numpy
+    array.  ``io.process_single_position`` recognises device tensors and lets the output store permute and compress them in HBM
+    (``ZarrArray.encode_volume_device``), so a compressed store's bytes cross PCIe once, compressed."""
+    zyx = np.asarray(data)[0]
+    dev = resolve_device(device)
+    if num_splits > 1:
+        chunks = np.array_split(zyx, num_splits, axis=2)
+        results = [fast_deskew_zyx(as_device_volume(np.ascontiguousarray(c), dev)[0], **kwargs) for c in reversed(chunks)]
+        return torch.cat(results, dim=1)[None]
+    t, _, _ = as_device_volume(zyx, dev)
+    return fast_deskew_zyx(t, **kwargs)[None]
+
+
+_fast_deskew_czyx_device.device_resident = True
+
+
 def deskew_zyx(
     raw_data: np.ndarray,
     ls_angle_deg: float,

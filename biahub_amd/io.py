@@ -510,7 +510,14 @@ class ZarrArray:
 
     def write_volume_device(self, t: int, c: int, vol) -> None:
         """Store a device tensor as the (t, c) volume.  For Blosc plane-stack chunks the shuffle runs on the GPU
-        (``bh_blosc_filter``), the download lands in pinned memory and the I/O threads only run the entropy coder."""
+        (``bh_blosc_filter``), with the lz4 inner codec the block codec too (``bh_blosc_lz4_compress``: only compressed frames
+        cross PCIe); the download lands in pinned memory and the I/O threads run the entropy coder (zstd / zlib) or just write."""
+        self.encode_volume_device(t, c, vol)()
+
+    def encode_volume_device(self, t: int, c: int, vol):
+        """The device half of ``write_volume_device``, on the CALLING thread (a ``bh_ctx`` is not thread-safe): permute, compress
+        where the device can, download.  Returns a callable that does the host half — entropy coding where left, file writes —
+        and may run on another thread (``process_single_position`` hands it to its writer thread)."""
         import torch
 
         from . import codecs
@@ -521,15 +528,19 @@ class ZarrArray:
             raise ValueError(f"volume shape {tuple(vol.shape)} does not match array {(Z, Y, X)}")
         plan = self._plane_chunks()
         cfg = self.codecs[0].cfg if self.codecs else {}
+        def host_path():
+            h = to_host(vol) if vol.is_cuda else np.asarray(vol)
+            return lambda: self.write_volume(t, c, h)
+
         if plan is None or not self.codecs or not vol.is_cuda or cfg.get("cname", "zstd") not in ("zstd", "lz4", "zlib") \
                 or codecs.default_blocksize(self.dtype.itemsize) > self.inner[2] * Y * X * self.dtype.itemsize:
-            return self.write_volume(t, c, to_host(vol) if vol.is_cuda else np.asarray(vol))
+            return host_path()
         ct, cc = self.chunks[:2]
         if (ct, cc) != (1, 1) or self.fill_value != 0:
-            return self.write_volume(t, c, to_host(vol))
+            return host_path()
         want = _torch_dtype(self.dtype)
         if want is None:
-            return self.write_volume(t, c, to_host(vol))
+            return host_path()
         v = vol.contiguous()
         if v.dtype != want:
             v = v.to(torch.float32).to(want) if want in (torch.uint16,) else v.to(want)
@@ -563,10 +574,12 @@ class ZarrArray:
                 else:
                     per_file.setdefault(zi, {})[(0, 0, kz, 0, 0)] = blob
 
-            _io_map(put, range(len(plan)))
-            for zi, pieces in per_file.items():
-                self._write_shard(self._chunk_path((t, c, zi, 0, 0)), pieces)
-            return
+            def commit_frames():
+                _io_map(put, range(len(plan)))
+                for zi, pieces in per_file.items():
+                    self._write_shard(self._chunk_path((t, c, zi, 0, 0)), pieces)
+
+            return commit_frames
         host = to_host(dstage)
 
         def one(i):
@@ -578,9 +591,12 @@ class ZarrArray:
             else:
                 per_file.setdefault(zi, {})[(0, 0, kz, 0, 0)] = blob
 
-        _io_map(one, range(len(plan)))
-        for zi, pieces in per_file.items():
-            self._write_shard(self._chunk_path((t, c, zi, 0, 0)), pieces)
+        def commit():
+            _io_map(one, range(len(plan)))
+            for zi, pieces in per_file.items():
+                self._write_shard(self._chunk_path((t, c, zi, 0, 0)), pieces)
+
+        return commit
 
     def __getitem__(self, key) -> np.ndarray:
         if not isinstance(key, tuple):
@@ -903,6 +919,14 @@ def create_empty_plate(store_path, position_keys, channel_names, shape, chunks=N
     _write_group(store, fmt, attrs, version)
 
 
+def _is_device_tensor(x) -> bool:
+    try:
+        import torch
+    except ImportError:  # pragma: no cover
+        return False
+    return isinstance(x, torch.Tensor) and x.is_cuda
+
+
 def process_single_position(func, input_position_path, output_position_path, input_channel_indices=None,
                             output_channel_indices=None, input_time_indices=None, output_time_indices=None,
                             num_workers: int = 1, resume: bool = False, resume_token: str | None = None, **kwargs):
@@ -950,7 +974,10 @@ def process_single_position(func, input_position_path, output_position_path, inp
     def store(u, res):
         if res is not None:
             for c, vol in zip(u[3], res):
-                dst.data.write_volume(u[1], c, vol)
+                if callable(vol):
+                    vol()  # the host half of a device-resident result (encode_volume_device ran on the operator's thread)
+                else:
+                    dst.data.write_volume(u[1], c, vol)
         done[u[4]] = True
         _write_json(done_file, {"token": resume_token, "units": done})
 
@@ -967,9 +994,17 @@ def process_single_position(func, input_position_path, output_position_path, inp
                 call_kw = dict(kwargs)
                 if wants_t:
                     call_kw["input_time_index"] = u[0]
-                res = np.asarray(func(czyx, **call_kw))
-                if res.shape[0] != len(u[3]):
-                    raise ValueError(f"operator returned {res.shape[0]} channels for {len(u[3])} output channels")
+                res = func(czyx, **call_kw)
+                if _is_device_tensor(res):
+                    # an operator marked `device_resident` hands its result over in HBM: permutation and (lz4 stores) block
+                    # codec run on the GPU, on this thread; the writer thread gets the host half
+                    if res.shape[0] != len(u[3]):
+                        raise ValueError(f"operator returned {res.shape[0]} channels for {len(u[3])} output channels")
+                    res = [dst.data.encode_volume_device(u[1], c, res[k]) for k, c in enumerate(u[3])]
+                else:
+                    res = np.asarray(res)
+                    if res.shape[0] != len(u[3]):
+                        raise ValueError(f"operator returned {res.shape[0]} channels for {len(u[3])} output channels")
                 n_run += 1
             pending.append(writer.submit(store, u, res))
             while len(pending) > 2:  # bound the results held in host memory

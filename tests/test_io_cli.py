@@ -225,6 +225,32 @@ def test_cli_deskew_blosc_input_to_ngff05_output(gpu, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_deskew_device_resident_blosc_lz4_store(gpu, tmp_path, monkeypatch):
+    """`BH_ZARR_COMPRESSOR=blosc-lz4`: the deskew result stays in HBM until the output store has bit-shuffled AND lz4-compressed
+    it on the GPU (csrc/lz4.hip); the chunks are ordinary Blosc frames — the host reader (pyarrow's lz4, as numcodecs' c-blosc
+    would) decodes them to the oracle's volume.  Volumes large enough for several 256-KiB blocks per chunk."""
+    src = tmp_path / "in.zarr"
+    shape = (1, 2, 48, 64, 128)
+    data = make_plate(src, positions=(("A", "1", "0"),), shape=shape, compressor="blosc")
+    cfg = tmp_path / "deskew.yml"
+    cfg.write_text(DESKEW_YML)
+    out = tmp_path / "deskewed.zarr"
+    monkeypatch.setenv("BH_ZARR_COMPRESSOR", "blosc-lz4")
+    res = CliRunner().invoke(cli, expand_eat_all(["deskew", "-i", str(src / "A/1/0"), "-c", str(cfg), "-o", str(out), "--cluster", "debug"]))
+    assert res.exit_code == 0, res.output
+    meta = json.loads((out / "A/1/0/0/.zarray").read_text())
+    assert meta["compressor"]["id"] == "blosc" and meta["compressor"]["cname"] == "lz4"
+    got = io.open_ome_zarr(out / "A/1/0")
+    raw_bytes = int(np.prod(got.data.shape)) * 4
+    stored = sum(f.stat().st_size for f in (out / "A/1/0/0").rglob("*") if f.is_file())
+    assert stored < 0.8 * raw_bytes  # the overhang fill alone is half the volume: it really is compressed
+    monkeypatch.setenv("BH_LZ4_DEVICE", "0")  # read back through the host codec only
+    for c in (0, 1):
+        want = O.fast_deskew_zyx(data[("A", "1", "0", 0, c)].astype(np.float32), 36.17, 0.371, True, 3, "mean")
+        assert np.abs(got.data[0, c] - want).max() <= 1e-5 * want.max()
+
+
+@pytest.mark.gpu
 def test_cli_steps_end_to_end(gpu, tmp_path):
     src = tmp_path / "in.zarr"
     shape = (2, 2, 16, 24, 20)

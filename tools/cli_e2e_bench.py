@@ -29,18 +29,29 @@ def du(path):
     return sum(f.stat().st_size for f in Path(path).rglob("*") if f.is_file())
 
 
-for comp, threads in ((None, "1"), (None, ""), ("blosc", "")):
+# "blosc-lz4": iohub-style Blosc input, output store with the lz4 inner codec — the result is permuted AND compressed on the GPU
+# (csrc/lz4.hip), compressed frames cross PCIe, the host only writes files
+for comp, threads in ((None, "1"), (None, ""), ("blosc", ""), ("blosc-lz4", "")):
     out = root / f"out_{comp}_{threads or 'default'}.zarr"
-    src = srcs[comp]
+    src = srcs["blosc" if comp == "blosc-lz4" else comp]
     env = dict(os.environ, BH_IO_THREADS=threads, BH_ZARR_COMPRESSOR=comp or "none")
-    t0 = time.perf_counter()
-    r = subprocess.run([sys.executable, "-m", "biahub_amd", "deskew", "-i", str(src / "A/1/0"), str(src / "A/2/0"), "-c",
-                        str(root / "d.yml"), "-o", str(out), "--cluster", "debug"], env=env, capture_output=True, text=True,
-                       cwd=str(Path(__file__).resolve().parent.parent))
-    dt = time.perf_counter() - t0
-    assert r.returncode == 0, r.stdout + r.stderr
+    def run(positions, dest):
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, "-m", "biahub_amd", "deskew", "-i", *[str(src / p) for p in positions], "-c",
+                            str(root / "d.yml"), "-o", str(dest), "--cluster", "debug"], env=env, capture_output=True, text=True,
+                           cwd=str(Path(__file__).resolve().parent.parent))
+        assert r.returncode == 0, r.stdout + r.stderr
+        return time.perf_counter() - t0
+
+    dt = run(["A/1/0", "A/2/0"], out)
+    # the same command on ONE position (4 volumes): the difference is what 4 more volumes cost once the process is up
+    # (interpreter + torch import + library and plate set-up are ~2 s of every CLI call)
+    dt1 = run(["A/1/0"], root / "one.zarr")
+    shutil.rmtree(root / "one.zarr")
+    marg = max(dt - dt1, 1e-9) / 4
     print(f"deskew CLI, {comp or 'uncompressed'} stores, BH_IO_THREADS={threads or 'default'}: {dt:.2f} s for 8 volumes of {shape[2:]} "
           f"uint16 -> {V / dt / 1e9:.2f} Gvox/s (in {du(src) / 1e9:.1f} GB on disk, out {du(out) / 1e9:.1f} GB on disk, "
-          f"{8 * 342 * 1024 * 1517 * 4 / 1e9:.1f} GB raw)", flush=True)
+          f"{8 * 342 * 1024 * 1517 * 4 / 1e9:.1f} GB raw); 4 volumes {dt1:.2f} s -> marginal {marg:.3f} s per volume = "
+          f"{V / 8 / marg / 1e9:.2f} Gvox/s", flush=True)
     shutil.rmtree(out)
 shutil.rmtree(root)
