@@ -125,13 +125,18 @@ __global__ __launch_bounds__(FF_NT) void median_z_kernel(const TIN* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 8 / 16-bit input (camera data): two-pass byte-radix selection with per-pixel histograms instead of 16 bit sweeps.
+// 8 / 16-bit input (camera data): range-adaptive radix selection with per-pixel histograms instead of 16 bit sweeps.
 // A workgroup owns 128 neighbouring pixels of an image row; lane l of every wave owns pixels 2l and 2l + 1 and counts
 // them in the two 16-bit halves of hist[bin][l] (256 x 64 words = 64 KiB; Z <= 65535 so a half never overflows).  The
-// bank of a counter is its lane, so the LDS atomics are conflict-free whatever the data.  Pass 1 histograms the high
-// byte and finds, per pixel, the bins holding the two middle ranks; pass 2 re-reads the 128 columns (L2 hits) and
-// histograms the low byte of the samples in the first bin (and keeps the smallest low byte of the second bin, for the
-// rare pixel whose two middle samples straddle a bin boundary).
+// bank of a counter is its lane, so the LDS atomics are conflict-free whatever the data.
+//   pass 0 (no atomics): per pixel the smallest and largest key over z -> base mn and shift s = the fewest low bits to drop
+//           so that (key - mn) >> s fits 256 bins.  Camera counts of one pixel along z span a few hundred levels: s = 0.
+//   pass 1: histogram of (key - mn) >> s; per pixel the bins holding the two middle ranks.  With s = 0 a bin IS a value: done —
+//           ONE atomic per sample instead of the two of a fixed high-byte / low-byte split (the pass is bound by its LDS
+//           atomics: ~32 cycles per wave instruction; round 3: 3.8 ms at config-2 size).
+//   pass 2 (only when some pixel of the tile has s > 0; workgroup-uniform): histogram of the dropped low bits of the samples
+//           in the first bin (and the smallest low part of the second bin, for the pixel whose middle samples straddle bins).
+// The re-reads of the 128 columns are L2 hits.
 constexpr int FH_NT = 512, FH_COLS = 128, FH_NW = FH_NT / 64, FH_U = 16;  // 2 workgroups x 8 waves x 16 row loads in flight per CU
 
 template <typename TIN>
@@ -141,6 +146,8 @@ __global__ __launch_bounds__(FH_NT) void median_hist_kernel(const TIN* __restric
     __shared__ __attribute__((aligned(16))) unsigned hist[256 * 64];
     __shared__ unsigned short sb1[FH_COLS], sb2[FH_COLS], sr1[FH_COLS];
     __shared__ unsigned minlo[FH_COLS];
+    __shared__ unsigned wmn[FH_NW][FH_COLS], wmx[FH_NW][FH_COLS];
+    __shared__ int any_shift;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t plane = (size_t)Y * X;
     const int k = (Z - 1) >> 1, k2 = Z >> 1;  // the two middle ranks (equal for odd Z)
@@ -161,8 +168,33 @@ __global__ __launch_bounds__(FH_NT) void median_hist_kernel(const TIN* __restric
         };
         for (int i = threadIdx.x; i < 256 * 16; i += FH_NT) reinterpret_cast<uint4*>(hist)[i] = make_uint4(0, 0, 0, 0);
         if (threadIdx.x < FH_COLS) minlo[threadIdx.x] = 0xffffffffu;
+        if (threadIdx.x == 0) any_shift = 0;
+        // pass 0: range of every pixel
+        unsigned mna = 0xffffffffu, mxa = 0u, mnb = 0xffffffffu, mxb = 0u;
+        for (int z0 = wave; z0 < Z; z0 += FH_NW * FH_U) {
+            unsigned ka[FH_U], kb[FH_U];
+#pragma unroll
+            for (int u = 0; u < FH_U; ++u) load2(min(z0 + FH_NW * u, Z - 1), ka[u], kb[u]);  // clamped rows repeat a sample: harmless here
+#pragma unroll
+            for (int u = 0; u < FH_U; ++u) {
+                mna = min(mna, ka[u]), mxa = max(mxa, ka[u]);
+                mnb = min(mnb, kb[u]), mxb = max(mxb, kb[u]);
+            }
+        }
+        wmn[wave][2 * lane] = mna, wmx[wave][2 * lane] = mxa;
+        wmn[wave][2 * lane + 1] = mnb, wmx[wave][2 * lane + 1] = mxb;
         __syncthreads();
-        // pass 1: high byte
+#pragma unroll
+        for (int w = 0; w < FH_NW; ++w) {
+            mna = min(mna, wmn[w][2 * lane]), mxa = max(mxa, wmx[w][2 * lane]);
+            mnb = min(mnb, wmn[w][2 * lane + 1]), mxb = max(mxb, wmx[w][2 * lane + 1]);
+        }
+        // bits to drop so that the range fits 256 bins (0 for a range below 256)
+        const int sa = max(0, 24 - (int)__builtin_clz((mxa - mna) | 1u)), sb = max(0, 24 - (int)__builtin_clz((mxb - mnb) | 1u));
+        if ((sa | sb) != 0) any_shift = 1;  // benign race: every writer stores 1
+        __syncthreads();
+        const bool refine = any_shift != 0;
+        // pass 1: bins of (key - mn) >> s
         for (int z0 = wave; z0 < Z; z0 += FH_NW * FH_U) {
             unsigned ka[FH_U], kb[FH_U];
 #pragma unroll
@@ -170,8 +202,8 @@ __global__ __launch_bounds__(FH_NT) void median_hist_kernel(const TIN* __restric
 #pragma unroll
             for (int u = 0; u < FH_U; ++u)
                 if (z0 + FH_NW * u < Z) {
-                    atomicAdd(&hist[(ka[u] >> 8) * 64 + lane], 1u);
-                    atomicAdd(&hist[(kb[u] >> 8) * 64 + lane], 0x10000u);
+                    atomicAdd(&hist[((ka[u] - mna) >> sa) * 64 + lane], 1u);
+                    atomicAdd(&hist[((kb[u] - mnb) >> sb) * 64 + lane], 0x10000u);
                 }
         }
         __syncthreads();
@@ -189,46 +221,60 @@ __global__ __launch_bounds__(FH_NT) void median_hist_kernel(const TIN* __restric
                     if (!f2 && cum + n[u] > (unsigned)k2) f2 = true, b2 = b0 + u;
                     cum += n[u];
                 }
+                if (f2) break;  // both ranks placed (k2 >= k)
             }
             sb1[c] = (unsigned short)b1, sb2[c] = (unsigned short)b2, sr1[c] = (unsigned short)r1;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < 256 * 16; i += FH_NT) reinterpret_cast<uint4*>(hist)[i] = make_uint4(0, 0, 0, 0);
         const unsigned a1 = sb1[2 * lane], a2 = sb2[2 * lane], c1 = sb1[2 * lane + 1], c2 = sb2[2 * lane + 1];
-        __syncthreads();
-        // pass 2: low byte of the samples in bin b1; smallest low byte of bin b2 when it is another bin
-        for (int z0 = wave; z0 < Z; z0 += FH_NW * FH_U) {
-            unsigned ka[FH_U], kb[FH_U];
+        if (refine) {  // (workgroup-uniform)
+            for (int i = threadIdx.x; i < 256 * 16; i += FH_NT) reinterpret_cast<uint4*>(hist)[i] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+            // pass 2: dropped low bits of the samples in bin b1; smallest low part of bin b2 when it is another bin
+            const unsigned ma = (1u << sa) - 1u, mb = (1u << sb) - 1u;
+            for (int z0 = wave; z0 < Z; z0 += FH_NW * FH_U) {
+                unsigned ka[FH_U], kb[FH_U];
 #pragma unroll
-            for (int u = 0; u < FH_U; ++u) load2(min(z0 + FH_NW * u, Z - 1), ka[u], kb[u]);
+                for (int u = 0; u < FH_U; ++u) load2(min(z0 + FH_NW * u, Z - 1), ka[u], kb[u]);
 #pragma unroll
-            for (int u = 0; u < FH_U; ++u)
-                if (z0 + FH_NW * u < Z) {
-                    if ((ka[u] >> 8) == a1) atomicAdd(&hist[(ka[u] & 255u) * 64 + lane], 1u);
-                    else if ((ka[u] >> 8) == a2) atomicMin(&minlo[2 * lane], ka[u] & 255u);
-                    if ((kb[u] >> 8) == c1) atomicAdd(&hist[(kb[u] & 255u) * 64 + lane], 0x10000u);
-                    else if ((kb[u] >> 8) == c2) atomicMin(&minlo[2 * lane + 1], kb[u] & 255u);
-                }
+                for (int u = 0; u < FH_U; ++u)
+                    if (z0 + FH_NW * u < Z) {
+                        const unsigned da = ka[u] - mna, db = kb[u] - mnb;
+                        if ((da >> sa) == a1) atomicAdd(&hist[(da & ma) * 64 + lane], 1u);
+                        else if ((da >> sa) == a2) atomicMin(&minlo[2 * lane], da & ma);
+                        if ((db >> sb) == c1) atomicAdd(&hist[(db & mb) * 64 + lane], 0x10000u);
+                        else if ((db >> sb) == c2) atomicMin(&minlo[2 * lane + 1], db & mb);
+                    }
+            }
+            __syncthreads();
+        }
+        // this lane's pixels' base and shift travel to the pixel-owning threads through LDS (wmn / wmx are free again)
+        if (wave == 0) {
+            wmn[0][2 * lane] = mna, wmn[0][2 * lane + 1] = mnb;
+            wmx[0][2 * lane] = (unsigned)sa, wmx[0][2 * lane + 1] = (unsigned)sb;
         }
         __syncthreads();
         if (threadIdx.x < FH_COLS && x0 + (int)threadIdx.x < X) {
             const int c = threadIdx.x, l = c >> 1, sh = (c & 1) * 16;
-            const unsigned b1 = sb1[c], b2 = sb2[c], r1 = sr1[c];
-            unsigned cum = 0, lo1 = 0, lo2 = 0;
-            bool f1 = false, f2 = false;
-            for (int b0 = 0; b0 < 256; b0 += 8) {
-                unsigned n[8];
+            const unsigned b1 = sb1[c], b2 = sb2[c], r1 = sr1[c], mn = wmn[0][c], s = wmx[0][c];
+            unsigned lo1 = 0, lo2 = 0;
+            if (refine) {
+                unsigned cum = 0;
+                bool f1 = false, f2 = false;
+                for (int b0 = 0; b0 < 256; b0 += 8) {
+                    unsigned n[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) n[u] = (hist[(b0 + u) * 64 + l] >> sh) & 0xffffu;
+                    for (int u = 0; u < 8; ++u) n[u] = (hist[(b0 + u) * 64 + l] >> sh) & 0xffffu;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (!f1 && cum + n[u] > r1) f1 = true, lo1 = b0 + u;
-                    if (!f2 && cum + n[u] > r1 + 1) f2 = true, lo2 = b0 + u;  // the next rank, if in the same high-byte bin
-                    cum += n[u];
+                    for (int u = 0; u < 8; ++u) {
+                        if (!f1 && cum + n[u] > r1) f1 = true, lo1 = b0 + u;
+                        if (!f2 && cum + n[u] > r1 + 1) f2 = true, lo2 = b0 + u;  // the next rank, if in the same bin
+                        cum += n[u];
+                    }
                 }
             }
-            const unsigned v1 = (b1 << 8) | lo1;
-            const unsigned v2 = (Z & 1) ? v1 : (b2 == b1 ? ((b1 << 8) | lo2) : ((b2 << 8) | minlo[c]));
+            const unsigned v1 = mn + (b1 << s) + lo1;
+            const unsigned v2 = (Z & 1) ? v1 : (b2 == b1 ? mn + (b1 << s) + lo2 : mn + (b2 << s) + (refine ? minlo[c] : 0u));
             pattern[(size_t)y * X + x0 + c] = (Z & 1) ? K::from(v1) : (K::from(v1) + K::from(v2)) * 0.5;
         }
         __syncthreads();

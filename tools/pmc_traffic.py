@@ -56,15 +56,16 @@ for k, v in col.items():
     it += per_it * (v[1] + v[2]) * 1e9
 # deskew + overhang fill as bh_deskew launches them: the resampling kernel plus every kernel of csrc/deskew_rows.inc and csrc/fill.hip
 # that ran beside it (the conditional mask pipeline moves nothing when the one-pass path took the volume), per deskew call
-dk_key = "deskew_pers_kernel<" if any("deskew_pers_kernel<" in k for k in rows) else "deskew_kernel<"
-n_dk = max(v[0] for k, v in rows.items() if dk_key in k)
+dk_rows = {k: v for k, v in rows.items() if "deskew_pers_kernel<" in k or "deskew_kernel<" in k}
+dk_key = max(dk_rows, key=lambda k: dk_rows[k][1] + dk_rows[k][2])  # the resampling kernel that moved the volume (the conditional one moved nothing)
+n_dk = dk_rows[dk_key][0]
 pair = 0.0
 for k, v in rows.items():
     if any(t in k for t in ("deskew_pers_kernel<", "deskew_kernel<", "rows::", "dilate_", "shell_kernel", "apply_fill_kernel", "finalize_kernel",
                             "mask0_kernel")):
         pair += v[0] / n_dk * (v[1] + v[2]) * 1e9
 rec = {"shape": shape, "unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KiB counters x1024)", "rl_iteration": it, "deskew_pair": pair,
-       "deskew_kernel": max((v[1] + v[2]) * 1e9 for k, v in rows.items() if dk_key in k),
+       "deskew_kernel": (dk_rows[dk_key][1] + dk_rows[dk_key][2]) * 1e9,
        "per_kernel_gb": {k[:60]: round(v[1] + v[2], 3) for k, v in rows.items()},
        "source": f"{prefix}_pmc_hbm_traffic.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of "
                  "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-ops`, summed over the 8 passes of one "
