@@ -193,8 +193,9 @@ def ops_suite(vol, psf, dev, ctx):
     del x
     rec("affine_nearest_f32", lambda: affine_device(vol, M, shape, "nearestneighbor"), _lib.T_AFFINE, 8 * V)
     rec("affine_cubic_f32", lambda: affine_device(vol, M, shape, "cubic", _lib.BOUNDARY_SCIPY_CONSTANT), _lib.T_AFFINE, 8 * V,
-        "SciPy order 3 (Transform.apply(order=3), apply_affine_transform(method='scipy')): three prefilter passes + 64-tap gather; "
-        "bytes by 4 (V_in + V_out) like the other warps, the prefilter's passes are not in the model")
+        "SciPy order 3 (Transform.apply(order=3), apply_affine_transform(method='scipy')): three prefilter passes + 64 taps per "
+        "voxel from LDS-staged source boxes (csrc/spline.hip; bound by vector instructions, not HBM); bytes by 4 (V_in + V_out) "
+        "like the other warps, the prefilter's passes (24 V more) are not in the model")
     v16 = vol.to(torch.uint16)
     rec("affine_linear_u16_in", lambda: affine_device(v16, M, shape, "linear"), _lib.T_AFFINE, 6 * V, "2 V_in + 4 V_out")
     rec("flat_field_u16", lambda: flat_field_device(v16), _lib.T_FLATFIELD, 8 * V, "two 2-byte reads (median, apply) + one f32 write")

