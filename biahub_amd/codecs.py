@@ -473,6 +473,48 @@ def blosc_lz4_decode_blocks_device(frame, out_dev, device=None) -> "BloscHeader"
     return h
 
 
+def blosc_lz4_decode_frames_device(frames, out_dev, out_offsets) -> list["BloscHeader"]:
+    """Several Blosc-lz4 frames in ONE upload and ONE launch of ``bh_lz4_decompress_streams``: frame ``k`` decodes to
+    ``out_dev[out_offsets[k]: out_offsets[k] + header.nbytes]`` (uint8 device tensor, still-permuted bytes).  A volume's chunks
+    decoded one by one keep a few hundred wavefronts busy each and synchronise per chunk; together they fill the device."""
+    import torch
+
+    from . import _lib
+    from .device import get_context, ptr
+
+    if out_dev.dtype != torch.uint8 or not out_dev.is_cuda or not out_dev.is_contiguous():
+        raise ValueError("output must be a contiguous uint8 device tensor")
+    heads, tabs, pos = [], [[], [], [], []], 0
+    sizes = []
+    for fr, o in zip(frames, out_offsets):
+        h, soff, csize, doff, dlen = blosc_lz4_stream_table(fr)
+        if o < 0 or o + h.nbytes > out_dev.numel():
+            raise ValueError("frame does not fit the output tensor")
+        heads.append(h)
+        tabs[0].append(soff + np.uint64(pos))
+        tabs[1].append(csize)
+        tabs[2].append(doff + np.uint64(o))
+        tabs[3].append(dlen)
+        sizes.append(h.cbytes)
+        pos += (h.cbytes + 15) & ~15
+    if not heads:
+        return heads
+    host = torch.empty(pos, dtype=torch.uint8, pin_memory=True)
+    hv, q = host.numpy(), 0
+    for fr, nb in zip(frames, sizes):
+        hv[q:q + nb] = np.frombuffer(memoryview(fr)[:nb], np.uint8)
+        q += (nb + 15) & ~15
+    dev = out_dev.device
+    src = host.to(dev, non_blocking=True)
+    cat = [np.concatenate(t) for t in tabs]
+    dtabs = [torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a.view(np.int32)).to(dev) for a in cat]
+    ctx = get_context(dev)
+    with torch.cuda.device(dev):
+        _lib.check(ctx.lib.bh_lz4_decompress_streams(ctx.handle, ptr(src), ptr(dtabs[0]), ptr(dtabs[1]), ptr(dtabs[2]), ptr(dtabs[3]),
+                                                     int(len(cat[1])), ptr(out_dev)))
+    return heads
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # zarr compressor configurations -> (decode, encode)
 # ---------------------------------------------------------------------------------------------------------------

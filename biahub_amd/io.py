@@ -489,6 +489,9 @@ class ZarrArray:
         dstage = stage.to(dev, non_blocking=True)
         plane = Y * X * self.dtype.itemsize
         tmp = None
+        if frames:  # LZ4 blocks -> permuted bytes on the device (csrc/lz4.hip), in the slots the host decoder would have filled:
+            ks = sorted(frames)  # every chunk of the volume in one upload and one launch
+            codecs.blosc_lz4_decode_frames_device([frames[k] for k in ks], dstage, [k * cbytes for k in ks])
         for i, (zi, kz, z0, iz) in enumerate(plan):
             h = heads[i]
             dst = out8[z0 * plane:min(Z, z0 + iz) * plane]
@@ -497,8 +500,6 @@ class ZarrArray:
                 continue
             mode = codecs.BLOSC_NOSHUFFLE if h.memcpyed else h.shuffle_mode
             src = dstage[i * cbytes:(i + 1) * cbytes]
-            if i in frames:  # LZ4 blocks -> permuted bytes on the device (csrc/lz4.hip), in the slot the host decoder would have filled
-                codecs.blosc_lz4_decode_blocks_device(frames[i], src)
             if dst.numel() == cbytes:
                 codecs.unfilter_device(src, dst, h.blocksize, h.typesize, mode)
             else:  # the last chunk overhangs the array: un-shuffle all of it, keep the planes inside

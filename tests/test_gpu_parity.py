@@ -1703,6 +1703,13 @@ def test_lz4_device_compressor_frames(gpu, dtype, mode):
             assert lib.blosc_decompress_ctx(buf.ctypes.data, back.ctypes.data, back.size, 1) == cbytes, i
             assert np.array_equal(back, c.view(np.uint8)), i
         sizes.append(h.cbytes)
+    # every frame of the "volume" in one upload and one launch (what read_volume_device does)
+    allout = torch.zeros_like(filt)
+    fr = [host[offs[i]: offs[i + 1]].tobytes() for i in range(len(chunks))]
+    hs = codecs.blosc_lz4_decode_frames_device(fr, allout, [i * cbytes for i in range(len(chunks))])
+    assert len(hs) == len(chunks) and torch.equal(allout, filt)
+    with pytest.raises(ValueError, match="fit"):
+        codecs.blosc_lz4_decode_frames_device(fr[:1], allout[: cbytes - 1], [0])
     # (a sine + Poisson noise wrapped into single bytes leaves LZ4 little to match: only the wider types must shrink there)
     assert sizes[0] < (0.8 if ts > 1 else 1.0) * cbytes and sizes[2] < 0.02 * cbytes and sizes[3] < 0.3 * cbytes, sizes
     nb = -(-cbytes // bsz)

@@ -97,5 +97,11 @@ def decode_all():
 
 t, _ = timed(decode_all, reps=3)
 assert torch.equal(back, filt)
-out["kernel_lz4_decompress_frames_incl_upload"] = {"ms": round(t * 1e3, 2), "GBps_out": round(src.numel() / t / 1e9, 1)}
+out["kernel_lz4_decompress_frames_incl_upload"] = {"ms": round(t * 1e3, 2), "GBps_out": round(src.numel() / t / 1e9, 1),
+                                                   "note": "chunk by chunk: one upload, launch and synchronisation per frame"}
+back.zero_()
+t, _ = timed(lambda: codecs.blosc_lz4_decode_frames_device(frames, back, [i * cbytes for i in range(nchunks)]), reps=3)
+assert torch.equal(back, filt)
+out["kernel_lz4_decompress_volume_incl_upload"] = {"ms": round(t * 1e3, 2), "GBps_out": round(src.numel() / t / 1e9, 1),
+                                                   "note": "the volume's frames in one upload and one launch (read_volume_device)"}
 print(json.dumps(out, indent=1))
