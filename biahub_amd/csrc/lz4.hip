@@ -24,9 +24,12 @@ namespace bh {
 namespace lz4 {
 
 constexpr int HASH_LOG = 12, HASH_SIZE = 1 << HASH_LOG;
-constexpr int WAVES = 4;            // wavefronts per workgroup, one block each (4 x 16 KiB of hash tables = the 64 KiB static LDS limit)
+// A table entry is the low 16 bits of a position: a match reaches at most 65535 bytes back, so the candidate is the position
+// with those low bits in the 64 KiB behind the current one (an entry never written reads as "exactly 65536 back": rejected).
+// 8 KiB per table: 8 wavefronts per workgroup (the 64-KiB static limit), 16 per CU — the matcher is a chain of dependent
+// accesses (table, candidate, compare), and with 16-KiB tables the CU held 8 wavefronts to hide them behind.
+constexpr int WAVES = 8;            // wavefronts per workgroup, one block each
 constexpr int MFLIMIT = 12, LASTLITERALS = 5, MINMATCH = 4;
-constexpr unsigned NOPOS = 0xFFFFFFFFu;
 
 __device__ __forceinline__ unsigned ld32(const uint8_t* p) {
     unsigned v;
@@ -52,31 +55,40 @@ __device__ __forceinline__ void put_ext(uint8_t* dst, unsigned len, int lane) { 
 
 // sizes[b] = compressed bytes of block b written at dst + b * slot (== the block's length when it does not shrink: the block
 // is then copied raw, which is how the Blosc container marks a stored block)
-__global__ __launch_bounds__(64 * WAVES) void compress_kernel(const uint8_t* __restrict__ src, uint64_t nbytes, uint32_t blocksize,
+// block b = frame b / nb, block b % nb of that frame: cbytes bytes per frame, the last block of a frame may be short
+__global__ __launch_bounds__(64 * WAVES) void compress_kernel(const uint8_t* __restrict__ src, uint32_t cbytes, uint32_t nb, uint32_t blocksize,
                                                              uint8_t* __restrict__ dst, uint64_t slot, uint32_t* __restrict__ sizes,
                                                              uint32_t nblocks) {
-    __shared__ unsigned table_all[WAVES][HASH_SIZE];
+    __shared__ unsigned short table_all[WAVES][HASH_SIZE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned* table = table_all[wave];
+    unsigned short* table = table_all[wave];
     for (uint32_t b = blockIdx.x * WAVES + wave; b < nblocks; b += gridDim.x * WAVES) {
-        const uint8_t* in = src + (uint64_t)b * blocksize;
-        const unsigned n = (unsigned)min((uint64_t)blocksize, nbytes - (uint64_t)b * blocksize);
+        const uint32_t fr = b / nb, jb = b - fr * nb;
+        const uint8_t* in = src + (uint64_t)fr * cbytes + (uint64_t)jb * blocksize;
+        const unsigned n = min(blocksize, cbytes - jb * blocksize);  // (jb * blocksize < cbytes < 2^32)
         uint8_t* out = dst + (uint64_t)b * slot;
-        for (int i = lane; i < HASH_SIZE; i += 64) table[i] = NOPOS;
+        // (no reset: a stale entry of the previous block is a candidate like any other — it is verified against the bytes)
         unsigned ip = 0, anchor = 0, op = 0;
         bool fits = true;
         const unsigned mflimit = n > MFLIMIT ? n - MFLIMIT : 0;   // a match starts before this position
         const unsigned matchlimit = n > LASTLITERALS ? n - LASTLITERALS : 0;  // and ends at or before this one
+        // the next window's dwords are requested a step ahead (they do not depend on the matching; after a match that ends
+        // beyond the window they are loaded again)
+        unsigned vnext = ip + 64 <= mflimit ? ld32(in + ip + lane) : 0u, pnext = ip;
         while (fits && ip + 64 <= mflimit) {
             const unsigned p = ip + lane;
-            const unsigned v = ld32(in + p);
+            const unsigned v = pnext == ip ? vnext : ld32(in + p);
+            pnext = ip + 64;
+            vnext = pnext + 64 <= mflimit ? ld32(in + pnext + lane) : 0u;
             const unsigned h = (v * 2654435761u) >> (32 - HASH_LOG);
-            const unsigned cand = table[h];
-            table[h] = p;  // reads of the step come before its writes (one wavefront's LDS operations execute in order)
-            // 1 <= p - cand <= 65535: after a short match the window starts again inside positions the table already holds, so a
-            // lane can find ITSELF (or a position ahead of it: the unsigned difference then wraps and fails the test too)
-            bool ok = cand != NOPOS && p - cand - 1u < 65535u;
+            const unsigned e = table[h];
+            table[h] = (unsigned short)p;  // reads of the step come before its writes (one wavefront's LDS operations execute in order)
+            // the position with these low 16 bits in (p - 65536, p]: distance 0 (the lane finds ITSELF: after a short match the
+            // window starts again inside positions the table already holds) and distances beyond the start of the block fail
+            const unsigned dist = (p - e) & 0xffffu;
+            const unsigned cand = p - dist;
+            bool ok = dist != 0u && dist <= p;
             ok = ok && ld32(in + (ok ? cand : 0)) == v;
             // every match of the window is taken in turn: the ballot of this step stays valid for the lanes behind a match's end
             unsigned long long m = __ballot(ok);
@@ -421,15 +433,10 @@ int bh_blosc_lz4_compress(bh_ctx* ctx, const void* src, uint32_t nframes, uint32
     BH_TRY(get_scratch(ctx, "lz4_fbytes", (uint64_t)nframes * 4, (void**)&fbytes));
     hipStream_t s = ctx->stream;
     const int grid = (int)std::min<uint64_t>(((uint64_t)nblocks + lz4::WAVES - 1) / lz4::WAVES, (uint64_t)ctx->num_cus * 2);
-    if (cbytes % blocksize == 0) {
-        hipLaunchKernelGGL(lz4::compress_kernel, dim3(grid), dim3(64 * lz4::WAVES), 0, s, (const uint8_t*)src, (uint64_t)nframes * cbytes,
-                           blocksize, slots, slot, sizes, nblocks);
-    } else {  // every frame ends in a short block: frames one by one
-        for (uint32_t f = 0; f < nframes; ++f)
-            hipLaunchKernelGGL(lz4::compress_kernel, dim3(std::min<int>(grid, (int)((nb + lz4::WAVES - 1) / lz4::WAVES))), dim3(64 * lz4::WAVES), 0,
-                               s, (const uint8_t*)src + (uint64_t)f * cbytes, (uint64_t)cbytes, blocksize, slots + (uint64_t)f * nb * slot, slot,
-                               sizes + (uint64_t)f * nb, nb);
-    }
+    // every block of every frame in one launch (frame by frame, a store with 60-MB chunks kept 30 CUs busy per launch: 35
+    // launches of 5.7 ms for a 2-GB volume)
+    hipLaunchKernelGGL(lz4::compress_kernel, dim3(grid), dim3(64 * lz4::WAVES), 0, s, (const uint8_t*)src, cbytes, (uint32_t)nb, blocksize, slots,
+                       slot, sizes, nblocks);
     hipLaunchKernelGGL(lz4::frame_scan_kernel, dim3(nframes), dim3(256), 0, s, sizes, nb, bstarts, fbytes);
     hipLaunchKernelGGL(lz4::frame_offsets_kernel, dim3(1), dim3(64), 0, s, fbytes, nframes, foff);
     const uint32_t flags = 0x10u | (1u << 5) | (shuffle_mode == BH_BLOSC_SHUFFLE ? 0x1u : (shuffle_mode == BH_BLOSC_BITSHUFFLE ? 0x4u : 0u));

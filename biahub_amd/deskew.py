@@ -179,8 +179,15 @@ def _fast_deskew_czyx_device(data, device="cuda", num_splits=1, **kwargs):
     """``_fast_deskew_czyx`` with the result left ON the GPU: a float32 ``(1, Z', Y', X')`` device tensor instead of a numpy
     array.  ``io.process_single_position`` recognises device tensors and lets the output store permute and compress them in HBM
     (``ZarrArray.encode_volume_device``), so a compressed store's bytes cross PCIe once, compressed."""
-    zyx = np.asarray(data)[0]
     dev = resolve_device(device)
+    if isinstance(data, torch.Tensor):  # already in HBM (io.process_single_position's device read path)
+        zyx = data[0]
+        if num_splits > 1:
+            results = [fast_deskew_zyx(as_device_volume(c.contiguous(), dev)[0], **kwargs)
+                       for c in reversed(torch.tensor_split(zyx, num_splits, dim=2))]
+            return torch.cat(results, dim=1)[None]
+        return fast_deskew_zyx(as_device_volume(zyx, dev)[0], **kwargs)[None]
+    zyx = np.asarray(data)[0]
     if num_splits > 1:
         chunks = np.array_split(zyx, num_splits, axis=2)
         results = [fast_deskew_zyx(as_device_volume(np.ascontiguousarray(c), dev)[0], **kwargs) for c in reversed(chunks)]
@@ -189,7 +196,8 @@ def _fast_deskew_czyx_device(data, device="cuda", num_splits=1, **kwargs):
     return fast_deskew_zyx(t, **kwargs)[None]
 
 
-_fast_deskew_czyx_device.device_resident = True
+_fast_deskew_czyx_device.device_resident = True  # result handed over in HBM
+_fast_deskew_czyx_device.device_input = True     # takes a (C, Z, Y, X) device tensor as well as a numpy array
 
 
 def deskew_zyx(

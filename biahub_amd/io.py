@@ -437,19 +437,33 @@ class ZarrArray:
     def read_volume_device(self, t: int, c: int, device=None):
         """One (t, c) volume as a device tensor.  Blosc chunks are entropy-decoded on the I/O threads into one pinned
         staging block, uploaded still shuffled, and un-shuffled by ``bh_blosc_unfilter`` straight into the volume; other
-        layouts are read on the host and uploaded."""
+        layouts are read on the host and uploaded.  = ``stage_volume`` (host half) + ``upload_staged`` (device half)."""
+        import torch
+
+        from .device import resolve_device, volume_pool
+
+        dev = resolve_device("cuda" if device is None else device)
+        staged = self.stage_volume(t, c)
+        if staged is None:
+            with volume_pool(dev):  # the volume gets the library's page layout (device.volume_pool)
+                return torch.from_numpy(self.read_volume(t, c)).to(dev)
+        return self.upload_staged(staged, dev)
+
+    def stage_volume(self, t: int, c: int):
+        """The HOST half of ``read_volume_device``, safe on any thread (no GPU call): the (t, c) volume's Blosc chunks are read
+        and entropy-decoded on the I/O threads into one pinned staging block, still permuted (lz4 frames stay compressed: their
+        block codec runs on the GPU).  Returns an opaque object for ``upload_staged``, or None when the layout has no device
+        path (not plane-stack Blosc chunks)."""
         import torch
 
         from . import codecs
-        from .device import empty as device_empty, resolve_device, volume_pool
 
-        dev = resolve_device("cuda" if device is None else device)
-        plan = self._plane_chunks()
-        tdt = _torch_dtype(self.dtype)
-        if plan is None or tdt is None or not self.codecs:
-            with volume_pool(dev):  # the volume gets the library's page layout (device.volume_pool)
-                return torch.from_numpy(self.read_volume(t, c)).to(dev)
         T, C, Z, Y, X = self.shape
+        if not (0 <= t < T and 0 <= c < C):
+            raise IndexError(f"(t, c) = ({t}, {c}) outside {self.shape[:2]}")
+        plan = self._plane_chunks()
+        if plan is None or _torch_dtype(self.dtype) is None or not self.codecs:
+            return None
         ct, cc = self.chunks[:2]
         cbytes = self.inner[2] * Y * X * self.dtype.itemsize
         stage = torch.empty(len(plan) * cbytes, dtype=torch.uint8, pin_memory=True)
@@ -484,6 +498,20 @@ class ZarrArray:
             heads[i] = h
 
         _io_map(one, range(len(plan)))
+        return {"stage": stage, "heads": heads, "frames": frames, "plan": plan, "cbytes": cbytes}
+
+    def upload_staged(self, staged, device=None):
+        """The DEVICE half of ``read_volume_device`` (on the thread that owns the GPU context): upload the staging block, decode
+        the LZ4 frames, un-shuffle into the volume.  Returns the (Z, Y, X) device tensor."""
+        import torch
+
+        from . import codecs
+        from .device import empty as device_empty, resolve_device
+
+        dev = resolve_device("cuda" if device is None else device)
+        T, C, Z, Y, X = self.shape
+        tdt = _torch_dtype(self.dtype)
+        stage, heads, frames, plan, cbytes = (staged[k] for k in ("stage", "heads", "frames", "plan", "cbytes"))
         out = device_empty((Z, Y, X), tdt, dev)
         out8 = out.view(torch.uint8).reshape(-1)
         dstage = stage.to(dev, non_blocking=True)
@@ -552,7 +580,21 @@ class ZarrArray:
         bsz = int(cfg.get("blocksize", 0)) or codecs.default_blocksize(ts)
         mode = int(cfg.get("shuffle", codecs.BLOSC_BITSHUFFLE))
         v8 = v.view(torch.uint8).reshape(-1)
+        prof = os.environ.get("BH_PIPE_TIMING") == "2"  # stage seconds of this call on stderr (synchronises between stages)
+        if prof:
+            import sys as _sys
+            import time as _time
+
+            torch.cuda.synchronize(v.device)
+            _tp = [_time.perf_counter()]
+
+            def _mark(name):
+                torch.cuda.synchronize(v.device)
+                _tp.append(_time.perf_counter())
+                print(f"   encode_volume_device {name}: {_tp[-1] - _tp[-2]:.3f} s", file=_sys.stderr, flush=True)
         dstage = torch.empty(len(plan) * cbytes, dtype=torch.uint8, device=v.device)
+        if prof:
+            _mark("(operator's queued work +) staging allocation")
         for i, (zi, kz, z0, _) in enumerate(plan):
             src = v8[z0 * plane:min(Z, z0 + iz) * plane]
             if src.numel() != cbytes:  # the overhanging chunk is padded (fill value 0: all-zero bytes)
@@ -561,15 +603,22 @@ class ZarrArray:
                 src = full
             codecs.filter_device(src, dstage[i * cbytes:(i + 1) * cbytes], bsz, ts, mode)
         per_file: dict = {}
+        if prof:
+            _mark("permutation")
         if cfg.get("cname", "zstd") == "lz4" and cbytes >= 128 and os.environ.get("BH_LZ4_DEVICE", "1") != "0":
             # the block codec runs on the GPU too (csrc/lz4.hip): only the finished frames cross PCIe, the I/O threads just write
             packed, offs = codecs.blosc_lz4_compress_device(dstage, len(plan), cbytes, bsz, ts, mode)
+            if prof:
+                _mark("lz4 + frames")
             hostp = to_host(packed[: offs[-1]])
+            if prof:
+                _mark("download")
 
             def put(i):
                 zi, kz, z0, _ = plan[i]
                 nb = int(np.frombuffer(hostp[offs[i] + 12: offs[i] + 16], np.uint32)[0])  # the frame's own length (header)
-                blob = hostp[offs[i]: offs[i] + nb].tobytes()
+                blob = hostp[offs[i]: offs[i] + nb]  # (a view of the pinned block: a bytes copy of it would hold the GIL for ~0.1 s per frame,
+                # stalling the operator's thread, which runs Python between its GPU calls)
                 if kz is None:
                     self._write_file(self._chunk_path((t, c, zi, 0, 0)), blob)
                 else:
@@ -968,11 +1017,57 @@ def process_single_position(func, input_position_path, output_position_path, inp
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
 
+    import time as _time
+
+    # BH_PIPE_TIMING=1: one line per position on stderr with the seconds each unit spent in each stage (load and store run on
+    # their own threads; wait = the operator's thread idle for the next unit's load)
+    timing = {"load": [], "wait": [], "func": [], "encode": [], "store": []} if os.environ.get("BH_PIPE_TIMING") else None
+
+    # An operator that takes device tensors (`device_input`, e.g. the deskew adapter of the CLI) gets its volumes through the
+    # store's device read path: the reader thread does the host half (file reads + entropy decoding into a pinned block), this
+    # thread the device half (upload, LZ4 blocks, un-shuffle) — the host un-shuffle and the stacking copy drop out of the read.
+    dev_in = None
+    if getattr(func, "device_input", False) and os.environ.get("BH_PIPE_DEVICE_INPUT", "1") != "0":
+        try:
+            import torch as _torch
+
+            if _torch.cuda.is_available() and not str(kwargs.get("device", "cuda")).startswith("cpu"):
+                from .device import resolve_device
+
+                dev_in = resolve_device(kwargs.get("device", "cuda"))
+        except ImportError:
+            dev_in = None
+
     def load(u):
-        vols = [src.data.read_volume(u[0], c) for c in u[2]]
-        return vols[0][None] if len(vols) == 1 else np.stack(vols)  # the common one-channel unit stays in its pinned block
+        t0 = _time.perf_counter()
+        r = None
+        if dev_in is not None:
+            staged = [src.data.stage_volume(u[0], c) for c in u[2]]
+            if all(s_ is not None for s_ in staged):
+                r = ("staged", staged)
+        if r is None:
+            vols = [src.data.read_volume(u[0], c) for c in u[2]]
+            r = vols[0][None] if len(vols) == 1 else np.stack(vols)  # the common one-channel unit stays in its pinned block
+        if timing is not None:
+            timing["load"].append(_time.perf_counter() - t0)
+        return r
+
+    def _all_nan_or_zero(x) -> bool:
+        if isinstance(x, np.ndarray):
+            return _check_nan_n_zeros(x)
+        import torch as _torch
+
+        if x.dtype.is_floating_point:
+            return bool(_torch.isnan(x).all()) or not bool((x != 0).any())
+        return not bool(x.view(_torch.int16 if x.element_size() == 2 else _torch.uint8).any())  # (integer: all zeros)
 
     def store(u, res):
+        t0 = _time.perf_counter()
+        _store(u, res)
+        if timing is not None:
+            timing["store"].append(_time.perf_counter() - t0)
+
+    def _store(u, res):
         if res is not None:
             for c, vol in zip(u[3], res):
                 if callable(vol):
@@ -988,20 +1083,34 @@ def process_single_position(func, input_position_path, output_position_path, inp
         nxt = reader.submit(load, units[0]) if units else None
         pending = deque()
         for i, u in enumerate(units):
+            t0 = _time.perf_counter()
             czyx = nxt.result()
+            t1 = _time.perf_counter()
             nxt = reader.submit(load, units[i + 1]) if i + 1 < len(units) else None
+            if isinstance(czyx, tuple):  # staged volumes: their device half, here
+                import torch as _torch
+
+                vols = [src.data.upload_staged(s_, dev_in) for s_ in czyx[1]]
+                czyx = vols[0][None] if len(vols) == 1 else _torch.stack(vols)
+                del vols
             res = None
-            if not _check_nan_n_zeros(czyx):
+            if not _all_nan_or_zero(czyx):
                 call_kw = dict(kwargs)
                 if wants_t:
                     call_kw["input_time_index"] = u[0]
                 res = func(czyx, **call_kw)
+                t2 = _time.perf_counter()
+                if timing is not None:
+                    timing["wait"].append(t1 - t0)
+                    timing["func"].append(t2 - t1)
                 if _is_device_tensor(res):
                     # an operator marked `device_resident` hands its result over in HBM: permutation and (lz4 stores) block
                     # codec run on the GPU, on this thread; the writer thread gets the host half
                     if res.shape[0] != len(u[3]):
                         raise ValueError(f"operator returned {res.shape[0]} channels for {len(u[3])} output channels")
                     res = [dst.data.encode_volume_device(u[1], c, res[k]) for k, c in enumerate(u[3])]
+                    if timing is not None:
+                        timing["encode"].append(_time.perf_counter() - t2)
                 else:
                     res = np.asarray(res)
                     if res.shape[0] != len(u[3]):
@@ -1012,6 +1121,11 @@ def process_single_position(func, input_position_path, output_position_path, inp
                 pending.popleft().result()
         while pending:
             pending.popleft().result()
+    if timing is not None:
+        import sys as _sys
+
+        print("pipe timing " + str(output_position_path) + ": " + ", ".join(
+            f"{k} " + "/".join(f"{x:.3f}" for x in v) for k, v in timing.items() if v) + " s", file=_sys.stderr, flush=True)
     if extra_metadata:
         merged = dict(dst.zattrs.get("extra_metadata", {}))
         merged.update(extra_metadata)
