@@ -367,15 +367,57 @@ def end_to_end(vol_host_u16, psf, rl, iterations, dev, ctx):
         host = to_host(out)                                    # 4 B/voxel of the deskewed volume, pinned destination
         t3 = time.perf_counter()
         nbytes_out = host.nbytes
-        del out, host, d
-        return t1 - t0, t2 - t1, t3 - t2, nbytes_out
+        del host
+        comp_leg = compressed_unit(out) if measure_compressed else None
+        del out, d
+        return t1 - t0, t2 - t1, t3 - t2, nbytes_out, comp_leg
 
-    once()  # pinned blocks and allocator warm
-    h2d, comp, d2h, nb_out = once()
+    def compressed_unit(out):
+        """The same result leaving as the Blosc-lz4 frames a compressed store takes (csrc/lz4.hip; what
+        ZarrArray.encode_volume_device does for a device-resident result): bit-shuffle + LZ4 + frame assembly on the GPU, then only
+        the frames cross PCIe."""
+        from biahub_amd import codecs
+
+        try:
+            Zo, Yo, Xo = out.shape
+            zc = 16
+            nch = -(-Zo // zc)
+            cbytes = zc * Yo * Xo * 4
+            bsz = codecs.default_blocksize(4)
+            v8 = out.view(torch.uint8).reshape(-1)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            stage = torch.empty(nch * cbytes, dtype=torch.uint8, device=dev)
+            for i in range(nch):
+                src = v8[i * cbytes:(i + 1) * cbytes]
+                if src.numel() != cbytes:  # the overhanging chunk: zero planes behind the volume
+                    full = torch.zeros(cbytes, dtype=torch.uint8, device=dev)
+                    full[: src.numel()] = src
+                    src = full
+                codecs.filter_device(src, stage[i * cbytes:(i + 1) * cbytes], bsz, 4, codecs.BLOSC_BITSHUFFLE)
+            packed, offs = codecs.blosc_lz4_compress_device(stage, nch, cbytes, bsz, 4, codecs.BLOSC_BITSHUFFLE)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            host = to_host(packed[: offs[-1]])
+            t2 = time.perf_counter()
+            nb = int(host.nbytes)
+            del host, packed, stage
+            return {"encode_ms": (t1 - t0) * 1e3, "d2h_ms": (t2 - t1) * 1e3, "frames_bytes": nb, "ratio": nb / (Zo * Yo * Xo * 4.0),
+                    "chunks": nch, "note": "float32 result as Blosc-lz4 frames (bit shuffle, 256-KiB blocks, chunks of 16 planes) made "
+                                           "on the GPU; d2h_ms carries the frames only.  A deconvolved float32 volume has noisy low "
+                                           "mantissa planes: the ratio is what LZ4 finds in the upper ones"}
+        except (RuntimeError, ValueError) as e:
+            return {"skipped": str(e)[:200]}
+
+    measure_compressed = True
+    once()  # pinned blocks, allocator and the codec's scratch warm
+    h2d, comp, d2h, nb_out, comp_leg = once()
     V = vol_host_u16.numel()
     res = {"voxels_per_s": V / (h2d + comp + d2h), "ms": (h2d + comp + d2h) * 1e3, "h2d_ms": h2d * 1e3, "compute_ms": comp * 1e3,
            "d2h_ms": d2h * 1e3, "h2d_GBps": V * 2 / h2d / 1e9, "d2h_GBps": nb_out / d2h / 1e9,
            "note": "uint16 in (pinned) -> float32 deskewed out (pinned); serial, no overlap between positions"}
+    if comp_leg is not None:
+        res["compressed_unit"] = comp_leg
     # the same units through biahub_amd.pipeline.run_overlapped: upload of unit i + 1, compute of unit i and download of unit
     # i - 1 on three streams (what a plate job on one GPU can do; the reference's worker is the serial form above)
     try:
