@@ -81,7 +81,13 @@ def pmc_traffic(key, shape):
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command, fetch doubled for gfx950 as
     MI355X_MICROARCH.md prescribes).  STATIC: collected once per round on the kernels of that round, not during this run
     (counters cannot be read from inside the process); only valid for the shape it was collected on.  -> (bytes, source)"""
-    files = sorted((ROOT / "profiles").glob("r*_pmc_hbm_traffic.json"))
+    def order(f):  # rNN, rNNa .. rNNz, rNNaa ..: round number, then the run's tag in the order the tags were handed out
+        import re
+
+        m = re.match(r"r(\d+)([a-z]*)_", f.name)
+        return (int(m.group(1)), len(m.group(2)), m.group(2)) if m else (-1, 0, "")
+
+    files = sorted((ROOT / "profiles").glob("r*_pmc_hbm_traffic.json"), key=order)
     for f in reversed(files):
         rec = json.load(open(f))
         if list(shape) == rec.get("shape") and rec.get(key):
