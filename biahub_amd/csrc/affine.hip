@@ -485,23 +485,27 @@ __global__ __launch_bounds__(A_NT) void affine_kernel(const TIN* __restrict__ in
 // (through load_clean), so every tap is an LDS read; stores are 64-byte segments.
 // The per-voxel arithmetic is sample_tile's, branch for branch (Q32.32 + lerp8 for linear with an edge clamp, the generic float64
 // path otherwise): results are bit-identical to the tile kernel's.
-#ifndef BH_AFFINE_GY
-#define BH_AFFINE_GY 8  // block rows: 8 (8 z x 8 y x 16 x) or 4 (16 z x 4 y x 16 x: measured 0-7 ms slower per 8.6-GB volume, e.g. 45 deg
-                        // about an oblique axis 22.4 against 15.7 ms: tools/affine_angle_sweep.py)
-#endif
-constexpr int GX = 16, GY = BH_AFFINE_GY, GZL = 256 / (GX * GY), GK = 4;  // lanes along x, y, z and planes per lane: block = GX x GY x (GZL * GK)
-constexpr int GYLOG = GY == 8 ? 3 : 2;
-static_assert(GY == 4 || GY == 8, "BH_AFFINE_GY must be 4 or 8");
-template <typename TIN, int INTERP, int BOUNDARY>
+// Block geometry G: GX x GY lanes of a plane, GZL plane groups of GK planes each (GX * GY * GZL = 256 threads).
+//   G = 0:  8 (z) x 8 (y) x 16 (x)  the round-3 shape
+//   G = 1: 16 (z) x 4 (y) x 32 (x)  twice the voxels on a footprint that is square in the z-x plane: a rotated block's bounding
+//   G = 2: 16 (z) x 8 (y) x 32 (x)  box over-fetches by 1 + (a/b + b/a) sin cos for a block of a x b — least for a = b — and its
+//                                   rows are twice as long for the staging loads (source rows of ~40 instead of ~20 voxels)
+template <int G>
+struct GGeo {
+    static constexpr int GX = G == 0 ? 16 : 32, GY = G == 1 ? 4 : 8, GZL = 256 / (GX * GY), GK = G == 0 ? 4 : (G == 1 ? 8 : 16);
+    static constexpr int BZ = GZL * GK;
+};
+template <typename TIN, int INTERP, int BOUNDARY, int G>
 __global__ __launch_bounds__(256) void affine_gather_kernel(const TIN* __restrict__ in, float* __restrict__ out, AffineParams p,
                                                             int nbx, int nby, int nblocks, int per_xcd) {
+    constexpr int GX = GGeo<G>::GX, GY = GGeo<G>::GY, GZL = GGeo<G>::GZL, GK = GGeo<G>::GK;
     extern __shared__ __attribute__((aligned(16))) float gtile[];
     __shared__ int gorg[3], gext[3];
     const int b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // every XCD walks its own contiguous run of blocks (x fastest)
     if ((int)(blockIdx.x >> 3) >= per_xcd || b >= nblocks) return;
     const int bz = b / (nbx * nby), rem = b - bz * (nbx * nby), byi = rem / nbx, bxi = rem - byi * nbx;
     const int t = threadIdx.x;
-    const int ox = bxi * GX + (t & (GX - 1)), oy = byi * GY + ((t >> 4) & (GY - 1)), ozb = bz * (GZL * GK) + (t >> (4 + GYLOG)) * GK;
+    const int ox = bxi * GX + (t % GX), oy = byi * GY + ((t / GX) % GY), ozb = bz * (GZL * GK) + (t / (GX * GY)) * GK;
     const size_t sY = (size_t)p.Xi, sZ = (size_t)p.Yi * p.Xi;
     // The block's source box (compute_box's bound on the block's own extents), staged in LDS through load_clean when it fits
     // the launch's capacity: a compact block's box is a few thousand voxels at any angle, so every tap comes from LDS and each
@@ -527,10 +531,23 @@ __global__ __launch_bounds__(256) void affine_gather_kernel(const TIN* __restric
     const long gbox = (long)gez * gey * gex;
     const bool staged = gbox > 0 && gbox <= (long)p.lds_floats;
     if (staged) {
+        // the box as a flat list, four loads in flight per thread; i / gex and r / gey by multiply-high with ceil(2^32 / d)
+        // (exact while i * d < 2^32: i < 2^14 here) — two integer divisions per staged voxel cost more than sampling one
         const unsigned nb = (unsigned)gbox, uex = (unsigned)gex, uey = (unsigned)gey;
-        for (unsigned i = t; i < nb; i += 256) {
-            const unsigned r = i / uex, x = i - r * uex, z = r / uey, y = r - z * uey;
-            gtile[i] = load_clean(in + (size_t)(gz0 + (int)z) * sZ + (size_t)(gy0 + (int)y) * sY + (gx0 + (int)x));
+        const unsigned rx = 0xffffffffu / uex + 1u, ry = 0xffffffffu / uey + 1u;
+        const TIN* gbase = in + (size_t)gz0 * sZ + (size_t)gy0 * sY + gx0;
+        for (unsigned i0 = t; i0 < nb; i0 += 1024) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned i = min(i0 + 256u * u, nb - 1u);
+                const unsigned r = uex == 1u ? i : __umulhi(i, rx), x = i - r * uex;
+                const unsigned z = uey == 1u ? r : __umulhi(r, ry), y = r - z * uey;
+                v[u] = load_clean(gbase + ((size_t)z * sZ + (size_t)y * sY + x));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + 256u * u < nb) gtile[i0 + 256u * u] = v[u];
         }
         __syncthreads();
     }
@@ -647,25 +664,28 @@ __global__ __launch_bounds__(256) void affine_gather_kernel(const TIN* __restric
     }
 }
 
-template <typename TIN>
-static int launch_affine_gather(bh_ctx* ctx, const TIN* in, float* out, const AffineParams& p) {
-    const int64_t nbx = ceil_div(p.Xo, GX), nby = ceil_div(p.Yo, GY), nbz = ceil_div(p.Zo, GZL * GK);
+template <typename TIN, int G>
+static int launch_affine_gather_g(bh_ctx* ctx, const TIN* in, float* out, const AffineParams& p) {
+    constexpr int GX = GGeo<G>::GX, GY = GGeo<G>::GY, BZ = GGeo<G>::BZ;
+    const int64_t nbx = ceil_div(p.Xo, GX), nby = ceil_div(p.Yo, GY), nbz = ceil_div(p.Zo, BZ);
     const int64_t nblocks = nbx * nby * nbz;
     BH_REQUIRE(nblocks < (1ll << 31) - 8, "affine output too large");
     const int per_xcd = (int)ceil_div(nblocks, (int64_t)8);
     const int grid = per_xcd * 8;
-    // LDS for the source box of a full block (the bound of bh_affine for the tile kernel, on the block's extents), 48 KiB at
-    // most (three workgroups per CU); blocks whose box is larger gather from global memory
+    // LDS for the source box of a full block (the bound of bh_affine for the tile kernel, on the block's extents): 48 KiB at
+    // most for the small block (three workgroups per CU), 64 KiB for the larger ones (two); blocks whose box is larger gather
+    // from global memory
     AffineParams q = p;
     {
-        const int T[3] = {GZL * GK, GY, GX};
+        const int T[3] = {BZ, GY, GX};
+        const double cap = G == 0 ? 12288.0 : 16384.0;
         double nb = 1.0;
         for (int a = 0; a < 3; ++a) {
             double span = 0.0;
             for (int j = 0; j < 3; ++j) span += std::fabs(p.m[4 * a + j]) * (double)(T[j] - 1);
             nb *= std::floor(span * (1.0 + 1e-6)) + 4.0;
         }
-        q.lds_floats = nb < 12288.0 ? (int)nb : 12288;
+        q.lds_floats = nb < cap ? (int)nb : (int)cap;
     }
     auto run = [&](auto kern) -> int {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), (size_t)q.lds_floats * sizeof(float), ctx->stream, in, out, q, (int)nbx, (int)nby,
@@ -673,7 +693,7 @@ static int launch_affine_gather(bh_ctx* ctx, const TIN* in, float* out, const Af
         BH_CHECK_HIP(hipGetLastError());
         return BH_OK;
     };
-#define BH_AFF(I, B) return run(affine_gather_kernel<TIN, I, B>)
+#define BH_AFF(I, B) return run(affine_gather_kernel<TIN, I, B, G>)
     if (p.interp == BH_INTERP_NEAREST) {
         if (p.boundary == BH_BOUNDARY_ITK) BH_AFF(BH_INTERP_NEAREST, BH_BOUNDARY_ITK);
         if (p.boundary == BH_BOUNDARY_SCIPY_CONSTANT) BH_AFF(BH_INTERP_NEAREST, BH_BOUNDARY_SCIPY_CONSTANT);
@@ -683,6 +703,15 @@ static int launch_affine_gather(bh_ctx* ctx, const TIN* in, float* out, const Af
     if (p.boundary == BH_BOUNDARY_SCIPY_CONSTANT) BH_AFF(BH_INTERP_LINEAR, BH_BOUNDARY_SCIPY_CONSTANT);
     BH_AFF(BH_INTERP_LINEAR, BH_BOUNDARY_ZEROS);
 #undef BH_AFF
+}
+
+template <typename TIN>
+static int launch_affine_gather(bh_ctx* ctx, const TIN* in, float* out, const AffineParams& p) {
+    const char* e = getenv("BH_AFFINE_GBLOCK");  // 0 / 1 / 2: block geometry (GGeo)
+    const int g = e ? atoi(e) : 0;
+    if (g == 1) return launch_affine_gather_g<TIN, 1>(ctx, in, out, p);
+    if (g == 2) return launch_affine_gather_g<TIN, 2>(ctx, in, out, p);
+    return launch_affine_gather_g<TIN, 0>(ctx, in, out, p);
 }
 
 template <typename TIN>
@@ -778,9 +807,11 @@ extern "C" int bh_affine(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, 
         p.lds_floats = nb < (double)cap ? (int)nb : cap;
         // The tile kernel stages every tile whose own box fits and gathers for the others, which it does well as long as a
         // row of 64 x-voxels stays within a few source planes.  The compact-block kernel takes over when a full tile's box
-        // does not fit AND the tile's x extent crosses 4 planes or more (|m_zx| * 63: ~4 degrees about y; measured per angle
-        // and axis by tools/affine_angle_sweep.py — below that, and for z-y coupling at any angle, the tile kernel is faster).
-        const double zx_min = getenv("BH_AFFINE_GATHER_ZX") ? atof(getenv("BH_AFFINE_GATHER_ZX")) : 4.0;
+        // does not fit AND the tile's x extent crosses 2 planes or more (|m_zx| * 63: ~2 degrees about y; measured per angle
+        // and axis by tools/affine_angle_sweep.py, profiles/r04al_affine_angle_sweep.txt — below that, and for z-y coupling
+        // at any angle, the tile kernel is faster; round 3's compact blocks paid two integer divisions per staged voxel and
+        // the threshold was 4).
+        const double zx_min = getenv("BH_AFFINE_GATHER_ZX") ? atof(getenv("BH_AFFINE_GATHER_ZX")) : 2.0;
         box_fits = nb < (double)cap || std::fabs(matrix[2]) * (double)(ATX - 1) < zx_min;
     }
     p.zslot = 0;
