@@ -253,6 +253,28 @@ __device__ __forceinline__ float blend64(const float (&wz)[4], const float (&wy)
     return acc.x + acc.y;
 }
 
+// The 4 x 4 blend of one voxel on a plane whose z taps were combined beforehand (gather_tile_kernel<.., ZUNI>): 8 two-word
+// LDS reads, 13 packed operations.  row(dy) -> the plane's row of tap iy[dy]; ix[] the four x indices within it.
+template <typename RowFn>
+__device__ __forceinline__ float blend16(const float (&wy)[4], const float (&wx)[4], const int (&ix)[4], RowFn row) {
+    f2 ta[4], tb[4];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+        const float* rowp = row(dy);
+        ta[dy] = f2{rowp[ix[0]], rowp[ix[1]]};
+        tb[dy] = f2{rowp[ix[2]], rowp[ix[3]]};
+    }
+    const f2 wa = {wx[0], wx[1]}, wb = {wx[2], wx[3]};
+    f2 az = {0.0f, 0.0f};
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+        const f2 ax = __builtin_elementwise_fma(tb[dy], wb, ta[dy] * wa);
+        const f2 w = {wy[dy], wy[dy]};
+        az = dy == 0 ? ax * w : __builtin_elementwise_fma(ax, w, az);
+    }
+    return az.x + az.y;
+}
+
 // One voxel whose taps come through the vector cache (the fallback of the tile kernel, and the whole of gather_kernel).
 __device__ __forceinline__ float sample_global(const float* __restrict__ coef, const GatherParams& p, double c0, double c1, double c2) {
     // SciPy "constant": a coordinate outside [0, n - 1] gives cval (no interpolation past the edge samples)
@@ -306,12 +328,12 @@ struct GBox {
     unsigned rcp_l, rcp_dy;  // ceil(2^32 / (ext_x / 4)), ceil(2^32 / ext_y): exact small divisions while staging
 };
 
-template <int GTZ, int G_NT>
+template <int GTZ, int G_NT, bool ZUNI>
 __global__ __launch_bounds__(G_NT) void gather_tile_kernel(const float* __restrict__ coef, float* __restrict__ out, GatherParams p,
                                                            int ntx, int nty, int ntiles, int per_xcd, int lds_floats, int x4, int pad32) {
 #pragma clang fp contract(off)
     constexpr int G_NW = G_NT / 64;
-    extern __shared__ float tile[];
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // (16-B: the plane-combining path reads and writes it 16 B wide)
     __shared__ GBox b;
     const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= per_xcd || t >= ntiles) return;
@@ -411,9 +433,82 @@ __global__ __launch_bounds__(G_NT) void gather_tile_kernel(const float* __restri
     __syncthreads();
     const bool interior = staged && b.interior[0] && b.interior[1] && b.interior[2];
     const int ox = ox0 + tx;
+    const int pz = dy * P;  // plane pitch of the box
+    if (ZUNI && staged && (pz & 3) == 0 && b.interior[0] && p.m[0] >= 1.0) {
+        // The matrix leaves z alone (m01 = m02 = 0: shifts, scalings, rotations about z — registration and stabilisation
+        // transforms): every voxel of an output plane has the same four source planes and z weights.  The workgroup combines
+        // them ONCE per output plane, and a voxel is a 4 x 4 blend on the combined plane: 16 taps instead of 64, a third of the
+        // vector instructions.  The combined planes replace the box IN PLACE, without a barrier between planes: a thread owns
+        // 16-B columns of the box and walks the output planes upwards; with m00 >= 1 the first source plane b_k of output plane
+        // k grows strictly, so plane b_k is read by no later output plane and takes the combination of k.  (z-interior tiles
+        // only: no mirrored planes, every plane in range; the other tiles, and matrices that compress z, take the 64-tap path.)
+        for (int q = threadIdx.x; q < (pz >> 2); q += G_NT) {
+            float4* col = reinterpret_cast<float4*>(tile) + q;
+            const int pq = pz >> 2;
+#pragma unroll
+            for (int kz = 0; kz < GTZ; ++kz) {
+                if (oz0 + kz < p.Zo) {
+                    int bz;
+                    float wz[4];
+                    weights3(p.m[0] * (double)(oz0 + kz + p.cz) + p.m[3], bz, wz);
+                    float4* s0 = col + (bz - bz0) * pq;
+                    const float4 a = s0[0], c = s0[pq], e = s0[2 * pq], g = s0[3 * pq];
+                    float4 r;
+                    r.x = __builtin_fmaf(wz[3], g.x, __builtin_fmaf(wz[2], e.x, __builtin_fmaf(wz[1], c.x, wz[0] * a.x)));
+                    r.y = __builtin_fmaf(wz[3], g.y, __builtin_fmaf(wz[2], e.y, __builtin_fmaf(wz[1], c.y, wz[0] * a.y)));
+                    r.z = __builtin_fmaf(wz[3], g.z, __builtin_fmaf(wz[2], e.z, __builtin_fmaf(wz[1], c.z, wz[0] * a.z)));
+                    r.w = __builtin_fmaf(wz[3], g.w, __builtin_fmaf(wz[2], e.w, __builtin_fmaf(wz[1], c.w, wz[0] * a.w)));
+                    s0[0] = r;
+                }
+            }
+        }
+        __syncthreads();
+        if (ox >= p.Xo) return;
+        const bool yx_interior = b.interior[1] && b.interior[2];
+        const double gx = (double)(ox + p.cx);
+        for (int r = wv; r < GTZ * GTY; r += G_NW) {
+            const int oz = oz0 + (r >> 3), oy = oy0 + (r & 7);
+            if (oy >= p.Yo || oz >= p.Zo) continue;
+            const double gz = (double)(oz + p.cz), gy = (double)(oy + p.cy);
+            const double c0 = p.m[0] * gz + p.m[3];  // (+ 0 * gy + 0 * gx)
+            const double c1 = p.m[4] * gz + p.m[5] * gy + p.m[6] * gx + p.m[7];
+            const double c2 = p.m[8] * gz + p.m[9] * gy + p.m[10] * gx + p.m[11];
+            const float* buf = tile + ((int)floor(c0) - 1 - bz0) * pz;  // the combined plane of this output plane
+            float v;
+            if (yx_interior) {
+                int by, bx;
+                float wy[4], wx[4];
+                weights3(c1, by, wy);
+                weights3(c2, bx, wx);
+                const float* q = buf + (by - by0) * P + (bx - bx0);
+                const int ix[4] = {0, 1, 2, 3};
+                v = blend16(wy, wx, ix, [&](int ky) { return q + ky * P; });
+            } else if (!(c1 >= 0.0 && c1 <= (double)(p.Yi - 1) && c2 >= 0.0 && c2 <= (double)(p.Xi - 1))) {
+                v = p.cval;
+            } else {
+                int by, bx;
+                float wy[4], wx[4];
+                weights3(c1, by, wy);
+                weights3(c2, bx, wx);
+                int ix[4], iy[4];
+                bool inbox = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ix[k] = mirror(bx + k, p.Xi) - bx0;
+                    iy[k] = mirror(by + k, p.Yi) - by0;
+                    inbox = inbox && (unsigned)ix[k] < (unsigned)dx && (unsigned)iy[k] < (unsigned)dy;
+                }
+                if (inbox)
+                    v = blend16(wy, wx, ix, [&](int ky) { return buf + iy[ky] * P; });
+                else
+                    v = sample_global(coef, p, c0, c1, c2);
+            }
+            out[((long)oz * p.Yo + oy) * p.Xo + ox] = v;
+        }
+        return;
+    }
     if (ox >= p.Xo) return;
     const double gx = (double)(ox + p.cx);
-    const int pz = dy * P;  // plane pitch of the box
     for (int r = wv; r < GTZ * GTY; r += G_NW) {
         const int oz = oz0 + (r >> 3), oy = oy0 + (r & 7);
         if (oy >= p.Yo || oz >= p.Zo) continue;
@@ -567,6 +662,10 @@ int affine_cubic(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, int64_t 
     const char* pad_env = getenv("BH_SPLINE_PITCH32");  // 0: natural LDS row pitch (the first form; A/B)
     const bool pad32 = !(pad_env && pad_env[0] == '0');
     const bool global_only = force && force[0] == 'g';
+    // a matrix that leaves z alone (and does not compress it) combines the four source planes once per output plane
+    // (gather_tile_kernel<.., ZUNI>)
+    const char* zu_env = getenv("BH_SPLINE_ZUNI");  // 0: the general 64-tap path for every matrix (A/B, parity tests)
+    const bool zuni = matrix[1] == 0.0 && matrix[2] == 0.0 && matrix[0] >= 1.0 && !(zu_env && zu_env[0] == '0');
     int gtz = tz_env && atoi(tz_env) == 4 ? 4 : 8;
     int lds_floats = global_only ? 0 : sp::gather_lds_floats(p, x4, gtz, pad32);
     if (lds_floats == 0 && gtz == 8 && !global_only) {
@@ -578,8 +677,10 @@ int affine_cubic(bh_ctx* ctx, const void* in, int in_dtype, int64_t Zi, int64_t 
     if (lds_floats > 0 && ntiles < (1ll << 30)) {
         const int per_xcd = (int)ceil_div(ntiles, (int64_t)8);
         const size_t lds = (size_t)lds_floats * sizeof(float);
-        auto kern = gtz == 8 ? (nt == 512 ? sp::gather_tile_kernel<8, 512> : sp::gather_tile_kernel<8, 256>)
-                             : (nt == 512 ? sp::gather_tile_kernel<4, 512> : sp::gather_tile_kernel<4, 256>);
+        auto kern = zuni ? (gtz == 8 ? (nt == 512 ? sp::gather_tile_kernel<8, 512, true> : sp::gather_tile_kernel<8, 256, true>)
+                                     : (nt == 512 ? sp::gather_tile_kernel<4, 512, true> : sp::gather_tile_kernel<4, 256, true>))
+                         : (gtz == 8 ? (nt == 512 ? sp::gather_tile_kernel<8, 512, false> : sp::gather_tile_kernel<8, 256, false>)
+                                     : (nt == 512 ? sp::gather_tile_kernel<4, 512, false> : sp::gather_tile_kernel<4, 256, false>));
         if (lds > 64 * 1024)
             BH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(nt == 512 ? 512 : 256), lds, ctx->stream, coef, out, p, (int)ntx, (int)nty,

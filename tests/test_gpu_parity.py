@@ -851,11 +851,22 @@ def test_affine_cubic_tile_gather(gpu, monkeypatch):
         for j, m in enumerate(mats):
             for oshape in (shape, (shape[0] + 3, shape[1] - 2, shape[2] + 17)):
                 monkeypatch.delenv("BH_SPLINE_GATHER", raising=False)
+                monkeypatch.delenv("BH_SPLINE_ZUNI", raising=False)
                 a = affine_device(v, m, oshape, "cubic", _lib.BOUNDARY_SCIPY_CONSTANT, 1.5)
+                monkeypatch.setenv("BH_SPLINE_ZUNI", "0")   # the general 64-tap tile path for matrices that leave z alone too
+                c = affine_device(v, m, oshape, "cubic", _lib.BOUNDARY_SCIPY_CONSTANT, 1.5)
                 monkeypatch.setenv("BH_SPLINE_GATHER", "global")
                 b = affine_device(v, m, oshape, "cubic", _lib.BOUNDARY_SCIPY_CONSTANT, 1.5)
-                assert torch.equal(a, b), (shape, j, oshape)
+                assert torch.equal(c, b), (shape, j, oshape)
+                # z-uniform matrices combine the four source planes first (another order of the same float32 sums)
+                assert float((a - b).abs().max()) <= 3e-6 * float(b.abs().max()), (shape, j, oshape)
     monkeypatch.delenv("BH_SPLINE_GATHER", raising=False)
+    monkeypatch.delenv("BH_SPLINE_ZUNI", raising=False)
+    # the plane-combining path against the float64 oracle: rotation about z + anisotropic scale + shift, volume faces included
+    thz = np.deg2rad(7.0)
+    Mz = np.array([[1.04, 0.0, 0.0, 1.7], [0.0, 1.05 * np.cos(thz), -np.sin(thz), 3.2], [0.0, np.sin(thz), 0.97 * np.cos(thz), -6.1], [0, 0, 0, 1.0]])
+    got = affine_device(vol, Mz, (30, 40, 210), "cubic", _lib.BOUNDARY_SCIPY_CONSTANT, 4.0).cpu().numpy()
+    assert rel_err(got, O.spline_affine_pull(vol, Mz, (30, 40, 210), 4.0)) <= 1e-5
     # identity on the integer grid returns the samples (prefilter and B-spline sampling are inverses)
     v = rng.random((20, 30, 140), dtype=np.float32)
     assert rel_err(affine_device(v, np.eye(4), v.shape, "cubic", _lib.BOUNDARY_SCIPY_CONSTANT).cpu().numpy(), v) <= 2e-6
