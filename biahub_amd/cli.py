@@ -435,21 +435,36 @@ def reconstruct_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, mo
                                      cluster)
 
 
+def _rl_operator(host_op, device_op):
+    """The device-resident adapter on a GPU box (volumes arrive through the store's device read path and leave through its
+    device codec), the numpy one without a GPU or with BH_PIPE_DEVICE_INPUT=0."""
+    import os
+
+    try:
+        import torch
+
+        if torch.cuda.is_available() and os.environ.get("BH_PIPE_DEVICE_INPUT", "1") != "0":
+            return device_op
+    except ImportError:  # pragma: no cover
+        pass
+    return host_op
+
+
 @cli.command("rl-deconvolve")
 @_common
 @_config
 @click.option("--psf-dirpath", "-p", required=True, type=click.Path(exists=True, file_okay=False, path_type=Path))
 def rl_deconvolve_cli(input_position_dirpaths, output_dirpath, sbatch_filepath, monitor, config_filepath, psf_dirpath):
     """Richardson-Lucy deconvolution (north-star extension; same layout as ``deconvolve``)."""
-    from .deconvolve import richardson_lucy_czyx
+    from .deconvolve import richardson_lucy_czyx, richardson_lucy_czyx_device
 
     settings = yaml_to_model(config_filepath, RichardsonLucySettings)
     _same_shape_plate(input_position_dirpaths, output_dirpath, settings.output_ome_zarr_version)
     psf = open_ome_zarr(Path(psf_dirpath, "0/0/0")).data[0, 0]
     outs = get_output_paths(input_position_dirpaths, output_dirpath)
     _run_positions("rl-deconvolve", input_position_dirpaths, outs,
-                   lambda s, d: process_single_position(richardson_lucy_czyx, s, d, psf_zyx=psf,
-                                                        iterations=settings.iterations, eps=settings.eps),
+                   lambda s, d: process_single_position(_rl_operator(richardson_lucy_czyx, richardson_lucy_czyx_device), s, d,
+                                                        psf_zyx=psf, iterations=settings.iterations, eps=settings.eps),
                    Path(output_dirpath).parent)
 
 

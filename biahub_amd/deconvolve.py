@@ -242,6 +242,19 @@ def richardson_lucy_czyx(czyx_raw_data: np.ndarray, psf_zyx: np.ndarray, iterati
     return np.stack([to_host(prep(_f32_device(zyx, dev)[0], iterations, eps)) for zyx in czyx])
 
 
+def richardson_lucy_czyx_device(czyx_raw_data, psf_zyx, iterations: int = 10, eps: float = 1e-6, device="cuda") -> torch.Tensor:
+    """``richardson_lucy_czyx`` with both ends in HBM: takes a numpy array or a ``(C, Z, Y, X)`` device tensor (what
+    ``io.process_single_position`` hands operators marked ``device_input``: the store's device read path) and returns a float32
+    device tensor (``device_resident``: the output store permutes and, for lz4 stores, compresses it on the GPU)."""
+    dev = resolve_device(device)
+    prep = _prepared_rl(psf_zyx, tuple(int(n) for n in czyx_raw_data.shape[-3:]), dev)
+    return torch.stack([prep(_f32_device(zyx, dev)[0], iterations, eps) for zyx in czyx_raw_data])
+
+
+richardson_lucy_czyx_device.device_resident = True
+richardson_lucy_czyx_device.device_input = True
+
+
 # The prepared handle of the PSF `richardson_lucy_czyx` was last called with (a plate job calls it once per (t, c) unit with
 # the same PSF array): keyed like _PREPARED by the identity of the object, its bytes' hash, the volume shape and the device.
 _PREPARED_RL: "dict[tuple, tuple]" = {}

@@ -251,6 +251,40 @@ def test_cli_deskew_device_resident_blosc_lz4_store(gpu, tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("stores", ["blosc-lz4", "raw"])
+def test_cli_rl_deconvolve_device_resident(gpu, tmp_path, monkeypatch, stores):
+    """`rl-deconvolve` with both ends in HBM (deconvolve.richardson_lucy_czyx_device): the volumes arrive through the store's
+    device read path and the estimate leaves through its device codec (Blosc-lz4 output) or a plain download (uncompressed
+    stores: no staged read, numpy in); every (t, c) unit against the oracle; BH_PIPE_DEVICE_INPUT=0 gives the same store."""
+    src = tmp_path / "in.zarr"
+    shape = (1, 2, 24, 32, 64)
+    data = make_plate(src, positions=(("A", "1", "0"),), shape=shape, compressor="blosc" if stores != "raw" else None)
+    psf = np.zeros((5, 5, 5), np.float32)
+    zz, yy, xx = np.ogrid[-2:3, -2:3, -2:3]
+    psf[:] = np.exp(-0.5 * (zz ** 2 / 1.2 ** 2 + yy ** 2 / 0.9 ** 2 + xx ** 2 / 0.9 ** 2))
+    psf /= psf.sum()
+    io.create_empty_plate(tmp_path / "psf.zarr", [("0", "0", "0")], ["PSF"], (1, 1) + psf.shape, chunks=(1, 1) + psf.shape, dtype=np.float32)
+    io.open_ome_zarr(tmp_path / "psf.zarr" / "0/0/0").data[0, 0] = psf
+    cfg = tmp_path / "rl.yml"
+    cfg.write_text("iterations: 4\neps: 1.0e-6\n")
+    if stores != "raw":
+        monkeypatch.setenv("BH_ZARR_COMPRESSOR", stores)
+    outs = []
+    for k, dev_in in enumerate(("1", "0")):
+        monkeypatch.setenv("BH_PIPE_DEVICE_INPUT", dev_in)
+        out = tmp_path / f"rl{k}.zarr"
+        res = CliRunner().invoke(cli, expand_eat_all(["rl-deconvolve", "-i", str(src / "A/1/0"), "-c", str(cfg), "-p", str(tmp_path / "psf.zarr"),
+                                                      "-o", str(out)]))
+        assert res.exit_code == 0, res.output
+        outs.append(io.open_ome_zarr(out / "A/1/0"))
+    for c in (0, 1):
+        want = O.richardson_lucy_zyx(data[("A", "1", "0", 0, c)].astype(np.float32), psf, 4, 1e-6)
+        got = outs[0].data[0, c]
+        assert got.dtype == np.float32 and np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+        assert np.array_equal(got, outs[1].data[0, c])
+
+
+@pytest.mark.gpu
 def test_cli_steps_end_to_end(gpu, tmp_path):
     src = tmp_path / "in.zarr"
     shape = (2, 2, 16, 24, 20)
