@@ -633,7 +633,7 @@ def main():
                 # the PAIR: everything bh_deskew launches for "deskew with a mean fill" — geometry bits, the fill value from the
                 # row sums R-L's last pass left behind, deskew_kernel<..., 2> writing whole rows (fill included), and the
                 # conditional mask pipeline behind it (returns at once unless the data held exact zeros)
-                "kernel": "deskew + overhang fill as one pass: deskew_kernel<float, 64, 4, 3, 256, true, 2> (fused shear-interpolate + "
+                "kernel": "deskew + overhang fill as one pass: deskew_kernel<float, 64, 2, 3, 256, true, 2> (fused shear-interpolate + "
                           "N-mean on LDS-staged tiles, whole rows incl. the fill value; BH_DESKEW_ROWS_KERNEL=pers: the persistent "
                           "double-buffered variant) + csrc/deskew_rows.inc (geometry bits, mean from row sums) + the conditional mask "
                           "pipeline",
