@@ -298,3 +298,88 @@ def test_workspace_rebuild_stress(gpu):
                        env={**os.environ, "BH_ALLOC_VMM_MIN_MB": "64"})
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "0 mismatches" in r.stdout
+
+
+def test_fuzz_cubic_warp_vs_oracle(gpu):
+    """Cubic (SciPy order 3) warp on random shapes and matrices against the float64 oracle: gentle similarities (LDS tiles,
+    interior and face tiles, the plane-combining path when z is left alone), strong rotations and shears (cache launch), output
+    grids larger and smaller than the input, non-zero cval, rows that are / are not 16-B aligned."""
+    from biahub_amd import _lib
+    from biahub_amd.register import affine_device
+
+    rng = np.random.default_rng(314)
+    for case in range(24):
+        shape = (int(rng.integers(1, 28)), int(rng.integers(4, 60)), int(rng.integers(4, 150)))
+        if case % 3 == 0:
+            shape = shape[:2] + (4 * (shape[2] // 4 + 1),)
+        vol = (rng.random(shape) * 200 - 20).astype(np.float32)
+        M = np.eye(4)
+        kind = case % 4
+        if kind == 0:    # leaves z alone: rotation about z, scale >= 1 along z, shifts
+            th = np.deg2rad(rng.uniform(-8, 8))
+            M[:3, :3] = [[rng.uniform(1.0, 1.3), 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]]
+        elif kind == 1:  # gentle general affine
+            M[:3, :3] = np.eye(3) + rng.uniform(-0.06, 0.06, (3, 3))
+        elif kind == 2:  # strong rotation / anisotropic scale
+            a, b = np.deg2rad(rng.uniform(20, 80)), np.deg2rad(rng.uniform(-40, 40))
+            Rz = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+            Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+            M[:3, :3] = Rz @ Ry @ np.diag(rng.uniform(0.6, 1.6, 3))
+        else:            # pure fractional shift (z included)
+            pass
+        ctr = (np.array(shape) - 1) / 2
+        M[:3, 3] = ctr - M[:3, :3] @ ctr + rng.uniform(-3, 3, 3)
+        oshape = tuple(int(max(1, n + rng.integers(-3, 6))) for n in shape)
+        cval = float(rng.uniform(-5, 5))
+        got = affine_device(vol, M, oshape, "cubic", _lib.BOUNDARY_SCIPY_CONSTANT, cval).cpu().numpy()
+        want = O.spline_affine_pull(vol, M, oshape, cval)
+        assert rel_err(got, want) <= 1e-5, (case, shape, oshape)
+
+
+def test_fuzz_lz4_device_codec(gpu):
+    """Random byte streams through the device codec — runs, periodic data with periods up to beyond the decoder's LDS ring and up
+    to the format's 65535-byte reach, noise, ramps, mixed — at typesizes 1 / 2 / 4, with and without shuffles, chunks shorter
+    than a block and with a short last block: GPU frames -> host decoder (pyarrow's lz4) and -> GPU decoder, bytes exact."""
+    from biahub_amd import codecs
+
+    rng = np.random.default_rng(2718)
+
+    def stream(n):
+        parts, left = [], n
+        while left > 0:
+            m = int(min(left, rng.integers(1, 200_000)))
+            k = rng.integers(0, 5)
+            if k == 0:
+                seg = np.full(m, rng.integers(0, 256), np.uint8)
+            elif k == 1:
+                period = int(rng.choice([1, 2, 3, 7, 64, 255, 4096, 12000, 12290, 20000, 65535, 70000]))
+                seg = np.resize(rng.integers(0, 256, period, dtype=np.uint8), m)
+            elif k == 2:
+                seg = rng.integers(0, 256, m, dtype=np.uint8)
+            elif k == 3:
+                seg = (np.arange(m) // int(rng.integers(1, 40))).astype(np.uint8)
+            else:
+                seg = np.where(rng.random(m) < 0.9, 17, rng.integers(0, 256, m)).astype(np.uint8)
+            parts.append(seg)
+            left -= m
+        return np.concatenate(parts)
+
+    for case in range(10):
+        ts = int(rng.choice([1, 2, 4]))
+        mode = int(rng.choice([0, 1, 2])) if ts > 1 else int(rng.choice([0, 2]))
+        nch = int(rng.integers(1, 4))
+        cbytes = ts * int(rng.integers(200, 400_000))
+        raw = stream(nch * cbytes)
+        bsz = codecs.default_blocksize(ts) if case % 2 else int(rng.choice([16384, 65536, 262144]))
+        src = torch.from_numpy(raw).to(gpu)
+        filt = torch.empty_like(src)
+        for i in range(nch):
+            codecs.filter_device(src[i * cbytes:(i + 1) * cbytes], filt[i * cbytes:(i + 1) * cbytes], bsz, ts, mode)
+        packed, offs = codecs.blosc_lz4_compress_device(filt, nch, cbytes, bsz, ts, mode)
+        host = packed[: offs[-1]].cpu().numpy()
+        frames = [host[offs[i]: offs[i + 1]].tobytes() for i in range(nch)]
+        back = torch.empty_like(filt)
+        heads = codecs.blosc_lz4_decode_frames_device(frames, back, [i * cbytes for i in range(nch)])
+        assert torch.equal(back, filt), (case, ts, mode, cbytes, bsz)
+        for i in range(nch):
+            assert np.array_equal(codecs.blosc_decompress(frames[i][: heads[i].cbytes]), raw[i * cbytes:(i + 1) * cbytes]), (case, i)
