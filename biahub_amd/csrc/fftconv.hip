@@ -1165,8 +1165,9 @@ static int launch_col(bh_ctx* ctx, const ConvPlan& pl, int mode, bool zaxis, cf*
     }
     // 384- / 768-point Z passes with a spectral product (the boxes of the deskewed config-4 / config-2 volumes): register stages
     // (BH_FC_COLZ3=0: A/B switch)
+    // (lane offsets are 32-bit: 64 rows of the spectrum must span less than 4 GiB, as for colz_kernel)
     if (zaxis && pl.colz3 && (p.N == 384 || p.N == 768) && (mode == COL_CONV || mode == COL_CORR || mode == COL_FILTER) &&
-        !(getenv("BH_FC_COLZ3") && atoi(getenv("BH_FC_COLZ3")) == 0)) {
+        p.row_stride * 8 * 64 < (1ll << 32) && !(getenv("BH_FC_COLZ3") && atoi(getenv("BH_FC_COLZ3")) == 0)) {
         p.tw = pl.colz3;
         auto run = [&](auto kern, int w, int nt, int lds) -> int {
             p.W = w;
